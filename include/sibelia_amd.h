@@ -1,0 +1,111 @@
+/*
+ * sibelia_amd.h -- C ABI of the MI355X-native BlockFinder hot path (libsibelia_amd.so).
+ *
+ * Drop-in boundary for the reference's SyntenyFinder::BlockFinder (bioinf/Sibelia 3.0.7,
+ * src/blockfinder.h:28-45).  The reference has no FFI layer; these entry points are what a
+ * C++ maintainer binds BlockFinder's methods to (see INTEGRATION.md and
+ * include/sibelia_amd/blockfinder.hpp, which restores the reference's class surface on top).
+ *
+ * Plain pointers and sizes only; no exceptions cross the boundary; every function returns an
+ * sbl_status.  One context per host thread; a context owns one GPU (HIP device) and its own
+ * glibc-compatible rand() stream (the reference consumes the process-global rand(),
+ * src/indexedsequence.cpp:35).
+ *
+ * All compute runs in HIP kernels on the context's device.  There is no CPU fallback:
+ * without a usable gfx950 device sbl_create fails with SBL_ERR_NO_DEVICE.
+ */
+#ifndef SIBELIA_AMD_H
+#define SIBELIA_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbl_ctx sbl_ctx;
+
+typedef enum {
+	SBL_OK = 0,
+	SBL_ERR_BAD_ARG = 1,       /* k < 2 (stage files enforce k >= 2, src/util.cpp:38-41), null pointers, ... */
+	SBL_ERR_NO_DEVICE = 2,     /* no usable HIP device: the product never computes on the host */
+	SBL_ERR_OOM = 3,
+	SBL_ERR_HIP = 4,           /* HIP runtime error, see sbl_last_error */
+	SBL_ERR_TOO_LARGE = 5,     /* a chromosome >= 2^29 bp or total input > 2^30 (src/stranditerator.cpp:19-27, src/common.h:52) */
+	SBL_ERR_UNSUPPORTED = 6,   /* vertex size not supported by this build */
+	SBL_ERR_INTERNAL = 7
+} sbl_status;
+
+/* BlockFinder::State + ProgressCallBack (src/blockfinder.h:31-39): called on the calling thread. */
+typedef enum { SBL_PROGRESS_START = 0, SBL_PROGRESS_RUN = 1, SBL_PROGRESS_END = 2 } sbl_progress_state;
+typedef void (*sbl_progress_fn)(size_t progress, int state, void *user);
+
+/* BifurcationInstance (src/indexedsequence.h:57-68).  Negative-strand `pos` is in reverse-complement
+ * coordinates, exactly as EnumerateBifurcationsSArrayInRAM reports it (src/vertexenumeration.cpp:334-346). */
+typedef struct { uint32_t id, chr, pos; } sbl_inst;
+
+/* BlockFinder::Edge (src/blockfinder.h:58-90) as produced by ListEdges (src/serialization.cpp:56-86). */
+typedef struct {
+	uint32_t chr, strand;            /* strand 0 = positive, 1 = negative */
+	uint32_t start_vertex, end_vertex;
+	uint32_t pos, len;               /* actual position (+ coordinates) and length */
+	uint32_t orig_pos, orig_len;     /* DNASequence::SpellOriginal (src/dnasequence.cpp:254-260) */
+	char first_char;
+	char pad_[3];
+} sbl_edge;
+
+/* Per-stage counters / timings of the last sbl_simplify_stage (seconds are device-event times). */
+typedef struct {
+	uint64_t strand_kmers;           /* N = 2 * sum(max(0, len - k + 1)), the metric's unit */
+	uint64_t bif_count, instances;   /* after enumeration */
+	uint64_t bulges;                 /* return value of PerformGraphSimplifications */
+	uint32_t iterations, rounds;     /* SimplifyGraph iterations run; ordered-commit rounds launched */
+	uint32_t replays;                /* iterations re-run because order validation fired */
+	uint32_t reserved_;
+	double enumerate_ms, simplify_ms, copyback_ms, total_ms;
+	double kmer_table_ms;            /* duration of the dominant kernel (k-mer table build) */
+	uint64_t kmer_table_bytes;       /* its algorithmic HBM bytes */
+} sbl_stage_stats;
+
+/* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).
+ * device < 0 selects the current HIP device. */
+sbl_status sbl_create(sbl_ctx **out, int device);
+void sbl_destroy(sbl_ctx *ctx);
+
+/* Replaces BlockFinder::Init (src/blockfinder.cpp:65-76): sequences are upper-case ASCII as
+ * delivered by the reference FASTA reader (src/fasta.cpp:92-104); originalPos = identity.
+ * Uploads the state to HBM; inputs are borrowed for the call only. */
+sbl_status sbl_load(sbl_ctx *ctx, uint32_t nchr, const uint8_t *const *seq, const uint64_t *len);
+
+/* Replaces IndexedSequence::Init's enumeration (src/indexedsequence.cpp:28-47 ->
+ * src/vertexenumeration.cpp:263-364) on the current state at vertex size k.
+ * Arrays are owned by the ctx, sorted by (chr,pos), valid until the next call on the ctx. */
+sbl_status sbl_enumerate(sbl_ctx *ctx, uint32_t k, uint32_t *bif_count,
+                         const sbl_inst **pos, uint64_t *npos, const sbl_inst **neg, uint64_t *nneg);
+
+/* Replaces BlockFinder::PerformGraphSimplifications (src/blockfinder.cpp:78-98): enumeration,
+ * marking, SimplifyGraph (bulge removal, src/blockfinder.cpp:16-51, src/bulgeremoval.cpp) and
+ * copy-back, all on the device; the state stays resident in HBM. */
+sbl_status sbl_simplify_stage(sbl_ctx *ctx, uint32_t k, uint32_t min_branch_size, uint32_t max_iterations,
+                              sbl_progress_fn progress, void *user, uint64_t *bulges);
+
+/* rawSeq_[chr] / originalPos_[chr] (src/blockfinder.h:52-54), downloaded on demand.
+ * Borrowed pointers, valid until the next mutating call. */
+sbl_status sbl_get_state(sbl_ctx *ctx, uint32_t chr, const uint8_t **seq, const uint32_t **orig_pos, uint64_t *len);
+uint32_t sbl_nchr(const sbl_ctx *ctx);
+
+/* Replaces BlockFinder::ListEdges on a fresh index at k (src/serialization.cpp:56-86), the
+ * observation channel behind SerializeCondensedGraph (src/serialization.cpp:88-110). */
+sbl_status sbl_list_edges(sbl_ctx *ctx, uint32_t k, const sbl_edge **edges, uint64_t *n);
+
+sbl_status sbl_last_stats(const sbl_ctx *ctx, sbl_stage_stats *out);
+const char *sbl_last_error(const sbl_ctx *ctx);
+const char *sbl_strerror(sbl_status s);
+
+/* Tuning knob (0 = default): number of bifurcation ids speculatively committed per ordered round. */
+sbl_status sbl_set_window(sbl_ctx *ctx, uint32_t window);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

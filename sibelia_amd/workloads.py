@@ -1,0 +1,175 @@
+"""Deterministic synthetic genome workloads + minimal FASTA I/O.
+
+Real E. coli genomes are not available offline, so BASELINE.json's E. coli configs
+are exercised with `gen_strains` (uniform random ACGT
+ancestor, 1 % SNPs, one indel per 2000 bp of length U[1,20], three inversions of
+50-200 kbp per strain; numpy `default_rng(seed)`, draws in a fixed order so that the
+n=2 set is a prefix of the n=8 set).  `small_case` produces the tiny randomised
+genomes used for golden-vector parity tests (tests/golden/).
+
+FASTA handling follows the reference reader's observable behaviour
+(reference src/fasta.cpp:23-104): lines are trimmed, sequence letters upper-cased,
+only `ACGTURYKMSWBDHWNX-` accepted, header = text up to the first blank.
+"""
+from __future__ import annotations
+
+import gzip
+import hashlib
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+VALID_CHARS = b"ACGTURYKMSWBDHWNX-"
+
+
+def gen_strains(L0: int = 4_600_000, n: int = 8, seed: int = 1, snp: float = 0.01,
+                indel_every: int = 2000, inversions: int = 3,
+                inv_min: int = 50_000, inv_max: int = 200_000) -> List[bytes]:
+    """n mutated copies of one random ancestor (upper-case ASCII ACGT, one record each)."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, L0, dtype=np.uint8)
+    out = []
+    for _ in range(n):
+        g = anc.copy()
+        m = rng.random(L0) < snp
+        g[m] = (g[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) % 4
+        pieces = []
+        p = 0
+        for q in np.sort(rng.choice(L0, L0 // indel_every, replace=False)):
+            q = int(q)
+            pieces.append(g[p:q])
+            if rng.random() < 0.5:
+                pieces.append(rng.integers(0, 4, int(rng.integers(1, 21)), dtype=np.uint8))
+                p = q
+            else:
+                p = min(L0, q + int(rng.integers(1, 21)))
+        pieces.append(g[p:])
+        g = np.concatenate(pieces)
+        for _ in range(inversions):
+            a = int(rng.integers(0, len(g) - inv_max))
+            b = a + int(rng.integers(inv_min, inv_max))
+            g[a:b] = _COMP[g[a:b][::-1]]
+        out.append(_ACGT[g].tobytes())
+    return out
+
+
+def random_dna(total: int, nrec: int, seed: int) -> List[bytes]:
+    """Uniform random ACGT split into nrec equal records (config 5 style input)."""
+    rng = np.random.default_rng(seed)
+    per = total // nrec
+    return [_ACGT[rng.integers(0, 4, per, dtype=np.uint8)].tobytes() for _ in range(nrec)]
+
+
+def small_case(seed: int) -> Tuple[List[bytes], int, int]:
+    """A tiny randomised multi-record input plus (k, D) chosen to provoke many bulges.
+
+    Mixes: low-complexity / repeated segments, SNPs, indels, inversions, duplicated
+    records, records shorter than k, and (for some seeds) ambiguity codes that the
+    reference replaces through glibc rand() (reference src/indexedsequence.cpp:31-37).
+    """
+    rng = np.random.default_rng(1_000_003 * (seed + 1))
+    k = int(rng.choice([3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 16, 20, 25, 31, 32]))
+    if seed % 11 == 7:
+        k = int(rng.choice([33, 40, 64, 65, 100]))
+    D = int(rng.integers(max(2, k // 2), 12 * k))
+    nrec = int(rng.integers(1, 6))
+    L0 = int(rng.integers(max(40, 3 * k), 2500))
+    alpha = 4 if rng.random() < 0.7 else int(rng.integers(2, 4))
+    anc = rng.integers(0, alpha, L0, dtype=np.uint8)
+    # plant repeats
+    for _ in range(int(rng.integers(0, 4))):
+        if L0 > 4 * k + 10:
+            ln = int(rng.integers(k, min(L0 // 3, 6 * k + 5)))
+            a = int(rng.integers(0, L0 - ln))
+            b = int(rng.integers(0, L0 - ln))
+            seg = anc[a:a + ln].copy()
+            if rng.random() < 0.4:
+                seg = _COMP[seg[::-1]]
+            anc[b:b + ln] = seg
+    recs = []
+    for r in range(nrec):
+        g = anc.copy()
+        rate = float(rng.choice([0.0, 0.005, 0.02, 0.05]))
+        m = rng.random(L0) < rate
+        g[m] = (g[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) % 4
+        pieces = []
+        p = 0
+        nind = int(rng.integers(0, max(1, L0 // 150)))
+        for q in np.sort(rng.choice(L0, nind, replace=False)) if nind else []:
+            q = int(q)
+            if q < p:
+                continue
+            pieces.append(g[p:q])
+            if rng.random() < 0.5:
+                pieces.append(rng.integers(0, 4, int(rng.integers(1, 2 * k + 2)), dtype=np.uint8))
+                p = q
+            else:
+                p = min(L0, q + int(rng.integers(1, 2 * k + 2)))
+        pieces.append(g[p:])
+        g = np.concatenate(pieces)
+        if rng.random() < 0.3 and len(g) > 3 * k:
+            a = int(rng.integers(0, len(g) - 2 * k))
+            b = a + int(rng.integers(k, len(g) - a))
+            g[a:b] = _COMP[g[a:b][::-1]]
+        if rng.random() < 0.15:
+            g = g[: int(rng.integers(1, k + 2))]          # shorter than / around k
+        s = bytearray(_ACGT[g].tobytes())
+        if seed % 5 == 3 and len(s) > 4:
+            for _ in range(int(rng.integers(1, 6))):
+                s[int(rng.integers(0, len(s)))] = int(rng.choice(list(b"NRYKMSWBDHX-U")))
+        recs.append(bytes(s))
+    return recs, k, D
+
+
+# ----------------------------------------------------------------------------- FASTA
+
+def read_fasta(path: str) -> Tuple[List[str], List[bytes]]:
+    opener = gzip.open if path.endswith(".gz") else open
+    names: List[str] = []
+    seqs: List[bytearray] = []
+    with opener(path, "rb") as f:
+        for raw in f:
+            line = raw.strip()
+            if not line:
+                continue
+            if line[:1] == b">":
+                hdr = line[1:].split(b" ")[0]
+                if not hdr:
+                    raise ValueError("empty header")
+                names.append(hdr.decode())
+                seqs.append(bytearray())
+            else:
+                up = line.upper()
+                if up.translate(None, VALID_CHARS):
+                    raise ValueError("illegal character in sequence")
+                if not seqs:
+                    raise ValueError("sequence before header")
+                seqs[-1] += up
+    for s in seqs:
+        if not s:
+            raise ValueError("empty sequence")
+    return names, [bytes(s) for s in seqs]
+
+
+def write_fasta(path: str, seqs: Sequence[bytes], names: Sequence[str] | None = None, width: int = 80) -> None:
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            nm = names[i] if names else "seq%d" % i
+            f.write(b">" + nm.encode() + b"\n")
+            for j in range(0, len(s), width):
+                f.write(s[j:j + width] + b"\n")
+
+
+def input_digest(seqs: Sequence[bytes]) -> str:
+    h = hashlib.sha256()
+    for s in seqs:
+        h.update(len(s).to_bytes(8, "little"))
+        h.update(s)
+    return h.hexdigest()
+
+
+def strand_kmers(seqs: Sequence[bytes], k: int) -> int:
+    """N = 2 * sum(max(0, len - k + 1)): the metric's unit (SURVEY.md §8 notation)."""
+    return 2 * sum(max(0, len(s) - k + 1) for s in seqs)

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/vectors.json from the UNMODIFIED reference (build container only).
+
+Test infrastructure.  Needs /root/reference and a reference build under /tmp/refbuild
+(make_golden.sh creates it with the reference's own CMake, out of tree) plus the
+ref_dump driver (ref_dump.cpp in this directory, linked against the reference's
+object files).  Nothing from the reference is copied into the repo: only inputs
+(generated here, or the two example FASTA sets the reference ships) and the sha256 /
+small literal outputs of the reference run on them are committed.
+
+Each vector = an input + a command list for ref_dump; every command yields one output
+file whose sha256 (and for tiny cases whose bytes) are stored.  Output formats:
+  enum:K          u32 bif_count | per strand: u64 n, n x (u32 id, u32 chr, u32 pos) in (chr,pos) order
+  stage:K:D:ITER  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
+  dot:K           text of BlockFinder::SerializeCondensedGraph(K)
+"""
+import base64, gzip, hashlib, json, os, shutil, struct, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
+sys.path.insert(0, ROOT)
+from sibelia_amd import workloads as W  # noqa: E402
+
+REF_DUMP = "/tmp/refbuild/ref_dump"
+REF = "/root/reference"
+
+
+def run_case(seqs, cmds, keep_bytes=False, timeout=None):
+    d = tempfile.mkdtemp(prefix="gold")
+    try:
+        fa = os.path.join(d, "in.fa")
+        W.write_fasta(fa, seqs)
+        subprocess.run([REF_DUMP, fa, os.path.join(d, "o")] + cmds, check=True,
+                       stderr=subprocess.DEVNULL, timeout=timeout)
+        outs = []
+        for ci, c in enumerate(cmds):
+            p = c.split(":")
+            b = open(os.path.join(d, "o.%d.out" % ci), "rb").read()
+            e = {"cmd": c, "sha256": hashlib.sha256(b).hexdigest(), "size": len(b)}
+            if p[0] == "enum":
+                e["bif_count"] = struct.unpack_from("<I", b, 0)[0]
+                npos = struct.unpack_from("<Q", b, 4)[0]
+                nneg = struct.unpack_from("<Q", b, 12 + 12 * npos)[0]
+                e["instances"] = [npos, nneg]
+            if p[0] == "stage":
+                e["bulges"] = struct.unpack_from("<Q", b, 0)[0]
+            if keep_bytes:
+                e["b64"] = base64.b64encode(b).decode()
+            outs.append(e)
+        return outs
+    finally:
+        shutil.rmtree(d)
+
+
+HAND = {
+    # SURVEY.md Appendix A.1 / A.2 (SNP bulge; indel + N + reverse complement)
+    "snp_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
+               ["enum:5", "dot:5", "stage:5:12:4", "enum:5", "dot:5"]),
+    "indel_N_rc_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC",
+                       "ACGTTGCAAGGCTTATCACGGATCCATGACCTGAATCGTTAGC",
+                       "GCTAACGATTCAGGTCATGGATCCGTNAGCCTTGCAACGT"],
+                      ["dot:5", "stage:5:12:4", "enum:5", "dot:5"]),
+    "palindrome_k4": (["AACGCGTTAGCTAGGATCCTTAATTAAGG", "AACGCGTTAGGTAGGATCCTTAATTCAGG"],
+                      ["enum:4", "stage:4:9:4", "dot:4"]),
+    "tandem_k3": (["ACGACGACGACGTTACGACGACG", "ACGACGACGTTTACGACGACGACG"], ["enum:3", "stage:3:8:4", "dot:3"]),
+    "short_chr_k6": (["ACGTA", "ACGTAC", "ACGTACG", "TTACGTACGGA", "A"], ["enum:6", "stage:6:10:4", "dot:6"]),
+    "identical_k5": (["ACGTTGCATGCCGTAAGCTTGGA"] * 3, ["enum:5", "stage:5:10:4", "dot:5"]),
+    "three_way_k4": (["TTGACCAGTACGGTCAATGCCATAGGCTAAGC", "TTGACCAGTTCGGTCAATGCGATAGGCTAAGC",
+                      "TTGACCAGTGCGGTCAATGCTATAGGCTAAGC", "TTGACCAGTACGGTCAATGCCATAGGCTAAGC"],
+                     ["enum:4", "stage:4:10:4", "dot:4"]),
+    "ambig_codes_k4": (["ACGTNNACGTRYACGTKMACGT-ACGTXACGU", "NACGTTGCAACGTNACGTTGCAAN"],
+                       ["dot:4", "stage:4:8:4", "dot:4", "stage:6:12:2", "dot:6"]),
+    "single_base_iter1": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
+                          ["stage:5:12:1", "stage:5:3:4", "stage:2:4:4", "dot:2"]),
+}
+
+
+def cases(skipped):
+    for name, (seqs, cmds) in HAND.items():
+        yield "hand/" + name, {"kind": "literal", "seqs": seqs}, (lambda seqs=seqs: [x.encode() for x in seqs]), cmds, True, None
+    for seed in range(240):
+        if "small/%03d" % seed in skipped:
+            continue
+        seqs, k, D = W.small_case(seed)
+        k2 = max(2, k // 2) if seed % 3 == 0 else min(2 * k, 130)
+        cmds = ["enum:%d" % k, "stage:%d:%d:4" % (k, D), "dot:%d" % k]
+        if seed % 2 == 0:
+            cmds += ["stage:%d:%d:3" % (k2, 3 * D), "enum:%d" % k2]
+        yield "small/%03d" % seed, {"kind": "small_case", "seed": seed}, (lambda seqs=seqs: seqs), cmds, False, 20
+    hp = "Helicobacter_pylori.fa.gz"
+    sa = "Staphylococcus_aureus_pair.fa.gz"
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    rd = lambda f: (lambda: W.read_fasta(os.path.join(data, f))[1])
+    yield "real/hpylori_k25", {"kind": "fasta", "file": hp}, rd(hp), ["enum:25", "stage:25:150:4", "enum:25", "dot:25"], False, None
+    yield "real/hpylori_fine", {"kind": "fasta", "file": hp}, rd(hp), ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "dot:500"], False, None
+    yield ("real/hpylori_loose", {"kind": "fasta", "file": hp}, rd(hp),
+           ["stage:30:150:4", "stage:100:1000:4", "stage:1000:5000:4", "stage:5000:15000:4", "enum:5000"], False, None)
+    yield "real/saureus_k25", {"kind": "fasta", "file": sa}, rd(sa), ["enum:25", "stage:25:150:4", "enum:25"], False, None
+    small_inv = dict(inv_min=2000, inv_max=9000)
+    synth = [
+        ("synth/strains4_100k", dict(L0=100_000, n=4, seed=7, **small_inv), ["enum:25", "stage:25:150:4", "enum:25", "dot:25"]),
+        ("synth/strains4_100k_fine", dict(L0=100_000, n=4, seed=7, **small_inv),
+         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500"]),
+        ("synth/strains3_400k_k16", dict(L0=400_000, n=3, seed=11, inv_min=5000, inv_max=20000), ["enum:16", "stage:16:120:4", "enum:31"]),
+        ("synth/strains2_4600k", dict(L0=4_600_000, n=2, seed=1), ["enum:25", "stage:25:150:4"]),
+        ("synth/strains8_4600k", dict(L0=4_600_000, n=8, seed=1), ["enum:25", "stage:25:150:4"]),
+    ]
+    for name, kw, cmds in synth:
+        yield name, {"kind": "gen_strains", "args": kw}, (lambda kw=kw: W.gen_strains(**kw)), cmds, False, None
+
+
+def write_real_inputs():
+    """gzip the two example inputs the reference ships (data fixtures, deterministic gzip header)."""
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    os.makedirs(data, exist_ok=True)
+    hp = os.path.join(REF, "examples/Sibelia/Helicobacter_pylori/Helicobacter_pylori.fasta")
+    sa = [os.path.join(REF, "examples/C-Sibelia/Staphylococcus_aureus", f) for f in ("NCTC8325.fasta", "RN4220.fasta")]
+    hp_seqs = W.read_fasta(hp)[1]
+    sa_seqs = []
+    for f in sa:
+        sa_seqs += W.read_fasta(f)[1]
+    for nm, seqs in (("Helicobacter_pylori.fa.gz", hp_seqs), ("Staphylococcus_aureus_pair.fa.gz", sa_seqs)):
+        tmp = os.path.join(data, nm[:-3])
+        W.write_fasta(tmp, seqs)
+        with open(tmp, "rb") as fi, gzip.GzipFile(os.path.join(data, nm), "wb", 9, mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+        os.remove(tmp)
+
+
+def main():
+    """usage: make_golden.py [--only PREFIX ...] [--big]   (without --big the 8-strain vector is not regenerated)"""
+    out = os.path.join(ROOT, "tests", "golden", "vectors.json")
+    old = json.load(open(out)) if os.path.exists(out) else {"vectors": [], "skipped": []}
+    only = [sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--only"]
+    skipped = set(old.get("skipped", []))
+    byname = {v["name"]: v for v in old["vectors"]}
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "data", "Helicobacter_pylori.fa.gz")):
+        write_real_inputs()
+    order = []
+    for name, spec, get, cmds, keep, tmo in cases(skipped):
+        order.append(name)
+        if only and not any(name.startswith(p) for p in only):
+            continue
+        if name == "synth/strains8_4600k" and "--big" not in sys.argv:
+            continue
+        if not only and name in byname and [o["cmd"] for o in byname[name]["outputs"]] == cmds:
+            continue                                   # already present with the same command list
+        seqs = get()
+        try:
+            outs = run_case(seqs, cmds, keep_bytes=keep, timeout=tmo)
+        except subprocess.TimeoutExpired:              # pathological low-complexity case: reference too slow
+            print(name, "skipped (reference > %d s)" % tmo, flush=True)
+            skipped.add(name)
+            continue
+        byname[name] = {"name": name, "input": spec, "input_sha256": W.input_digest(seqs), "outputs": outs}
+        print(name, [(o["cmd"], o.get("bulges"), o.get("bif_count")) for o in outs], flush=True)
+    vec = [byname[n] for n in order if n in byname]
+    json.dump({"reference": "bioinf/Sibelia 3.0.7 (unmodified, built out of tree with its own CMake, g++ 11.4, -O3 -DNDEBUG)",
+               "skipped": sorted(skipped), "vectors": vec}, open(out, "w"), indent=0, separators=(",", ":"))
+    print("wrote", out, len(vec), "vectors")
+
+
+if __name__ == "__main__":
+    main()

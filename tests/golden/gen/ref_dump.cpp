@@ -1,0 +1,101 @@
+// Golden-vector generator (TEST INFRASTRUCTURE, runs only in the build container).
+//
+// This is NOT reference code: it is a small driver that links against the object
+// files of the *unmodified* reference build (out-of-tree under /tmp, see
+// make_golden.sh) and dumps the observable results of the hot path
+//   BlockFinder::PerformGraphSimplifications  (reference src/blockfinder.cpp:78-98)
+//   IndexedSequence enumeration + marking     (reference src/indexedsequence.cpp:28-72)
+//   BlockFinder::SerializeCondensedGraph      (reference src/serialization.cpp:88-110)
+// into flat binary files that make_golden.py turns into committed fixtures.
+//
+// usage: ref_dump <in.fasta> <out-prefix> <cmd>...
+//   cmd = enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+#include "common.h"
+#include "fasta.h"
+#include "dnasequence.h"
+#define private public
+#include "blockfinder.h"
+#undef private
+#include <stdint.h>
+
+const std::string VERSION("golden-dump");
+using namespace SyntenyFinder;
+
+static void put32(FILE *f, uint32_t v) { fwrite(&v, 4, 1, f); }
+static void put64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
+
+static void dump_enum(BlockFinder &bf, size_t k, const std::string &path)
+{
+	IndexedSequence iseq(bf.rawSeq_, k, "");
+	DNASequence &seq = iseq.Sequence();
+	BifurcationStorage &st = iseq.BifStorage();
+	FILE *f = fopen(path.c_str(), "wb");
+	put32(f, (uint32_t)st.GetMaxId());
+	for(size_t strand = 0; strand < 2; strand++)
+	{
+		std::vector<uint32_t> rec;
+		for(size_t chr = 0; chr < seq.ChrNumber(); chr++)
+		{
+			size_t pos = 0;
+			StrandIterator end = seq.End((DNASequence::Direction)strand, chr);
+			for(StrandIterator it = seq.Begin((DNASequence::Direction)strand, chr); it != end; ++it, ++pos)
+			{
+				size_t id = st.GetBifurcation(it);
+				if(id != BifurcationStorage::NO_BIFURCATION)
+				{
+					rec.push_back((uint32_t)id); rec.push_back((uint32_t)chr); rec.push_back((uint32_t)pos);
+				}
+			}
+		}
+		put64(f, rec.size() / 3);
+		if(!rec.empty()) fwrite(&rec[0], 4, rec.size(), f);
+	}
+	fclose(f);
+}
+
+static void dump_state(BlockFinder &bf, uint64_t bulges, const std::string &path)
+{
+	FILE *f = fopen(path.c_str(), "wb");
+	put64(f, bulges);
+	put32(f, (uint32_t)bf.rawSeq_.size());
+	for(size_t chr = 0; chr < bf.rawSeq_.size(); chr++)
+	{
+		put64(f, bf.rawSeq_[chr].size());
+		fwrite(bf.rawSeq_[chr].data(), 1, bf.rawSeq_[chr].size(), f);
+		if(!bf.originalPos_[chr].empty()) fwrite(&bf.originalPos_[chr][0], 4, bf.originalPos_[chr].size(), f);
+	}
+	fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+	if(argc < 4) { fprintf(stderr, "usage\n"); return 2; }
+	std::vector<FASTARecord> chrList;
+	FASTAReader reader(argv[1]);
+	if(!reader.IsOk()) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+	reader.GetSequences(chrList);
+	std::string prefix(argv[2]);
+	BlockFinder finder(chrList);
+	for(int a = 3; a < argc; a++)
+	{
+		unsigned k = 0, d = 0, it = 0;
+		char buf[64]; sprintf(buf, ".%d.out", a - 3);      // one output file per command, in order
+		if(sscanf(argv[a], "enum:%u", &k) == 1)
+		{
+			dump_enum(finder, k, prefix + buf);
+		}
+		else if(sscanf(argv[a], "stage:%u:%u:%u", &k, &d, &it) == 3)
+		{
+			size_t bulges = finder.PerformGraphSimplifications(k, d, it);
+			dump_state(finder, bulges, prefix + buf);
+			fprintf(stderr, "stage k=%u D=%u iter=%u -> bulges=%zu\n", k, d, it, bulges);
+		}
+		else if(sscanf(argv[a], "dot:%u", &k) == 1)
+		{
+			std::ofstream out((prefix + buf).c_str());
+			finder.SerializeCondensedGraph(k, out);
+		}
+		else { fprintf(stderr, "bad cmd %s\n", argv[a]); return 2; }
+	}
+	return 0;
+}
