@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's BlockFinder surface over the C ABI (include/sibelia_amd.h).
+
+`BlockFinder` keeps the reference's method names and argument meaning
+(reference src/blockfinder.h:40-45): PerformGraphSimplifications(k, minBranchSize, maxIterations, f),
+SerializeCondensedGraph(k, out), plus the enumeration / state accessors the parity tests need.
+All compute happens in libsibelia_amd.so's HIP kernels; importing this module without the
+built library, or constructing a BlockFinder without a GPU, fails loudly -- there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import formats
+from .build import LIB
+
+INST_DTYPE = np.dtype([("id", "<u4"), ("chr", "<u4"), ("pos", "<u4")])
+EDGE_DTYPE = formats.EDGE_DTYPE
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
+
+EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
+           "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window"]
+
+
+class StageStats(C.Structure):
+    _fields_ = [("strand_kmers", C.c_uint64), ("bif_count", C.c_uint64), ("instances", C.c_uint64), ("bulges", C.c_uint64),
+                ("iterations", C.c_uint32), ("rounds", C.c_uint32), ("replays", C.c_uint32), ("reserved_", C.c_uint32),
+                ("enumerate_ms", C.c_double), ("simplify_ms", C.c_double), ("copyback_ms", C.c_double), ("total_ms", C.c_double),
+                ("kmer_table_ms", C.c_double), ("kmer_table_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved_"}
+
+
+class SibeliaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsibelia_amd.so (built in-tree by sibelia_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise SibeliaError("libsibelia_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is mandatory, there is no host fallback)")
+        L = C.CDLL(LIB)
+        L.sbl_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.sbl_destroy.argtypes = [C.c_void_p]
+        L.sbl_destroy.restype = None
+        L.sbl_load.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+        L.sbl_enumerate.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.sbl_simplify_stage.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sbl_get_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.sbl_nchr.argtypes = [C.c_void_p]
+        L.sbl_nchr.restype = C.c_uint32
+        L.sbl_list_edges.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.sbl_last_stats.argtypes = [C.c_void_p, C.POINTER(StageStats)]
+        L.sbl_last_error.argtypes = [C.c_void_p]
+        L.sbl_last_error.restype = C.c_char_p
+        L.sbl_strerror.argtypes = [C.c_int]
+        L.sbl_strerror.restype = C.c_char_p
+        L.sbl_set_window.argtypes = [C.c_void_p, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _view(ptr, n, dtype):
+    if not n:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class BlockFinder:
+    """SyntenyFinder::BlockFinder for the hot path, backed by one MI355X.
+
+    seqs: upper-case sequences as delivered by the reference FASTA reader (one per FASTARecord)."""
+
+    def __init__(self, seqs: Sequence[bytes], device: int = -1):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.sbl_create(C.byref(self.h), device)
+        if rc:
+            raise SibeliaError("sbl_create: " + self.L.sbl_strerror(rc).decode())
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*[bytes(s) for s in seqs])
+        lens = (C.c_uint64 * n)(*[len(s) for s in seqs])
+        self._check(self.L.sbl_load(self.h, n, arr, lens), "sbl_load")
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self.L.sbl_last_error(self.h).decode() if self.h else ""
+            raise SibeliaError("%s: %s (%s)" % (what, self.L.sbl_strerror(rc).decode(), msg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sbl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference surface ---------------------------------------------------------------
+    def PerformGraphSimplifications(self, k: int, minBranchSize: int, maxIterations: int,
+                                    f: Optional[Callable[[int, int], None]] = None) -> int:
+        b = C.c_uint64()
+        cb = PROGRESS_FN(lambda p, s, u: f(p, s)) if f else None
+        rc = self.L.sbl_simplify_stage(self.h, k, minBranchSize, maxIterations, C.cast(cb, C.c_void_p) if cb else None, None, C.byref(b))
+        self._check(rc, "sbl_simplify_stage")
+        return b.value
+
+    def SerializeCondensedGraph(self, k: int, out) -> None:
+        out.write(formats.dot_text(self.list_edges(k)).decode("latin1"))
+
+    # ---- backend protocol shared with the oracle wrapper (tests/vectors.py) ------------------
+    def enumerate(self, k: int) -> Tuple[int, np.ndarray, np.ndarray]:
+        bc = C.c_uint32()
+        p, q = C.c_void_p(), C.c_void_p()
+        n, m = C.c_uint64(), C.c_uint64()
+        self._check(self.L.sbl_enumerate(self.h, k, C.byref(bc), C.byref(p), C.byref(n), C.byref(q), C.byref(m)), "sbl_enumerate")
+        return bc.value, _view(p.value, n.value, INST_DTYPE), _view(q.value, m.value, INST_DTYPE)
+
+    def simplify_stage(self, k: int, min_branch: int, max_iter: int) -> int:
+        return self.PerformGraphSimplifications(k, min_branch, max_iter)
+
+    def state(self) -> Tuple[List[bytes], List[np.ndarray]]:
+        seqs, pos = [], []
+        for c in range(self.L.sbl_nchr(self.h)):
+            s, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+            self._check(self.L.sbl_get_state(self.h, c, C.byref(s), C.byref(p), C.byref(n)), "sbl_get_state")
+            seqs.append(_view(s.value, n.value, np.dtype("u1")).tobytes())
+            pos.append(_view(p.value, n.value, np.dtype("<u4")))
+        return seqs, pos
+
+    def list_edges(self, k: int) -> np.ndarray:
+        e, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.sbl_list_edges(self.h, k, C.byref(e), C.byref(n)), "sbl_list_edges")
+        return _view(e.value, n.value, EDGE_DTYPE)
+
+    def stats(self) -> dict:
+        s = StageStats()
+        self.L.sbl_last_stats(self.h, C.byref(s))
+        return s.as_dict()
+
+    def set_window(self, w: int) -> None:
+        self.L.sbl_set_window(self.h, w)

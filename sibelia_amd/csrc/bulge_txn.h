@@ -1,0 +1,654 @@
+// bulge_txn.h -- one bifurcation id's bulge removal as a device "transaction".
+//
+// Replaces BlockFinder::RemoveBulges and everything it calls
+//   (reference src/bulgeremoval.cpp:39-430, src/bifurcationstorage.cpp:113-162, src/dnasequence.cpp:189-252)
+// on a GPU-resident graph:
+//   * the editable sequence is an index-linked list over flat HBM arrays (stable element identity,
+//     O(1) insert/erase) instead of the reference's unrolled list;
+//   * bifurcation marks are two dense arrays bif[strand][element] instead of an address-keyed hash set;
+//   * per-(strand,id) instance lists are index-linked nodes with front insertion and lazy erase,
+//     which is the order the reference's slist produces (bifurcationstorage.cpp:122,144-155);
+//   * the iteration order of the reference's boost::unordered_map in AnyBulges is reproduced by a
+//     fixed-capacity restatement of Boost 1.54's bucket list (bulgeremoval.cpp:168,203-215).
+//
+// One GPU thread executes one transaction; thousands run per launch (simplify.hip).  The functions
+// are __host__ __device__ so that tests/hostsim can unit-test this exact code without a GPU; the
+// shipped library only ever calls them from kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BT_NONE 0xFFFFFFFFu
+#define BT_SEP '$'
+#define BT_DEAD_CHAR 0            // ch[] of an element that was erased from the list
+#define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
+#define BT_BLOCK_SHIFT 5          // validation granularity: 32 element slots
+
+enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
+       CTR_BIG = 8, CTR_PUSHED = 9, CTR_COUNT = 16 };
+enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
+
+struct GraphView {
+	uint8_t *ch; uint32_t *op, *nx, *pv;
+	uint32_t *bif[2], *nodeof[2];
+	uint32_t *nslot, *nnext, *nclr; uint8_t *ndead;   // nclr: chain of nodes erased by the running transaction
+	uint32_t *head[2], *lsize[2];
+	uint32_t *ctr;
+	uint32_t cap_e, cap_n;
+	uint32_t k, D, nid;                 // ids 0 .. nid-1
+	uint8_t *need;                      // need[id] != 0: RemoveBulges(id) must run at its turn
+	uint8_t *big;                       // big[id] != 0: needs the large scratch arena (runs alone)
+	// reservation (ordered-commit rounds) and order validation, see simplify.hip
+	uint32_t *own;                      // per id: round-stamped owner (atomicMin)
+	uint32_t *lock, *rmax, *wmax;       // per resource: blocks [0,nblk) then ids [nblk, nblk+nid]
+	uint32_t nblk;
+	uint32_t round_bits;                // (ROUND_MAX - round) << 20
+	const uint32_t *win;                // ids of the current window
+};
+
+// ------------------------------------------------------------------------------------------- atomics (host + device)
+__host__ __device__ __forceinline__ uint32_t bt_atomic_add(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+__host__ __device__ __forceinline__ uint32_t bt_atomic_min(uint32_t *p, uint32_t v) { return __atomic_fetch_min(p, v, __ATOMIC_RELAXED); }
+__host__ __device__ __forceinline__ uint32_t bt_atomic_max(uint32_t *p, uint32_t v) { return __atomic_fetch_max(p, v, __ATOMIC_RELAXED); }
+__host__ __device__ __forceinline__ uint32_t bt_atomic_or(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+// ------------------------------------------------------------------------------------------- strand iterators
+struct SIt { uint32_t e; uint32_t d; };   // element + direction (0 positive, 1 negative); reference src/stranditerator.cpp
+
+__host__ __device__ __forceinline__ char bt_comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; }
+
+struct Txn {
+	GraphView g;
+	uint32_t id, stamp;                 // stamp = round_bits | window index
+	uint32_t tid;                       // id + 1, the value written to rmax / wmax
+	// 0: no validation (snapshot verdicts, solo runs)
+	// 1: read-only pass of a round: exclusive block locks + "nothing I read was written by a higher id"
+	// 2: writer pass: additionally publishes its reads / writes in rmax / wmax
+	uint32_t mode;
+	uint32_t last_r, last_w;            // one-entry caches of the last stamped blocks
+	uint8_t *scr; uint32_t scr_cap, scr_used;
+	uint32_t err;
+	uint32_t tc_head;                   // lazy erase chain (BifurcationStorage::toClear_), linked through g.nclr
+	bool wrote;                         // the graph has been modified by this transaction
+
+	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
+	{
+		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; err = 0; tc_head = BT_NONE; wrote = false;
+	}
+	// ---- scratch
+	__host__ __device__ void *alloc(uint32_t bytes)
+	{
+		uint32_t a = (scr_used + 7u) & ~7u;
+		if (a + bytes > scr_cap || a + bytes < a) { err |= BT_ERR_SCRATCH; return nullptr; }
+		scr_used = a + bytes;
+		return scr + a;
+	}
+	// ---- order validation (simplify.hip explains the protocol)
+	__host__ __device__ void violation(uint32_t other_prio)
+	{
+		uint32_t x = id;
+		if (other_prio != BT_NONE && g.win) { uint32_t o = g.win[other_prio]; if (o < x) x = o; }
+		bt_atomic_min(&g.ctr[CTR_VIOL], x);
+	}
+	__host__ __device__ void stamp_res(uint32_t r, bool write)
+	{
+		uint32_t old = bt_atomic_min(&g.lock[r], stamp);
+		if (old != stamp && (old >> 20) == (stamp >> 20)) violation(old & 0xFFFFFu);   // two transactions of one round share r
+		if (mode == 1) { if (g.wmax[r] > tid) violation(BT_NONE); return; }
+		if (write) {
+			uint32_t a = bt_atomic_max(&g.wmax[r], tid);
+			if (a > tid || g.rmax[r] > tid) violation(BT_NONE);
+		} else {
+			bt_atomic_max(&g.rmax[r], tid);
+			if (g.wmax[r] > tid) violation(BT_NONE);
+		}
+	}
+	__host__ __device__ __forceinline__ void tr(uint32_t e)     // element read
+	{
+		if (!mode) return;
+		uint32_t b = e >> BT_BLOCK_SHIFT;
+		if (b == last_r || b == last_w) return;
+		last_r = b; stamp_res(b, false);
+	}
+	__host__ __device__ __forceinline__ void tw(uint32_t e)     // element write
+	{
+		wrote = true;
+		if (!mode) return;
+		uint32_t b = e >> BT_BLOCK_SHIFT;
+		if (b == last_w) return;
+		last_w = b; stamp_res(b, true);
+	}
+	__host__ __device__ __forceinline__ void ir(uint32_t b) { if (mode) stamp_res(g.nblk + b, false); }   // id (list / count) read
+	__host__ __device__ __forceinline__ void iw(uint32_t b) { if (mode) stamp_res(g.nblk + b, true); }
+
+	// ---- iterator primitives
+	__host__ __device__ __forceinline__ SIt next(SIt a) { tr(a.e); a.e = a.d ? g.pv[a.e] : g.nx[a.e]; return a; }     // operator++ :117-130
+	__host__ __device__ __forceinline__ SIt adv(SIt a, uint32_t n) { while (n--) a = next(a); return a; }
+	__host__ __device__ __forceinline__ SIt inv(SIt a)                                                                // Invert :192-200
+	{ tr(a.e); SIt r; if (a.d == 0) { r.e = g.pv[a.e]; r.d = 1; } else { r.e = g.nx[a.e]; r.d = 0; } return r; }
+	__host__ __device__ __forceinline__ char chr(SIt a) { tr(a.e); char c = (char)g.ch[a.e]; return a.d ? bt_comp(c) : c; }   // operator* :202-210
+	__host__ __device__ __forceinline__ bool valid(SIt a) { tr(a.e); return g.ch[a.e] != BT_SEP; }                     // AtValidPosition :97-100
+	__host__ __device__ __forceinline__ uint32_t getbif(SIt a) { tr(a.e); return g.bif[a.d][a.e]; }                    // GetBifurcation, bifurcationstorage.cpp:157
+
+	// a changed instance list makes that id's verdict stale: it must (re)run at its turn in this iteration
+	__host__ __device__ __forceinline__ void push_dirty(uint32_t b)
+	{ if (b > id && b < g.nid) g.need[b] = 1; }
+
+	// AddPoint, bifurcationstorage.cpp:113-126
+	__host__ __device__ void add_point(SIt a, uint32_t b)
+	{
+		tr(a.e);
+		if (g.bif[a.d][a.e] != BT_NONE || b == BT_NONE) return;
+		uint32_t nd = bt_atomic_add(&g.ctr[CTR_NN], 1u);
+		if (nd >= g.cap_n) { err |= BT_ERR_NODE_CAP; return; }
+		tw(a.e); iw(b);
+		g.nslot[nd] = a.e; g.ndead[nd] = 0;
+		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
+		g.lsize[a.d][b]++;
+		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
+		push_dirty(b);
+	}
+	// ErasePoint, bifurcationstorage.cpp:144-155 (physical removal deferred to cleanup())
+	__host__ __device__ void erase_point(SIt a)
+	{
+		tr(a.e);
+		uint32_t b = g.bif[a.d][a.e];
+		if (b == BT_NONE) return;
+		tw(a.e); iw(b);
+		uint32_t nd = g.nodeof[a.d][a.e];
+		g.bif[a.d][a.e] = BT_NONE;
+		g.ndead[nd] = 1;
+		g.nslot[nd] = (b << 1) | a.d;        // a dead node is never dereferenced again: remember its list instead
+		g.nclr[nd] = tc_head; tc_head = nd;
+		push_dirty(b);
+	}
+	// Cleanup, bifurcationstorage.cpp:33-41
+	__host__ __device__ void cleanup()
+	{
+		for (uint32_t nd = tc_head; nd != BT_NONE; nd = g.nclr[nd]) g.lsize[g.nslot[nd] & 1][g.nslot[nd] >> 1]--;
+		tc_head = BT_NONE;
+	}
+	__host__ __device__ __forceinline__ uint32_t count_bif(uint32_t b) { ir(b); return g.lsize[0][b] + g.lsize[1][b]; }   // :71-75
+};
+
+// ------------------------------------------------------------------------------------------- Boost 1.54 unordered_map order
+// boost/unordered/detail/{buckets.hpp:603-654, unique.hpp:302-354,591-619, table.hpp:321-338,808-824} as vendored by the
+// reference: identity hash + mix64, power-of-two bucket counts from 16, max load factor 1, one singly linked node list.
+struct BoostMap {
+	uint32_t *key; int32_t *nxt; int32_t *bprev;     // node arrays [cap]; buckets [bcap]
+	uint32_t size, cap, bc, bcap;
+	int32_t first;
+	bool started;
+};
+__host__ __device__ __forceinline__ uint64_t bt_mix64(uint64_t key)
+{
+	key = (~key) + (key << 21);
+	key = key ^ (key >> 24);
+	key = (key + (key << 3)) + (key << 8);
+	key = key ^ (key >> 14);
+	key = (key + (key << 2)) + (key << 4);
+	key = key ^ (key >> 28);
+	key = key + (key << 31);
+	return key;
+}
+__host__ __device__ __forceinline__ uint32_t bt_new_bucket_count(uint32_t m)
+{
+	if (m <= 4) return 4;
+	--m; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+	return m + 1;
+}
+__host__ __device__ __forceinline__ int32_t *bm_link(BoostMap &m, int32_t l) { return l == -2 ? &m.first : &m.nxt[l]; }
+__host__ __device__ inline void bm_create_buckets(BoostMap &m, uint32_t bc)
+{
+	for (uint32_t i = 0; i < bc; i++) m.bprev[i] = -1;
+	m.bc = bc;
+}
+__host__ __device__ inline int32_t bm_find(BoostMap &m, uint32_t key)
+{
+	if (!m.started) return -1;
+	uint32_t b = (uint32_t)(bt_mix64(key) & (m.bc - 1));
+	if (m.bprev[b] == -1) return -1;
+	for (int32_t p = *bm_link(m, m.bprev[b]); p != -1 && (uint32_t)(bt_mix64(m.key[p]) & (m.bc - 1)) == b; p = m.nxt[p])
+		if (m.key[p] == key) return p;
+	return -1;
+}
+// operator[] for an absent key; returns the node index or -1 if the fixed capacity is exhausted
+__host__ __device__ inline int32_t bm_insert(BoostMap &m, uint32_t key)
+{
+	uint32_t need = m.size + 1;
+	if (need > m.cap) return -1;
+	if (!m.started) { bm_create_buckets(m, 16); m.started = true; }                 // max(16, min_buckets_for_size(1))
+	else if (need > m.bc) {                                                          // reserve_for_insert
+		uint32_t want = need > m.size + (m.size >> 1) ? need : m.size + (m.size >> 1);
+		uint32_t nb = bt_new_bucket_count(want + 1);
+		if (nb > m.bcap) return -1;
+		if (nb != m.bc) {                                                            // rehash_impl / place_in_bucket
+			bm_create_buckets(m, nb);
+			int32_t prev = -2;
+			while (*bm_link(m, prev) != -1) {
+				int32_t n = *bm_link(m, prev);
+				uint32_t b = (uint32_t)(bt_mix64(m.key[n]) & (nb - 1));
+				if (m.bprev[b] == -1) { m.bprev[b] = prev; prev = n; }
+				else {
+					*bm_link(m, prev) = m.nxt[n];
+					m.nxt[n] = *bm_link(m, m.bprev[b]);
+					*bm_link(m, m.bprev[b]) = n;
+				}
+			}
+		}
+	}
+	int32_t n = (int32_t)m.size++;
+	m.key[n] = key;
+	uint32_t b = (uint32_t)(bt_mix64(key) & (m.bc - 1));
+	if (m.bprev[b] == -1) {                                                          // add_node
+		if (m.first != -1) m.bprev[(uint32_t)(bt_mix64(m.key[m.first]) & (m.bc - 1))] = n;
+		m.bprev[b] = -2;
+		m.nxt[n] = m.first;
+		m.first = n;
+	} else {
+		m.nxt[n] = *bm_link(m, m.bprev[b]);
+		*bm_link(m, m.bprev[b]) = n;
+	}
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------- small sorts
+__host__ __device__ inline void bt_sort_u64(uint64_t *a, uint32_t n)
+{
+	for (uint32_t gap = n / 2; gap > 0; gap /= 2)                 // shell sort
+		for (uint32_t i = gap; i < n; i++) {
+			uint64_t v = a[i]; uint32_t j = i;
+			for (; j >= gap && a[j - gap] > v; j -= gap) a[j] = a[j - gap];
+			a[j] = v;
+		}
+}
+__host__ __device__ inline void bt_sort_u32(uint32_t *a, uint32_t n)
+{
+	for (uint32_t gap = n / 2; gap > 0; gap /= 2)
+		for (uint32_t i = gap; i < n; i++) {
+			uint32_t v = a[i]; uint32_t j = i;
+			for (; j >= gap && a[j - gap] > v; j -= gap) a[j] = a[j - gap];
+			a[j] = v;
+		}
+}
+
+// ------------------------------------------------------------------------------------------- the transaction
+struct BulgeWork {
+	uint32_t n;                  // instances of the id
+	uint32_t *start;             // (node << 1) | strand, list order: + list then - list (ListPositions, bifurcationstorage.h:59-72)
+	char *endc;                  // endChar
+	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
+	uint32_t *occ; uint32_t occ_cap;
+	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
+};
+
+__host__ __device__ __forceinline__ SIt bt_deref(Txn &t, uint32_t packed) { SIt a; a.e = t.g.nslot[packed >> 1]; a.d = packed & 1; return a; }
+__host__ __device__ __forceinline__ bool bt_pvalid(Txn &t, uint32_t packed) { return !t.g.ndead[packed >> 1]; }      // IteratorProxy::Valid :23-26
+
+// number of live instances of an id (skipping nodes erased by an earlier Cleanup)
+__host__ __device__ inline uint32_t bt_count_instances(const GraphView &g, uint32_t id)
+{
+	uint32_t n = 0;
+	for (int s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) n += !g.ndead[nd];
+	return n;
+}
+
+// FillVisit, bulgeremoval.cpp:122-146
+__host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, SIt kmer)
+{
+	uint32_t D = t.g.D, n = 0;
+	uint32_t start = t.getbif(kmer);
+	kmer = t.next(kmer);
+	for (uint32_t step = 1; step < D && t.valid(kmer); kmer = t.next(kmer), step++) {
+		uint32_t b = t.getbif(kmer);
+		if (b == start) break;
+		if (b != BT_NONE) {
+			if (n >= w.visit_cap) { t.err |= BT_ERR_SCRATCH; break; }
+			w.visit[n++] = ((uint64_t)b << 32) | step;
+		}
+	}
+	bt_sort_u64(w.visit, n);
+	w.nvisit = n;
+}
+
+// Overlap, bulgeremoval.cpp:97-120
+__host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, SIt si, uint32_t di, SIt sj, uint32_t dj)
+{
+	uint32_t k = t.g.k, n = di + k;
+	if (n > w.occ_cap) { t.err |= BT_ERR_SCRATCH; return true; }
+	for (uint32_t i = 0; i < n; i++, si = t.next(si)) w.occ[i] = si.e;
+	bt_sort_u32(w.occ, n);
+	for (uint32_t i = 0; i < dj + k; i++, sj = t.next(sj)) {
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.occ[mid] < sj.e) lo = mid + 1; else hi = mid; }
+		if (lo < n && w.occ[lo] == sj.e) return true;
+	}
+	return false;
+}
+
+// MaxBifurcationMultiplicity, bulgeremoval.cpp:39-53
+__host__ __device__ inline uint32_t bt_max_mult(Txn &t, SIt a, uint32_t distance)
+{
+	uint32_t r = 0;
+	for (uint32_t i = 0; i + 1 < distance; i++) {
+		a = t.next(a);
+		uint32_t b = t.getbif(a);
+		if (b != BT_NONE) { uint32_t c = t.count_bif(b); if (c > r) r = c; }
+	}
+	return r;
+}
+
+// DNASequence::ReplaceDirect, dnasequence.cpp:189-230 (target = first element of the old span in + direction)
+__host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t dS, uint32_t target, uint32_t dT)
+{
+	GraphView &g = t.g;
+	uint32_t save = target, e = target;
+	uint32_t common = dS < dT ? dS : dT;
+	t.tr(save);
+	uint32_t firstPos = g.op[save] & BT_POS_MASK;
+	for (uint32_t i = 0; i < dT; i++) { t.tr(e); e = g.nx[e]; }
+	t.tr(e);
+	uint32_t lastPos = g.op[e] & BT_POS_MASK;
+	for (uint32_t i = 0; i < common; i++) { char c = t.chr(source); t.tw(target); g.ch[target] = (uint8_t)c; target = g.nx[target]; source = t.next(source); }
+	if (dS < dT) {                                   // erase the surplus
+		t.tr(target);
+		uint32_t before = g.pv[target], cur = target;
+		for (uint32_t i = 0; i < dT - dS; i++) { t.tw(cur); g.ch[cur] = BT_DEAD_CHAR; cur = g.nx[cur]; }
+		t.tw(before); t.tw(cur);
+		g.nx[before] = cur; g.pv[cur] = before;
+	} else if (dS > dT) {                            // insert the deficit before `target`
+		uint32_t m = dS - dT;
+		uint32_t span = (m + 31u) & ~31u;            // whole validation blocks per insertion: no block is shared by two transactions
+		uint32_t base = bt_atomic_add(&g.ctr[CTR_NE], span);
+		if (base + span > g.cap_e) { t.err |= BT_ERR_ELEM_CAP; return; }
+		t.tr(target);
+		uint32_t before = g.pv[target];
+		t.tw(before); t.tw(target);
+		for (uint32_t i = 0; i < span; i++) {        // the characters are read from the source one by one (no element is both source and target)
+			uint32_t ne = base + i;
+			if (i < m) {
+				g.ch[ne] = (uint8_t)t.chr(source); source = t.next(source);
+				g.op[ne] = 0;
+				g.bif[0][ne] = g.bif[1][ne] = BT_NONE;
+				t.tw(ne);
+				g.nx[before] = ne; g.pv[ne] = before;
+				before = ne;
+			} else { g.ch[ne] = BT_DEAD_CHAR; g.bif[0][ne] = g.bif[1][ne] = BT_NONE; }
+		}
+		g.nx[before] = target; g.pv[target] = before;
+	}
+	double acc = (double)firstPos;                   // :221-227, same operation order: acc += ssize
+	double ssize = (double)dT / (double)dS;
+	for (uint32_t i = 0; i < dS; i++, acc += ssize) {
+		uint64_t p = (uint64_t)acc;
+		if (p > lastPos) p = lastPos;
+		t.tw(save);
+		g.op[save] = (uint32_t)p & BT_POS_MASK;
+		save = g.nx[save];
+	}
+}
+
+// every id whose forward window can see the rewritten region must be re-examined at its turn
+__host__ __device__ inline void bt_push_neighbourhood(Txn &t, SIt tstart, uint32_t newlen)
+{
+	uint32_t reach = t.g.D + t.g.k, k = t.g.k;
+	// backwards from the target instance (opposite to its direction), then forwards across the region and beyond
+	SIt a = tstart;
+	a.d ^= 1;
+	for (uint32_t i = 0; i <= reach; i++) {
+		if (t.g.ch[a.e] == BT_SEP) break;
+		uint32_t b0 = t.g.bif[0][a.e], b1 = t.g.bif[1][a.e];
+		if (b0 != BT_NONE) t.push_dirty(b0);
+		if (b1 != BT_NONE) t.push_dirty(b1);
+		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
+	}
+	a = tstart;
+	for (uint32_t i = 0; i <= newlen + 2 * k + reach; i++) {
+		if (t.g.ch[a.e] == BT_SEP) break;
+		uint32_t b0 = t.g.bif[0][a.e], b1 = t.g.bif[1][a.e];
+		if (b0 != BT_NONE) t.push_dirty(b0);
+		if (b1 != BT_NONE) t.push_dirty(b1);
+		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
+	}
+}
+
+// CollapseBulgeGreedily = EraseBifurcations + DNASequence::Replace + UpdateBifurcations
+// (bulgeremoval.cpp:284-327, :55-95, dnasequence.cpp:232-252, bulgeremoval.cpp:238-282)
+__host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK, uint32_t dS, uint32_t tgtK, uint32_t dT)
+{
+	uint32_t k = t.g.k;
+	SIt tt = bt_deref(t, w.start[tgtK]), ss = bt_deref(t, w.start[srcK]);
+	uint32_t nlb = 0, nlf = 0, anear = 0, bnear = 0;
+	SIt amer = t.inv(t.adv(tt, k));
+	SIt bmer = t.adv(tt, dT);
+	for (uint32_t i = 0; i < k; i++, amer = t.next(amer), bmer = t.next(bmer)) {
+		uint32_t b = t.getbif(amer);
+		if (b != BT_NONE) { t.erase_point(amer); w.lb[2 * nlb] = i; w.lb[2 * nlb + 1] = b; nlb++; }
+		b = t.getbif(bmer);
+		if (b != BT_NONE) { t.erase_point(bmer); w.lf[2 * nlf] = i; w.lf[2 * nlf + 1] = b; nlf++; }
+	}
+	amer = tt;
+	bmer = t.inv(t.adv(tt, k + dT));
+	for (uint32_t i = 0; i < k + dT; i++, amer = t.next(amer), bmer = t.next(bmer)) {
+		if (i > 0) t.erase_point(amer);
+		t.erase_point(bmer);
+	}
+	{
+		SIt source = t.adv(ss, k), target = t.adv(tt, k);
+		if (target.d == 0) bt_replace_direct(t, source, dS, target.e, dT);
+		else {
+			source = t.inv(t.adv(source, dS));
+			bt_replace_direct(t, source, dS, t.inv(t.adv(target, dT)).e, dT);
+		}
+	}
+	if (t.err) return;
+	amer = t.inv(t.adv(tt, k));
+	bmer = t.adv(tt, dS);
+	for (uint32_t i = 0; i < k; i++, amer = t.next(amer), bmer = t.next(bmer)) {
+		if (anear < nlb && i == w.lb[2 * anear]) { t.add_point(amer, w.lb[2 * anear + 1]); anear++; }
+		if (bnear < nlf && i == w.lf[2 * bnear]) { t.add_point(bmer, w.lf[2 * bnear + 1]); bnear++; }
+	}
+	amer = tt;
+	bmer = t.inv(t.adv(tt, dS + k));
+	SIt sa = ss, sb = t.inv(t.adv(ss, dS + k));
+	for (uint32_t i = 0; i < dS + 1; i++, amer = t.next(amer), bmer = t.next(bmer), sa = t.next(sa), sb = t.next(sb)) {
+		uint32_t b = t.getbif(sa);
+		if (b != BT_NONE) t.add_point(amer, b);
+		b = t.getbif(sb);
+		if (b != BT_NONE) t.add_point(bmer, b);
+	}
+	bt_push_neighbourhood(t, tt, dS);
+}
+
+// AnyBulges (bulgeremoval.cpp:158-218) into a BoostMap + per-entry member lists.
+// Returns the number of groups with more than one member; group g's members are written to
+// grp_off[g] .. grp_off[g+1] of grp_mem, in unordered_map iteration order.
+struct AnyBulgesOut { uint32_t ngroups; uint32_t *grp_off; uint32_t *grp_mem; };
+
+__host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, AnyBulgesOut *out, bool verdict_only)
+{
+	uint32_t D = t.g.D, n = w.n;
+	// capacity: whatever scratch is left, split between the map and the member log
+	uint32_t left = t.scr_cap - ((t.scr_used + 7u) & ~7u);
+	uint32_t cap = left / 48;                        // key 4 + nxt 4 + echar 1 + head/tail/cnt 12 + buckets 2x4 + log 2x8 < 48
+	if (cap < 16) { t.err |= BT_ERR_SCRATCH; return false; }
+	uint32_t bcap = bt_new_bucket_count(cap + 1);
+	if (bcap > 2 * cap) bcap >>= 1;
+	BoostMap m;
+	m.key = (uint32_t *)t.alloc(cap * 4); m.nxt = (int32_t *)t.alloc(cap * 4); m.bprev = (int32_t *)t.alloc(bcap * 4);
+	char *echar = (char *)t.alloc(cap);
+	uint32_t *mhead = (uint32_t *)t.alloc(cap * 4), *mtail = (uint32_t *)t.alloc(cap * 4), *mcnt = (uint32_t *)t.alloc(cap * 4);
+	uint32_t logcap = cap + n;
+	uint32_t *log_inst = (uint32_t *)t.alloc(logcap * 4), *log_next = (uint32_t *)t.alloc(logcap * 4);
+	if (t.err) return false;
+	m.size = 0; m.cap = cap; m.bc = 0; m.bcap = bcap; m.first = -1; m.started = false;
+	uint32_t nlog = 0;
+	bool any = false;
+	for (uint32_t i = 0; i < n; i++) {
+		if (w.endc[i] == ' ') continue;
+		SIt kmer = bt_deref(t, w.start[i]);
+		uint32_t start = t.getbif(kmer);
+		kmer = t.next(kmer);
+		for (uint32_t step = 1; step < D && t.valid(kmer); kmer = t.next(kmer), step++) {
+			uint32_t b = t.getbif(kmer);
+			if (b == start) break;
+			if (b == BT_NONE) continue;
+			int32_t kt = bm_find(m, b);
+			if (kt < 0) {
+				kt = bm_insert(m, b);
+				if (kt < 0 || nlog >= logcap) { t.err |= BT_ERR_SCRATCH; return false; }
+				echar[kt] = w.endc[i];
+				log_inst[nlog] = i; log_next[nlog] = BT_NONE;
+				mhead[kt] = mtail[kt] = nlog++; mcnt[kt] = 1;
+			} else if (echar[kt] != w.endc[i]) {
+				if (nlog >= logcap) { t.err |= BT_ERR_SCRATCH; return false; }
+				log_inst[nlog] = i; log_next[nlog] = BT_NONE;
+				log_next[mtail[kt]] = nlog; mtail[kt] = nlog++; mcnt[kt]++;
+				any = true;
+				if (verdict_only) return true;
+				break;
+			}
+		}
+	}
+	if (!any || verdict_only) return any;
+	uint32_t ng = 0, total = 0;
+	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (mcnt[p] > 1) { ng++; total += mcnt[p]; }
+	out->grp_off = (uint32_t *)t.alloc((ng + 1) * 4);
+	out->grp_mem = (uint32_t *)t.alloc(total * 4);
+	if (t.err) return false;
+	uint32_t gi = 0, o = 0;
+	for (int32_t p = m.first; p != -1; p = m.nxt[p]) {
+		if (mcnt[p] <= 1) continue;
+		out->grp_off[gi++] = o;
+		for (uint32_t l = mhead[p]; l != BT_NONE; l = log_next[l]) out->grp_mem[o++] = log_inst[l];
+	}
+	out->grp_off[gi] = o;
+	out->ngroups = ng;
+	return true;
+}
+
+// ListPositions + endChar (bulgeremoval.cpp:335-347).  Returns false when there are fewer than two instances.
+__host__ __device__ inline bool bt_list_instances(Txn &t, BulgeWork &w)
+{
+	GraphView &g = t.g;
+	uint32_t k = g.k, n = 0;
+	t.ir(t.id);
+	n = bt_count_instances(g, t.id);
+	w.n = n;
+	if (n < 2) return false;
+	w.start = (uint32_t *)t.alloc(n * 4);
+	w.endc = (char *)t.alloc(n);
+	if (t.err) return false;
+	n = 0;
+	for (uint32_t s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][t.id]; nd != BT_NONE; nd = g.nnext[nd])
+			if (!g.ndead[nd]) w.start[n++] = (nd << 1) | s;
+	for (uint32_t i = 0; i < n; i++) {              // ProperKMer(k + 1), dnasequence.h:154-165
+		SIt a = bt_deref(t, w.start[i]);
+		bool ok = true;
+		for (uint32_t j = 0; j < k + 1; j++) { if (!t.valid(a)) { ok = false; break; } if (j < k) a = t.next(a); }
+		w.endc[i] = ok ? t.chr(a) : ' ';
+	}
+	return true;
+}
+
+// Verdict of AnyBulges for one id against the current graph (read only).
+__host__ __device__ inline bool bt_has_bulges(Txn &t)
+{
+	BulgeWork w;
+	if (!bt_list_instances(t, w)) return false;
+	return bt_any_bulges(t, w, nullptr, true);
+}
+
+// RemoveBulges, bulgeremoval.cpp:330-430.  Returns the number of bulges collapsed.
+__host__ __device__ inline uint32_t bt_remove_bulges(Txn &t)
+{
+	GraphView &g = t.g;
+	uint32_t k = g.k, D = g.D, ret = 0;
+	BulgeWork w;
+	if (!bt_list_instances(t, w)) return 0;
+	w.visit_cap = D; w.occ_cap = D + k;
+	w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
+	w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
+	w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+	if (t.err) return 0;
+	AnyBulgesOut ab;
+	if (!bt_any_bulges(t, w, &ab, false)) return 0;
+	t.iw(t.id);
+	for (uint32_t gi = 0; gi < ab.ngroups; gi++) {
+		uint32_t gb = ab.grp_off[gi], ge = ab.grp_off[gi + 1];
+		for (uint32_t idI = gb; idI < ge; idI++) {
+			uint32_t kmerI = ab.grp_mem[idI];
+			if (!bt_pvalid(t, w.start[kmerI])) continue;
+			bt_fill_visit(t, w, bt_deref(t, w.start[kmerI]));
+			for (uint32_t idJ = idI + 1; idJ < ge; idJ++) {
+				uint32_t kmerJ = ab.grp_mem[idJ];
+				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
+				SIt kmer = t.next(bt_deref(t, w.start[kmerJ]));
+				for (uint32_t step = 1; t.valid(kmer) && step < D; kmer = t.next(kmer), step++) {
+					uint32_t nowBif = t.getbif(kmer);
+					if (nowBif == BT_NONE) continue;
+					if (nowBif == t.id) break;
+					uint32_t lo = 0, hi = w.nvisit;                  // lower_bound(BifurcationMark(nowBif, 0))
+					uint64_t probe = (uint64_t)nowBif << 32;
+					while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.visit[mid] < probe) lo = mid + 1; else hi = mid; }
+					if (lo < w.nvisit && (uint32_t)(w.visit[lo] >> 32) == nowBif) {
+						uint32_t dJ = step, dI = (uint32_t)w.visit[lo];
+						if (bt_overlap(t, w, bt_deref(t, w.start[kmerI]), dI, bt_deref(t, w.start[kmerJ]), dJ)) break;
+						if (t.err) return ret;
+						++ret;
+						uint32_t imlp = bt_max_mult(t, bt_deref(t, w.start[kmerI]), dI);
+						uint32_t jmlp = bt_max_mult(t, bt_deref(t, w.start[kmerJ]), dJ);
+						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
+							w.endc[kmerJ] = w.endc[kmerI];
+							bt_collapse(t, w, kmerI, dI, kmerJ, dJ);
+						} else {
+							w.endc[kmerI] = w.endc[kmerJ];
+							bt_collapse(t, w, kmerJ, dJ, kmerI, dI);
+							bt_fill_visit(t, w, bt_deref(t, w.start[kmerI]));
+						}
+						if (t.err) return ret;
+						break;
+					}
+				}
+			}
+		}
+	}
+	t.cleanup();
+	return ret;
+}
+
+// ------------------------------------------------------------------------------------------- reservation footprint
+// Calls f(b) for the transaction's own id and for every id marked (either strand) within
+// [a - (D+k), a + 2(D+k) + k] of each instance a of the id, directions relative to the instance.
+// Two transactions whose accessed elements or lists can interact always share at least one of
+// these ids (simplify.hip), so owning all of them isolates the transaction inside a round.
+template <class F>
+__host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F f)
+{
+	uint32_t back = g.D + g.k, fwd = 2 * (g.D + g.k) + g.k;
+	f(id);
+	for (uint32_t s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+			if (g.ndead[nd]) continue;
+			uint32_t e0 = g.nslot[nd], e = e0;
+			for (uint32_t i = 0; i <= fwd; i++) {
+				if (i && g.ch[e] == BT_SEP) break;
+				uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
+				if (b0 != BT_NONE) f(b0);
+				if (b1 != BT_NONE) f(b1);
+				e = s ? g.pv[e] : g.nx[e];
+				if (e == BT_NONE) break;
+			}
+			e = s ? g.nx[e0] : g.pv[e0];
+			for (uint32_t i = 1; i <= back && e != BT_NONE; i++) {
+				if (g.ch[e] == BT_SEP) break;
+				uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
+				if (b0 != BT_NONE) f(b0);
+				if (b1 != BT_NONE) f(b1);
+				e = s ? g.nx[e] : g.pv[e];
+			}
+		}
+}

@@ -59,7 +59,7 @@ __device__ __forceinline__ bool mask_is_bifurcation(unsigned m)
 // ---------------------------------------------------------------------------------------------
 // K1: ASCII -> 2-bit words + separator bits.  One thread per 32 elements (two 16-B loads).
 // ch must be padded with '$' up to a multiple of 32 elements.
-__global__ void __launch_bounds__(256) k_pack2bit(const uint8_t *__restrict__ ch, unsigned long long *__restrict__ pk,
+static __global__ void __launch_bounds__(256) k_pack2bit(const uint8_t *__restrict__ ch, unsigned long long *__restrict__ pk,
                                                   unsigned *__restrict__ sp, size_t nwords)
 {
 	size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void tile_walk(const KmerTile &t, size_t tile, unsign
 // K2: k-mer table build.  One atomicCAS (key claim) + one atomicOr (mask merge) per base position;
 // a position covers the + occurrence of fwd and the - occurrence of rev, which contribute the same
 // bits in canonical orientation.
-__global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const unsigned long long *__restrict__ pk,
+static __global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const unsigned long long *__restrict__ pk,
                                                                  const unsigned *__restrict__ sp, size_t nwords, size_t nelem,
                                                                  unsigned k, KmerSlot *__restrict__ table, unsigned long long capmask,
                                                                  size_t ntiles)
@@ -191,10 +191,18 @@ __global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const unsigned 
 	}
 }
 
+static __global__ void __launch_bounds__(256) k_table_init(KmerSlot *__restrict__ table, size_t cap)
+{
+	for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (size_t)gridDim.x * blockDim.x) {
+		KmerSlot e; e.key = SBL_EMPTY_KEY; e.mask = 0; e.aux = SBL_NONE;
+		table[s] = e;
+	}
+}
+
 // K3: classify table slots, compact the bifurcation slots and emit their sort keys
 // (the canonical code and, unless palindromic, its reverse complement).
 // keyinfo payload = 2 * pairIndex + orientation (0 = canonical code, 1 = reverse complement).
-__global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ table, size_t cap, unsigned k,
+static __global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ table, size_t cap, unsigned k,
                                                         unsigned *__restrict__ counters /* [0]=pairs [1]=keys [2]=used slots */,
                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ payload,
                                                         unsigned maxpairs)
@@ -209,7 +217,7 @@ __global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ t
 			unsigned nk = r == sl.key ? 1u : 2u;
 			unsigned pi = atomicAdd(&counters[0], 1u);
 			unsigned ki = atomicAdd(&counters[1], nk);
-			if (pi < maxpairs) {
+			if (pi < maxpairs && ki + nk <= 2 * maxpairs) {
 				aux = pi;
 				keys[ki] = sl.key; payload[ki] = 2 * pi;
 				if (nk == 2) { keys[ki + 1] = r; payload[ki + 1] = 2 * pi + 1; }
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ t
 }
 
 // K4b: after the radix sort of the keys, rank = bifurcation id.  pairids[2p+o] = id.
-__global__ void __launch_bounds__(256) k_scatter_ids(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ spayload,
+static __global__ void __launch_bounds__(256) k_scatter_ids(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ spayload,
                                                      unsigned nkeys, unsigned k, unsigned *__restrict__ pairids)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(256) k_scatter_ids(const unsigned long long *_
 //   bif[1][g+k-1]   = id of the - strand k-mer starting at element g+k-1 (= reverse complement of the same window)
 // (what the marking loop of IndexedSequence::Init builds with AddPoint, reference src/indexedsequence.cpp:49-67).
 // Arrays must be pre-filled with SBL_NONE.
-__global__ void __launch_bounds__(KM_THREADS) k_resolve_marks(const unsigned long long *__restrict__ pk, const unsigned *__restrict__ sp,
+static __global__ void __launch_bounds__(KM_THREADS) k_resolve_marks(const unsigned long long *__restrict__ pk, const unsigned *__restrict__ sp,
                                                               size_t nwords, size_t nelem, unsigned k,
                                                               const KmerSlot *__restrict__ table, unsigned long long capmask,
                                                               const unsigned *__restrict__ pairids,
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__(KM_THREADS) k_resolve_marks(const unsigned lon
 // ---------------------------------------------------------------------------------------------
 // Ordered compaction of the marks of one strand: (element index, id) pairs in ascending element order.
 // Pass 1 counts per 1024-element chunk, pass 2 (after an exclusive scan of the counts) writes.
-__global__ void __launch_bounds__(256) k_count_marks(const unsigned *__restrict__ bif, size_t nelem, unsigned *__restrict__ chunkcnt)
+static __global__ void __launch_bounds__(256) k_count_marks(const unsigned *__restrict__ bif, size_t nelem, unsigned *__restrict__ chunkcnt)
 {
 	__shared__ unsigned cnt;
 	if (threadIdx.x == 0) cnt = 0;
@@ -279,7 +287,7 @@ __global__ void __launch_bounds__(256) k_count_marks(const unsigned *__restrict_
 	__syncthreads();
 	if (threadIdx.x == 0) chunkcnt[blockIdx.x] = cnt;
 }
-__global__ void __launch_bounds__(256) k_write_marks(const unsigned *__restrict__ bif, size_t nelem, const unsigned *__restrict__ chunkoff,
+static __global__ void __launch_bounds__(256) k_write_marks(const unsigned *__restrict__ bif, size_t nelem, const unsigned *__restrict__ chunkoff,
                                                      unsigned *__restrict__ out_elem, unsigned *__restrict__ out_id)
 {
 	// 256 threads x 4 consecutive elements; wave ballot prefix + per-wave offsets through LDS
@@ -310,7 +318,7 @@ __device__ __forceinline__ unsigned chr_of(const unsigned *__restrict__ sepidx, 
 
 // (element, id) -> sbl_inst {id, chr, pos}; strand 1 reports reverse-complement coordinates
 // (vertexenumeration.cpp:334-346): element e on chromosome c <-> rc position len_c - 1 - local(e).
-__global__ void __launch_bounds__(256) k_make_instances(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, unsigned n,
+static __global__ void __launch_bounds__(256) k_make_instances(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, unsigned n,
                                                         const unsigned *__restrict__ sepidx, unsigned nchr, unsigned strand,
                                                         unsigned *__restrict__ out /* n x 3 */)
 {

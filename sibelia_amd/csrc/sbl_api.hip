@@ -1,0 +1,440 @@
+// sbl_api.hip -- C ABI (include/sibelia_amd.h) + enumeration pipeline of the MI355X-native BlockFinder hot path.
+//
+// Host code here only orchestrates: every pass over sequence data, every table access and every
+// sort runs in a HIP kernel on the context's device.  There is no host compute path.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#include "sbl_ctx.h"
+#include "kmer_kernels.h"
+
+static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------- small kernels
+__global__ void __launch_bounds__(256) k_scatter_chars(uint8_t *ch, const unsigned *elem, const uint8_t *val, unsigned n)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) ch[elem[i]] = val[i];
+}
+
+// ListEdges (reference src/serialization.cpp:56-86) over the dense mark arrays of a fresh index.
+// Edge i of a strand connects the consecutive marks (i, i+1) of the compacted list when both lie
+// on the same chromosome; `valid[i]` says whether it exists.
+__global__ void __launch_bounds__(256) k_list_edges(const unsigned *__restrict__ melem, const unsigned *__restrict__ mid, unsigned n,
+                                                    unsigned strand, unsigned k, const uint8_t *__restrict__ ch,
+                                                    const unsigned *__restrict__ op, const unsigned *__restrict__ sepidx, unsigned nchr,
+                                                    sbl_edge *__restrict__ out, uint8_t *__restrict__ valid)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i + 1 >= n) return;
+	unsigned lo = melem[i], hi = melem[i + 1];
+	unsigned c = chr_of(sepidx, nchr, lo);
+	if (hi > sepidx[c + 1]) { valid[i] = 0; return; }
+	unsigned length = sepidx[c + 1] - sepidx[c] - 1, step = hi - lo;
+	sbl_edge e;
+	unsigned p1, p2;
+	if (strand == 0) {
+		unsigned pos = lo - sepidx[c] - 1;
+		e.start_vertex = mid[i]; e.end_vertex = mid[i + 1];
+		e.pos = pos;
+		e.first_char = (char)ch[lo + k];
+		p1 = op[lo] & 0x1FFFFFFFu; p2 = op[hi + k - 1] & 0x1FFFFFFFu;
+	} else {
+		unsigned pos = sepidx[c + 1] - 1 - hi;            // walk position of the origin (the higher element)
+		e.start_vertex = mid[i + 1]; e.end_vertex = mid[i];
+		e.pos = length - (pos + step + k);
+		unsigned char x = ch[hi - k];
+		e.first_char = (char)(x == 'A' ? 'T' : x == 'C' ? 'G' : x == 'G' ? 'C' : x == 'T' ? 'A' : x);
+		p1 = op[hi] & 0x1FFFFFFFu; p2 = op[lo - k + 1] & 0x1FFFFFFFu;
+	}
+	e.chr = c; e.strand = strand; e.len = step + k;
+	e.orig_pos = p1 < p2 ? p1 : p2;
+	e.orig_len = (p1 < p2 ? p2 : p1) + 1 - e.orig_pos;
+	e.pad_[0] = e.pad_[1] = e.pad_[2] = 0;
+	out[i] = e;
+	valid[i] = 1;
+}
+
+// ------------------------------------------------------------------------------------------- helpers
+static void drop_host_state(sbl_ctx *c) { c->host_state_valid = false; }
+
+// IndexedSequence::Init sanitise (reference src/indexedsequence.cpp:31-37): every non-ACGT character,
+// chromosome-major, becomes "ACGT"[rand() % 4].  Returns true if something was replaced.
+static bool sanitise_apply(sbl_ctx *c)
+{
+	size_t n = c->amb_elem.size();
+	if (!n) return false;
+	std::vector<uint8_t> rep(n);
+	for (size_t i = 0; i < n; i++) rep[i] = (uint8_t)"ACGT"[c->rng.next() % 4];
+	c->d_amb_elem.ensure(n * 4); c->d_amb_char.ensure(n);
+	HIP_TRY(hipMemcpyAsync(c->d_amb_elem.p, c->amb_elem.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->d_amb_char.p, rep.data(), n, hipMemcpyHostToDevice, c->stream));
+	k_scatter_chars<<<nblocks(n, 256), 256, 0, c->stream>>>(c->d_ch.as<uint8_t>(), c->d_amb_elem.as<unsigned>(), c->d_amb_char.as<uint8_t>(), (unsigned)n);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return true;
+}
+static void sanitise_revert(sbl_ctx *c)
+{
+	size_t n = c->amb_elem.size();
+	if (!n) return;
+	HIP_TRY(hipMemcpyAsync(c->d_amb_char.p, c->amb_orig.data(), n, hipMemcpyHostToDevice, c->stream));
+	k_scatter_chars<<<nblocks(n, 256), 256, 0, c->stream>>>(c->d_ch.as<uint8_t>(), c->d_amb_elem.as<unsigned>(), c->d_amb_char.as<uint8_t>(), (unsigned)n);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+}
+void sbl_sanitise_commit(sbl_ctx *c) { c->amb_elem.clear(); c->amb_orig.clear(); }
+
+// K1
+void sbl_pack(sbl_ctx *c)
+{
+	size_t nwords = (c->nelem + 31) / 32;
+	c->d_pk.ensure(nwords * 8); c->d_sp.ensure(nwords * 4);
+	k_pack2bit<<<nblocks(nwords, 256), 256, 0, c->stream>>>(c->d_ch.as<uint8_t>(), c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords);
+	HIP_TRY(hipGetLastError());
+}
+
+static void device_sort_pairs(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n, unsigned bits)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
+	c->d_sorttmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
+}
+static void device_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+	c->d_scantmp.ensure(tmp);
+	HIP_TRY(rocprim::exclusive_scan(c->d_scantmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+}
+
+// E1 (+ the dense form of E2): pack -> table build -> classify -> rank -> resolve.
+// elem_capacity >= nelem is the allocated length of the mark arrays (simplification appends elements).
+void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
+{
+	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
+	SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
+	hipStream_t s = c->stream;
+	size_t E = c->nelem, nwords = (E + 31) / 32;
+	size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
+	c->cur_k = k;
+	sbl_pack(c);
+
+	// table capacity: power of two >= 2 x number of base positions (an upper bound of the distinct canonical k-mers)
+	size_t cap = 1024;
+	while (cap < 2 * E) cap <<= 1;
+	c->d_table.ensure(cap * sizeof(KmerSlot));
+	c->table_cap = cap;
+	c->d_counters.ensure(64 * 4);
+	k_table_init<<<(unsigned)std::min<size_t>((cap + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap);
+	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+
+	unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 8);
+	HIP_TRY(hipEventRecord(c->ev[0], s));
+	k_kmer_table_build<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
+	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, ntiles);
+	HIP_TRY(hipEventRecord(c->ev[1], s));
+	HIP_TRY(hipGetLastError());
+
+	// classify: first count, then emit keys into exactly sized buffers
+	unsigned cgrid = (unsigned)std::min<size_t>((cap + 255) / 256, 256 * 16);
+	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap, k, c->d_counters.as<unsigned>(), nullptr, nullptr, 0);
+	unsigned cnt[4];
+	HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned npairs = cnt[0], nkeys = cnt[1];
+	c->d_keys.ensure((size_t)nkeys * 8 + 16); c->d_payload.ensure((size_t)nkeys * 4 + 16);
+	c->d_skeys.ensure((size_t)nkeys * 8 + 16); c->d_spayload.ensure((size_t)nkeys * 4 + 16);
+	c->d_pairids.ensure((size_t)npairs * 8 + 16);
+	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap, k, c->d_counters.as<unsigned>(),
+	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), npairs);
+	if (nkeys) {
+		device_sort_pairs(c, c->d_keys.as<unsigned long long>(), c->d_skeys.as<unsigned long long>(),
+		                  c->d_payload.as<unsigned>(), c->d_spayload.as<unsigned>(), nkeys, 2 * k);
+		k_scatter_ids<<<nblocks(nkeys, 256), 256, 0, s>>>(c->d_skeys.as<unsigned long long>(), c->d_spayload.as<unsigned>(), nkeys, k,
+		                                                 c->d_pairids.as<unsigned>());
+	}
+	c->bif_count = nkeys;
+
+	for (int st = 0; st < 2; st++) {
+		c->d_bif[st].ensure(elem_capacity * 4);
+		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
+	}
+	k_resolve_marks<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
+	                                            c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, c->d_pairids.as<unsigned>(),
+	                                            c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(), ntiles);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+	c->stats.kmer_table_ms = ms;
+	// algorithmic bytes of the table build: 2-bit sequence read once + one 16-B slot read and written per base position
+	size_t positions = 0;
+	for (uint32_t ch = 0; ch < c->nchr; ch++) {
+		size_t len = c->sepidx[ch + 1] - c->sepidx[ch] - 1;
+		if (len >= k) positions += len - k + 1;
+	}
+	c->stats.kmer_table_bytes = positions * 32 + E / 4;
+	c->stats.strand_kmers = 2 * positions;
+	c->stats.bif_count = nkeys;
+}
+
+// ordered compaction of one strand's marks into (element, id) arrays
+void sbl_compact_marks(sbl_ctx *c, int strand)
+{
+	hipStream_t s = c->stream;
+	size_t E = c->nelem;
+	unsigned nchunks = nblocks(E, 1024);
+	c->d_chunkcnt.ensure((size_t)(nchunks + 1) * 4); c->d_chunkoff.ensure((size_t)(nchunks + 1) * 4);
+	HIP_TRY(hipMemsetAsync(c->d_chunkcnt.p, 0, (size_t)(nchunks + 1) * 4, s));
+	k_count_marks<<<nchunks, 256, 0, s>>>(c->d_bif[strand].as<unsigned>(), E, c->d_chunkcnt.as<unsigned>());
+	device_exclusive_scan(c, c->d_chunkcnt.as<unsigned>(), c->d_chunkoff.as<unsigned>(), nchunks + 1);
+	unsigned total = 0;
+	HIP_TRY(hipMemcpyAsync(&total, c->d_chunkoff.as<unsigned>() + nchunks, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	c->nmarks[strand] = total;
+	c->d_melem[strand].ensure((size_t)total * 4 + 16); c->d_mid[strand].ensure((size_t)total * 4 + 16);
+	if (total)
+		k_write_marks<<<nchunks, 256, 0, s>>>(c->d_bif[strand].as<unsigned>(), E, c->d_chunkoff.as<unsigned>(),
+		                                      c->d_melem[strand].as<unsigned>(), c->d_mid[strand].as<unsigned>());
+	HIP_TRY(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------- C ABI
+template <class F>
+static sbl_status guarded(sbl_ctx *c, F f)
+{
+	if (!c) return SBL_ERR_BAD_ARG;
+	try {
+		(void)hipSetDevice(c->device);
+		f();
+		return SBL_OK;
+	} catch (const SblError &e) {
+		c->err = e.msg;
+		return e.st;
+	} catch (const std::bad_alloc &) {
+		c->err = "host allocation failed";
+		return SBL_ERR_OOM;
+	} catch (...) {
+		c->err = "unexpected exception";
+		return SBL_ERR_INTERNAL;
+	}
+}
+
+extern "C" sbl_status sbl_create(sbl_ctx **out, int device)
+{
+	if (!out) return SBL_ERR_BAD_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SBL_ERR_NO_DEVICE;
+	if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+	if (device >= ndev) return SBL_ERR_BAD_ARG;
+	if (hipSetDevice(device) != hipSuccess) return SBL_ERR_NO_DEVICE;
+	sbl_ctx *c = new (std::nothrow) sbl_ctx();
+	if (!c) return SBL_ERR_OOM;
+	c->device = device;
+	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SBL_ERR_HIP; }
+	for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return SBL_ERR_HIP; }
+	*out = c;
+	return SBL_OK;
+}
+
+extern "C" void sbl_destroy(sbl_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	sbl_simplify_free(c);
+	DevBuf *bufs[] = { &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
+	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
+	for (DevBuf *b : bufs) b->release();
+	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" sbl_status sbl_load(sbl_ctx *c, uint32_t nchr, const uint8_t *const *seq, const uint64_t *len)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(nchr == 0 || (seq && len), SBL_ERR_BAD_ARG, "null input");
+		uint64_t L = 0;
+		for (uint32_t i = 0; i < nchr; i++) {
+			SBL_CHECK(len[i] < (1ull << 29), SBL_ERR_TOO_LARGE, "a chromosome must be shorter than 2^29 bp (29-bit original positions)");
+			L += len[i];
+		}
+		SBL_CHECK(L <= (1ull << 30), SBL_ERR_TOO_LARGE, "total input larger than 2^30 bp");
+		size_t E = (size_t)L + nchr + 1, Epad = (E + 31) / 32 * 32 + 64;
+		std::vector<uint8_t> ch(Epad, (uint8_t)'$');
+		std::vector<uint32_t> op(E, 0);
+		c->sepidx.assign(nchr + 1, 0);
+		c->amb_elem.clear(); c->amb_orig.clear();
+		size_t e = 1;
+		for (uint32_t i = 0; i < nchr; i++) {
+			c->sepidx[i] = (uint32_t)(e - 1);
+			memcpy(&ch[e], seq[i], len[i]);
+			for (uint64_t j = 0; j < len[i]; j++) {
+				uint8_t x = seq[i][j];
+				if (x != 'A' && x != 'C' && x != 'G' && x != 'T') { c->amb_elem.push_back((uint32_t)(e + j)); c->amb_orig.push_back(x); }
+				op[e + j] = (uint32_t)j;                         // Counter<Pos>, reference src/blockfinder.cpp:74
+			}
+			e += len[i];
+			op[e] = (uint32_t)len[i];                            // trailing '$' stores the length, reference src/dnasequence.cpp:96
+			e++;
+		}
+		c->sepidx[nchr] = (uint32_t)(e - 1);
+		c->nchr = nchr; c->nelem = E;
+		c->d_ch.ensure(Epad); c->d_op.ensure(E * 4); c->d_sepidx.ensure((size_t)(nchr + 1) * 4);
+		HIP_TRY(hipMemcpyAsync(c->d_ch.p, ch.data(), Epad, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_op.p, op.data(), E * 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_sepidx.p, c->sepidx.data(), (size_t)(nchr + 1) * 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		drop_host_state(c);
+	});
+}
+
+extern "C" uint32_t sbl_nchr(const sbl_ctx *c) { return c ? c->nchr : 0; }
+
+extern "C" sbl_status sbl_enumerate(sbl_ctx *c, uint32_t k, uint32_t *bif_count,
+                                    const sbl_inst **pos, uint64_t *npos, const sbl_inst **neg, uint64_t *nneg)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
+		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
+		bool temp = sanitise_apply(c);
+		sbl_run_enumeration(c, k, c->nelem);
+		for (int st = 0; st < 2; st++) {
+			sbl_compact_marks(c, st);
+			unsigned n = c->nmarks[st];
+			c->inst[st].resize(n);
+			if (n) {
+				c->d_inst.ensure((size_t)n * 12);
+				k_make_instances<<<nblocks(n, 256), 256, 0, c->stream>>>(c->d_melem[st].as<unsigned>(), c->d_mid[st].as<unsigned>(), n,
+				                                                        c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)st, c->d_inst.as<unsigned>());
+				HIP_TRY(hipMemcpyAsync(c->inst[st].data(), c->d_inst.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));
+			}
+		}
+		// the negative list is sorted by (chr, reverse-complement pos): reverse each chromosome's run
+		{
+			auto &v = c->inst[1];
+			size_t a = 0;
+			while (a < v.size()) {
+				size_t b = a;
+				while (b < v.size() && v[b].chr == v[a].chr) b++;
+				std::reverse(v.begin() + a, v.begin() + b);
+				a = b;
+			}
+		}
+		if (temp) sanitise_revert(c);
+		c->stats.instances = c->inst[0].size() + c->inst[1].size();
+		if (bif_count) *bif_count = c->bif_count;
+		if (pos) *pos = c->inst[0].data();
+		if (npos) *npos = c->inst[0].size();
+		if (neg) *neg = c->inst[1].data();
+		if (nneg) *nneg = c->inst[1].size();
+	});
+}
+
+extern "C" sbl_status sbl_list_edges(sbl_ctx *c, uint32_t k, const sbl_edge **edges, uint64_t *n)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
+		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
+		bool temp = sanitise_apply(c);
+		sbl_run_enumeration(c, k, c->nelem);
+		c->edges.clear();
+		DevBuf d_edges, d_valid;
+		for (int st = 0; st < 2; st++) {
+			sbl_compact_marks(c, st);
+			unsigned m = c->nmarks[st];
+			if (m < 2) continue;
+			d_edges.ensure((size_t)m * sizeof(sbl_edge)); d_valid.ensure(m);
+			HIP_TRY(hipMemsetAsync(d_valid.p, 0, m, c->stream));
+			k_list_edges<<<nblocks(m, 256), 256, 0, c->stream>>>(c->d_melem[st].as<unsigned>(), c->d_mid[st].as<unsigned>(), m, (unsigned)st, k,
+			                                                    c->d_ch.as<uint8_t>(), c->d_op.as<unsigned>(), c->d_sepidx.as<unsigned>(), c->nchr,
+			                                                    d_edges.as<sbl_edge>(), d_valid.as<uint8_t>());
+			std::vector<sbl_edge> he(m);
+			std::vector<uint8_t> hv(m);
+			HIP_TRY(hipMemcpyAsync(he.data(), d_edges.p, (size_t)m * sizeof(sbl_edge), hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipMemcpyAsync(hv.data(), d_valid.p, m, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			size_t first = c->edges.size();
+			for (unsigned i = 0; i + 1 < m; i++) if (hv[i]) c->edges.push_back(he[i]);
+			if (st == 1) {                          // walk order on the negative strand is descending element order
+				size_t a = first;
+				while (a < c->edges.size()) {
+					size_t b = a;
+					while (b < c->edges.size() && c->edges[b].chr == c->edges[a].chr) b++;
+					std::reverse(c->edges.begin() + a, c->edges.begin() + b);
+					a = b;
+				}
+			}
+		}
+		d_edges.release(); d_valid.release();
+		if (temp) sanitise_revert(c);
+		if (edges) *edges = c->edges.data();
+		if (n) *n = c->edges.size();
+	});
+}
+
+extern "C" sbl_status sbl_simplify_stage(sbl_ctx *c, uint32_t k, uint32_t min_branch_size, uint32_t max_iterations,
+                                         sbl_progress_fn progress, void *user, uint64_t *bulges)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
+		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
+		if (sanitise_apply(c)) sbl_sanitise_commit(c);       // the sanitised copy flows back through the copy-back (src/blockfinder.cpp:85-95)
+		uint64_t b = 0;
+		sbl_simplify_run(c, k, min_branch_size, max_iterations, progress, user, &b);
+		drop_host_state(c);
+		if (bulges) *bulges = b;
+	});
+}
+
+extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **seq, const uint32_t **orig_pos, uint64_t *len)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(chr < c->nchr, SBL_ERR_BAD_ARG, "chromosome index out of range");
+		if (!c->host_state_valid) {
+			std::vector<uint8_t> ch(c->nelem);
+			std::vector<uint32_t> op(c->nelem);
+			HIP_TRY(hipMemcpyAsync(ch.data(), c->d_ch.p, c->nelem, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipMemcpyAsync(op.data(), c->d_op.p, c->nelem * 4, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			c->h_seq.assign(c->nchr, {}); c->h_op.assign(c->nchr, {});
+			for (uint32_t i = 0; i < c->nchr; i++) {
+				size_t a = c->sepidx[i] + 1, b = c->sepidx[i + 1];
+				c->h_seq[i].assign(ch.begin() + a, ch.begin() + b);
+				c->h_op[i].resize(b - a);
+				for (size_t j = a; j < b; j++) c->h_op[i][j - a] = op[j] & 0x1FFFFFFFu;
+			}
+			c->host_state_valid = true;
+		}
+		if (seq) *seq = c->h_seq[chr].data();
+		if (orig_pos) *orig_pos = c->h_op[chr].data();
+		if (len) *len = c->h_seq[chr].size();
+	});
+}
+
+extern "C" sbl_status sbl_last_stats(const sbl_ctx *c, sbl_stage_stats *out)
+{
+	if (!c || !out) return SBL_ERR_BAD_ARG;
+	*out = c->stats;
+	return SBL_OK;
+}
+extern "C" const char *sbl_last_error(const sbl_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char *sbl_strerror(sbl_status s)
+{
+	switch (s) {
+	case SBL_OK: return "ok";
+	case SBL_ERR_BAD_ARG: return "bad argument";
+	case SBL_ERR_NO_DEVICE: return "no usable HIP device (this library has no host compute path)";
+	case SBL_ERR_OOM: return "out of memory";
+	case SBL_ERR_HIP: return "HIP runtime error";
+	case SBL_ERR_TOO_LARGE: return "input exceeds the 29-bit position / 2^30 total limits";
+	case SBL_ERR_UNSUPPORTED: return "unsupported vertex size";
+	default: return "internal error";
+	}
+}
+extern "C" sbl_status sbl_set_window(sbl_ctx *c, uint32_t w) { if (!c) return SBL_ERR_BAD_ARG; c->window = w; return SBL_OK; }

@@ -1,0 +1,61 @@
+// sbl_ctx.h -- the context behind the C ABI (one per host thread, one GPU each).
+#pragma once
+#include "sbl_common.h"
+
+struct sbl_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	GlibcRand rng;
+
+	// ---- state carried between stages (rawSeq_ / originalPos_, reference src/blockfinder.h:52-54),
+	//      resident in HBM as the element array '$' c0 '$' c1 '$' ... '$'
+	uint32_t nchr = 0;
+	std::vector<uint32_t> sepidx;        // host copy: element index of the '$' before chromosome c (nchr+1)
+	size_t nelem = 0;                    // E = L + nchr + 1
+	DevBuf d_ch;                         // uint8  [E padded to 32 with '$']
+	DevBuf d_op;                         // uint32 [E] original positions (29 bit)
+	DevBuf d_sepidx;                     // uint32 [nchr+1]
+	// characters the reference would replace through rand() at the next IndexedSequence::Init
+	std::vector<uint32_t> amb_elem;      // element indices, chromosome-major order
+	std::vector<uint8_t> amb_orig;       // their original characters
+	DevBuf d_amb_elem, d_amb_char;
+
+	// host mirrors for sbl_get_state
+	bool host_state_valid = false;
+	std::vector<std::vector<uint8_t>> h_seq;
+	std::vector<std::vector<uint32_t>> h_op;
+
+	// ---- enumeration workspace
+	DevBuf d_pk, d_sp;                   // packed bases / separator bits
+	DevBuf d_table;                      // KmerSlot[cap]
+	size_t table_cap = 0;
+	DevBuf d_counters;                   // small uint32 scratch block
+	DevBuf d_keys, d_payload, d_skeys, d_spayload, d_pairids, d_sorttmp;
+	DevBuf d_bif[2];                     // dense marks, uint32 [element capacity]
+	DevBuf d_chunkcnt, d_chunkoff, d_scantmp;
+	DevBuf d_melem[2], d_mid[2];         // compacted marks per strand (element, id), ascending element
+	uint32_t nmarks[2] = {0, 0};
+	uint32_t bif_count = 0;
+	uint32_t cur_k = 0;
+	DevBuf d_inst;                       // marshalling buffer
+
+	// results handed out through the ABI
+	std::vector<sbl_inst> inst[2];
+	std::vector<sbl_edge> edges;
+
+	// ---- simplification workspace lives in simplify.hip (opaque here)
+	struct SimplifyState *simp = nullptr;
+	uint32_t window = 0;
+
+	sbl_stage_stats stats{};
+	hipEvent_t ev[8] = {};
+};
+
+// implemented in sbl_api.hip
+void sbl_pack(sbl_ctx *c);
+void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // fills d_bif[0..1], bif_count
+void sbl_compact_marks(sbl_ctx *c, int strand);
+// implemented in simplify.hip
+void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
+void sbl_simplify_free(sbl_ctx *c);

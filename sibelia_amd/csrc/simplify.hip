@@ -1,0 +1,504 @@
+// simplify.hip -- BlockFinder::PerformGraphSimplifications (reference src/blockfinder.cpp:78-98) on the GPU:
+//   enumeration (sbl_api.hip) -> instance lists (E2) -> SimplifyGraph rounds (simplify_steps.h) -> copy-back (T3).
+// Everything that touches sequence or graph data is a kernel in this file; the host only sequences
+// launches (simplify_driver.h) and reads a 64-byte counter block back per round.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#include "sbl_ctx.h"
+#include "kmer_kernels.h"
+#include "simplify_driver.h"
+
+static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------- graph construction kernels
+__global__ void __launch_bounds__(256) k_init_links(unsigned *__restrict__ nx, unsigned *__restrict__ pv, unsigned *__restrict__ nodeof0,
+                                                    unsigned *__restrict__ nodeof1, uint8_t *__restrict__ ch, size_t E, size_t cap)
+{
+	size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= cap) return;
+	if (e < E) { nx[e] = e + 1 < E ? (unsigned)(e + 1) : SBL_NONE; pv[e] = e ? (unsigned)(e - 1) : SBL_NONE; }
+	else { nx[e] = pv[e] = SBL_NONE; ch[e] = BT_DEAD_CHAR; }
+	nodeof0[e] = nodeof1[e] = SBL_NONE;
+}
+
+// sort key of an instance: (id << 32) | order, where ascending order reproduces the initial slist order of
+// BifurcationStorage (front insertion while scanning (chr,pos) ascending, reference src/indexedsequence.cpp:51-67
+// + src/bifurcationstorage.cpp:122): + list = elements descending; - list = chromosomes descending, elements ascending.
+__global__ void __launch_bounds__(256) k_instance_keys(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, unsigned n, unsigned strand,
+                                                       const unsigned *__restrict__ sepidx, unsigned nchr, unsigned E,
+                                                       unsigned long long *__restrict__ keys)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned e = elem[i], ord;
+	if (strand == 0) ord = 0xFFFFFFFFu - e;
+	else { unsigned c = chr_of(sepidx, nchr, e); ord = (E - sepidx[c + 1]) + (e - sepidx[c]); }
+	keys[i] = ((unsigned long long)id[i] << 32) | ord;
+}
+
+__global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ selem, unsigned n,
+                                                     unsigned node_base, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext,
+                                                     uint8_t *__restrict__ ndead, unsigned *__restrict__ head, unsigned *__restrict__ lsize,
+                                                     unsigned *__restrict__ nodeof)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned id = (unsigned)(skeys[i] >> 32), nd = node_base + i, e = selem[i];
+	bool last = i + 1 >= n || (unsigned)(skeys[i + 1] >> 32) != id;
+	bool first = i == 0 || (unsigned)(skeys[i - 1] >> 32) != id;
+	nslot[nd] = e; ndead[nd] = 0;
+	nnext[nd] = last ? SBL_NONE : nd + 1;
+	nodeof[e] = nd;
+	if (first) head[id] = nd;
+	atomicAdd(&lsize[id], 1u);
+}
+
+// ------------------------------------------------------------------------------------------- SimplifyGraph kernels
+__global__ void __launch_bounds__(256) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes)
+{
+	unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+	uint8_t *mine = arena + (size_t)tid * arena_bytes;
+	for (unsigned id = tid; id < g.nid; id += nthreads) ss_snapshot(g, id, mine, arena_bytes);
+}
+
+// one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
+// (and runs alone if it is the lowest).  out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
+__global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, unsigned lo, unsigned limit, unsigned W)
+{
+	__shared__ unsigned s_wave[16];
+	__shared__ unsigned s_base, s_first, s_bigid, s_stop, s_solo;
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (threadIdx.x == 0) { s_base = 0; s_first = SBL_NONE; s_stop = 0; s_solo = 0; }
+	__syncthreads();
+	for (unsigned long long start = lo; start <= limit; start += 1024) {
+		unsigned long long idl = start + threadIdx.x;
+		unsigned id = (unsigned)idl;
+		bool pend = idl <= limit && g.need[id];
+		bool isbig = pend && g.big[id];
+		if (threadIdx.x == 0) s_bigid = SBL_NONE;
+		__syncthreads();
+		if (isbig) atomicMin(&s_bigid, id);
+		if (pend) atomicMin(&s_first, id);
+		__syncthreads();
+		unsigned bigid = s_bigid;
+		bool take = pend && id < bigid;
+		unsigned long long m = __ballot(take);
+		unsigned before = __popcll(m & ((1ull << lane) - 1ull));
+		if (lane == 0) s_wave[wv] = __popcll(m);
+		__syncthreads();
+		unsigned woff = 0, total = 0;
+		for (unsigned w = 0; w < 16; w++) { unsigned v = s_wave[w]; if (w < wv) woff += v; total += v; }
+		unsigned pos = s_base + woff + before;
+		if (take && pos < W) win[pos] = id;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned cnt = s_base + total;
+			if (cnt >= W) { cnt = W; s_stop = 1; }
+			else if (bigid != SBL_NONE) {
+				s_stop = 1;
+				if (cnt == 0) { win[0] = bigid; cnt = 1; s_solo = 1; }
+			}
+			s_base = cnt;
+		}
+		__syncthreads();
+		if (s_stop) break;
+	}
+	if (threadIdx.x == 0) {
+		g.ctr[CTR_NWIN] = s_base;
+		g.ctr[CTR_LO] = s_first == SBL_NONE ? lo : s_first;
+		g.ctr[CTR_PUSHED] = s_solo;
+	}
+}
+
+__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin)
+{
+	unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w < nwin) ss_reserve(g, w);
+}
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo)
+{
+	unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w < nwin) ss_commit(g, w, arena + (size_t)w * arena_bytes, arena_bytes, solo != 0);
+}
+
+// ------------------------------------------------------------------------------------------- copy-back (T3) kernels
+// The list is a chain of "segments" = maximal runs of consecutive slots linked consecutively.  Heads are
+// found with a flag pass, segments are ranked by pointer jumping, elements scatter to rank + offset.
+__global__ void __launch_bounds__(256) k_seg_flags(const uint8_t *__restrict__ ch, const unsigned *__restrict__ nx, unsigned ne, unsigned *__restrict__ flag)
+{
+	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= ne) return;
+	bool alive = ch[e] != BT_DEAD_CHAR;
+	bool cont = e > 0 && ch[e - 1] != BT_DEAD_CHAR && nx[e - 1] == e;
+	flag[e] = alive && !cont ? 1u : 0u;
+}
+// segidx = inclusive scan of flag.  For every alive tail element: record its segment's tail and successor.
+__global__ void __launch_bounds__(256) k_seg_tails(const uint8_t *__restrict__ ch, const unsigned *__restrict__ nx, unsigned ne,
+                                                   const unsigned *__restrict__ flag, const unsigned *__restrict__ segidx /* exclusive scan */,
+                                                   unsigned *__restrict__ seg_head, unsigned *__restrict__ seg_len, unsigned *__restrict__ seg_succ_elem)
+{
+	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= ne || ch[e] == BT_DEAD_CHAR) return;
+	unsigned seg = segidx[e] + flag[e] - 1;            // exclusive scan + own flag - 1 = index of the segment containing e
+	if (flag[e]) seg_head[seg] = e;
+	bool tail = !(e + 1 < ne && ch[e + 1] != BT_DEAD_CHAR && nx[e] == e + 1);
+	if (tail) { seg_len[seg] = e; seg_succ_elem[seg] = nx[e]; }   // seg_len temporarily holds the tail element
+}
+__global__ void __launch_bounds__(256) k_seg_finish(unsigned nseg, const unsigned *__restrict__ seg_head, unsigned *__restrict__ seg_len,
+                                                    const unsigned *__restrict__ seg_succ_elem, const unsigned *__restrict__ flag,
+                                                    const unsigned *__restrict__ segidx, unsigned *__restrict__ succ, unsigned long long *__restrict__ dist)
+{
+	unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	unsigned len = seg_len[s] - seg_head[s] + 1;
+	seg_len[s] = len;
+	unsigned se = seg_succ_elem[s];
+	succ[s] = se == SBL_NONE ? SBL_NONE : segidx[se] + flag[se] - 1;
+	dist[s] = len;
+}
+// Wyllie pointer jumping: dist[s] = total length from s to the end of the chain
+__global__ void __launch_bounds__(256) k_seg_jump(unsigned nseg, const unsigned *__restrict__ succ_in, const unsigned long long *__restrict__ dist_in,
+                                                  unsigned *__restrict__ succ_out, unsigned long long *__restrict__ dist_out)
+{
+	unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nseg) return;
+	unsigned n = succ_in[s];
+	if (n == SBL_NONE) { succ_out[s] = SBL_NONE; dist_out[s] = dist_in[s]; }
+	else { succ_out[s] = succ_in[n]; dist_out[s] = dist_in[s] + dist_in[n]; }
+}
+__global__ void __launch_bounds__(256) k_scatter_linear(const uint8_t *__restrict__ ch, const unsigned *__restrict__ op, unsigned ne,
+                                                        const unsigned *__restrict__ flag, const unsigned *__restrict__ segidx,
+                                                        const unsigned *__restrict__ seg_head, const unsigned long long *__restrict__ dist,
+                                                        unsigned long long total, uint8_t *__restrict__ ch_out, unsigned *__restrict__ op_out,
+                                                        unsigned *__restrict__ newidx)
+{
+	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= ne) return;
+	if (ch[e] == BT_DEAD_CHAR) { newidx[e] = SBL_NONE; return; }
+	unsigned seg = segidx[e] + flag[e] - 1;
+	unsigned long long pos = total - dist[seg] + (e - seg_head[seg]);
+	ch_out[pos] = ch[e];
+	op_out[pos] = op[e] & BT_POS_MASK;
+	newidx[e] = (unsigned)pos;
+}
+__global__ void k_remap_seps(const unsigned *__restrict__ newidx, unsigned *__restrict__ sepidx, unsigned n)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) sepidx[i] = newidx[sepidx[i]];
+}
+__global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_t from, size_t to)
+{
+	size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < to) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------- device backend
+struct SimplifyState {
+	DevBuf ch, op, nx, pv, nodeof[2];
+	DevBuf nslot, nnext, nclr, ndead, head[2], lsize[2];
+	DevBuf ctr, need, big, own, lock, rmax, wmax, win;
+	DevBuf arena, snap_arena, big_arena;
+	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
+	DevBuf keys, skeys, selem, sorttmp, scantmp;
+	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
+	unsigned *h_ctr = nullptr;            // pinned
+};
+
+struct DeviceBackend {
+	sbl_ctx *c;
+	SimplifyState *st;
+	GraphView g{};
+	uint32_t cap_e = 0, cap_n = 0, nid_ = 0;
+	uint32_t ck_ne = 0, ck_nn = 0;
+	uint32_t window = 0, arena_bytes = 1u << 16, snap_arena_bytes = 1u << 13, snap_threads = 256 * 256;
+	uint32_t big_arena_bytes = 1u << 28;
+	size_t nres = 0;
+
+	uint32_t nid() { return nid_; }
+	void bind()
+	{
+		g.ch = st->ch.as<uint8_t>(); g.op = st->op.as<uint32_t>(); g.nx = st->nx.as<uint32_t>(); g.pv = st->pv.as<uint32_t>();
+		for (int s = 0; s < 2; s++) {
+			g.bif[s] = c->d_bif[s].as<uint32_t>(); g.nodeof[s] = st->nodeof[s].as<uint32_t>();
+			g.head[s] = st->head[s].as<uint32_t>(); g.lsize[s] = st->lsize[s].as<uint32_t>();
+		}
+		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
+		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>();
+		g.own = st->own.as<uint32_t>(); g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
+		g.cap_e = cap_e; g.cap_n = cap_n; g.nid = nid_;
+		g.nblk = (cap_e >> BT_BLOCK_SHIFT) + 1;
+		g.win = st->win.as<uint32_t>();
+		nres = (size_t)g.nblk + nid_ + 1;
+		st->lock.ensure(nres * 4); st->rmax.ensure(nres * 4); st->wmax.ensure(nres * 4);
+		g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
+	}
+	void read_ctr()
+	{
+		HIP_TRY(hipMemcpyAsync(st->h_ctr, st->ctr.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	void copy(DevBuf &dst, const DevBuf &src, size_t bytes)
+	{
+		dst.ensure(bytes);
+		if (bytes) HIP_TRY(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+	}
+	void checkpoint()
+	{
+		read_ctr();
+		ck_ne = st->h_ctr[CTR_NE]; ck_nn = st->h_ctr[CTR_NN];
+		copy(st->ck_ch, st->ch, ck_ne); copy(st->ck_op, st->op, (size_t)ck_ne * 4); copy(st->ck_nx, st->nx, (size_t)ck_ne * 4); copy(st->ck_pv, st->pv, (size_t)ck_ne * 4);
+		for (int s = 0; s < 2; s++) {
+			copy(st->ck_bif[s], c->d_bif[s], (size_t)ck_ne * 4); copy(st->ck_nodeof[s], st->nodeof[s], (size_t)ck_ne * 4);
+			copy(st->ck_head[s], st->head[s], ((size_t)nid_ + 1) * 4); copy(st->ck_lsize[s], st->lsize[s], ((size_t)nid_ + 1) * 4);
+		}
+		copy(st->ck_nslot, st->nslot, (size_t)ck_nn * 4); copy(st->ck_nnext, st->nnext, (size_t)ck_nn * 4); copy(st->ck_ndead, st->ndead, ck_nn);
+	}
+	void restore()
+	{
+		auto back = [&](DevBuf &dst, const DevBuf &src, size_t bytes) { if (bytes) HIP_TRY(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, c->stream)); };
+		back(st->ch, st->ck_ch, ck_ne); back(st->op, st->ck_op, (size_t)ck_ne * 4); back(st->nx, st->ck_nx, (size_t)ck_ne * 4); back(st->pv, st->ck_pv, (size_t)ck_ne * 4);
+		for (int s = 0; s < 2; s++) {
+			back(c->d_bif[s], st->ck_bif[s], (size_t)ck_ne * 4); back(st->nodeof[s], st->ck_nodeof[s], (size_t)ck_ne * 4);
+			back(st->head[s], st->ck_head[s], ((size_t)nid_ + 1) * 4); back(st->lsize[s], st->ck_lsize[s], ((size_t)nid_ + 1) * 4);
+		}
+		back(st->nslot, st->ck_nslot, (size_t)ck_nn * 4); back(st->nnext, st->ck_nnext, (size_t)ck_nn * 4); back(st->ndead, st->ck_ndead, ck_nn);
+		unsigned v[2] = { ck_ne, ck_nn };
+		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	void snapshot_all()
+	{
+		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
+		k_snapshot<<<snap_threads / 256, 256, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
+		HIP_TRY(hipGetLastError());
+	}
+	void reset_round_state(bool stamps_too)
+	{
+		HIP_TRY(hipMemsetAsync(st->own.p, 0xFF, ((size_t)nid_ + 1) * 4, c->stream));
+		HIP_TRY(hipMemsetAsync(st->lock.p, 0xFF, nres * 4, c->stream));
+		if (stamps_too) {
+			HIP_TRY(hipMemsetAsync(st->rmax.p, 0, nres * 4, c->stream));
+			HIP_TRY(hipMemsetAsync(st->wmax.p, 0, nres * 4, c->stream));
+		}
+	}
+	void clear_counters()
+	{
+		unsigned v[CTR_COUNT - 2] = {0};
+		v[CTR_VIOL - 2] = BT_NONE;
+		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + 2, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
+	{
+		k_select<<<1, 1024, 0, c->stream>>>(g, st->win.as<unsigned>(), lo, limit, W);
+		HIP_TRY(hipGetLastError());
+		read_ctr();
+		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
+	}
+	void reserve(uint32_t nwin, uint32_t round)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		k_reserve<<<nblocks(nwin, 64), 64, 0, c->stream>>>(g, nwin);
+		HIP_TRY(hipGetLastError());
+	}
+	void commit(uint32_t nwin, uint32_t round, bool solo)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		if (solo) {
+			st->big_arena.ensure(big_arena_bytes);
+			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1);
+		} else
+			k_commit<<<nblocks(nwin, 64), 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0);
+		HIP_TRY(hipGetLastError());
+	}
+	SimplifyCounters counters()
+	{
+		read_ctr();
+		SimplifyCounters r;
+		memcpy(r.v, st->h_ctr, sizeof r.v);
+		return r;
+	}
+	bool grow(uint32_t err)
+	{
+		if (err & ~(uint32_t)(BT_ERR_ELEM_CAP | BT_ERR_NODE_CAP)) return false;
+		hipStream_t s = c->stream;
+		if (err & BT_ERR_ELEM_CAP) {
+			size_t n = (size_t)cap_e * 2;
+			SBL_CHECK(n < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
+			st->ch.grow_keep(n, cap_e, s); st->op.grow_keep(n * 4, (size_t)cap_e * 4, s); st->nx.grow_keep(n * 4, (size_t)cap_e * 4, s); st->pv.grow_keep(n * 4, (size_t)cap_e * 4, s);
+			for (int k = 0; k < 2; k++) { c->d_bif[k].grow_keep(n * 4, (size_t)cap_e * 4, s); st->nodeof[k].grow_keep(n * 4, (size_t)cap_e * 4, s); }
+			cap_e = (uint32_t)n;
+		}
+		if (err & BT_ERR_NODE_CAP) {
+			size_t n = (size_t)cap_n * 2;
+			SBL_CHECK(n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
+			st->nslot.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nnext.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nclr.grow_keep(n * 4, (size_t)cap_n * 4, s);
+			st->ndead.grow_keep(n, cap_n, s);
+			cap_n = (uint32_t)n;
+		}
+		bind();
+		return true;
+	}
+};
+
+void sbl_simplify_free(sbl_ctx *c)
+{
+	SimplifyState *st = c->simp;
+	if (!st) return;
+	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nclr, &st->ndead,
+	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
+	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
+	for (DevBuf *b : bufs) b->release();
+	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
+	delete st;
+	c->simp = nullptr;
+}
+
+static void sort_pairs64(sbl_ctx *c, SimplifyState *st, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	st->sorttmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(st->sorttmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+}
+static void scan_u32(sbl_ctx *c, SimplifyState *st, unsigned *in, unsigned *out, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+	st->scantmp.ensure(tmp);
+	HIP_TRY(rocprim::exclusive_scan(st->scantmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+}
+
+void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
+{
+	hipStream_t s = c->stream;
+	if (!c->simp) { c->simp = new SimplifyState(); HIP_TRY(hipHostMalloc((void **)&c->simp->h_ctr, CTR_COUNT * 4)); }
+	SimplifyState *st = c->simp;
+	DeviceBackend be;
+	be.c = c; be.st = st;
+	c->stats = sbl_stage_stats{};
+	HIP_TRY(hipEventRecord(c->ev[2], s));
+
+	// ---- E1: enumeration into mark arrays with room for inserted elements
+	size_t E = c->nelem, ne0 = (E + 31) / 32 * 32;
+	size_t cap_e = ne0 + E / 8 + (1u << 20);
+	SBL_CHECK(cap_e < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
+	sbl_run_enumeration(c, k, cap_e);
+	be.nid_ = c->bif_count;
+	be.cap_e = (uint32_t)cap_e;
+
+	// ---- graph arrays
+	st->ch.ensure(cap_e); st->op.ensure(cap_e * 4); st->nx.ensure(cap_e * 4); st->pv.ensure(cap_e * 4);
+	st->nodeof[0].ensure(cap_e * 4); st->nodeof[1].ensure(cap_e * 4);
+	HIP_TRY(hipMemcpyAsync(st->ch.p, c->d_ch.p, E, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipMemcpyAsync(st->op.p, c->d_op.p, E * 4, hipMemcpyDeviceToDevice, s));
+	k_init_links<<<nblocks(cap_e, 256), 256, 0, s>>>(st->nx.as<unsigned>(), st->pv.as<unsigned>(), st->nodeof[0].as<unsigned>(), st->nodeof[1].as<unsigned>(),
+	                                                st->ch.as<uint8_t>(), E, cap_e);
+
+	// ---- E2: instance lists in the reference's initial order
+	sbl_compact_marks(c, 0);
+	sbl_compact_marks(c, 1);
+	size_t n0 = c->nmarks[0], n1 = c->nmarks[1], ninst = n0 + n1;
+	c->stats.instances = ninst;
+	size_t cap_n = 4 * ninst + (1u << 20);
+	SBL_CHECK(cap_n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
+	be.cap_n = (uint32_t)cap_n;
+	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);
+	size_t nidp = (size_t)be.nid_ + 1;
+	for (int t = 0; t < 2; t++) {
+		st->head[t].ensure(nidp * 4); st->lsize[t].ensure(nidp * 4);
+		HIP_TRY(hipMemsetAsync(st->head[t].p, 0xFF, nidp * 4, s));
+		HIP_TRY(hipMemsetAsync(st->lsize[t].p, 0, nidp * 4, s));
+	}
+	size_t nmax = std::max(n0, n1);
+	st->keys.ensure(nmax * 8 + 16); st->skeys.ensure(nmax * 8 + 16); st->selem.ensure(nmax * 4 + 16);
+	for (int t = 0; t < 2; t++) {
+		unsigned n = c->nmarks[t];
+		if (!n) continue;
+		k_instance_keys<<<nblocks(n, 256), 256, 0, s>>>(c->d_melem[t].as<unsigned>(), c->d_mid[t].as<unsigned>(), n, (unsigned)t,
+		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, st->keys.as<unsigned long long>());
+		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), c->d_melem[t].as<unsigned>(), st->selem.as<unsigned>(), n);
+		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), n, t ? (unsigned)n0 : 0u,
+		                                             st->nslot.as<unsigned>(), st->nnext.as<unsigned>(), st->ndead.as<uint8_t>(),
+		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>());
+	}
+	HIP_TRY(hipGetLastError());
+
+	// ---- control state
+	st->ctr.ensure(CTR_COUNT * 4);
+	{
+		unsigned v[CTR_COUNT] = {0};
+		v[CTR_NE] = (unsigned)ne0; v[CTR_NN] = (unsigned)ninst; v[CTR_VIOL] = BT_NONE;
+		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, sizeof v, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+	}
+	st->need.ensure(nidp); st->big.ensure(nidp); st->own.ensure(nidp * 4);
+	HIP_TRY(hipMemsetAsync(st->need.p, 0, nidp, s));
+	HIP_TRY(hipMemsetAsync(st->big.p, 0, nidp, s));
+	uint32_t window = c->window ? c->window : 16384;
+	window = std::min<uint32_t>(window, (1u << 20) - 1);
+	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
+	be.window = window;
+	st->win.ensure((size_t)window * 4 + 16);
+	st->arena.ensure((size_t)window * be.arena_bytes);
+	be.bind();
+	be.g.k = k; be.g.D = D;
+	HIP_TRY(hipEventRecord(c->ev[3], s));
+
+	// ---- SimplifyGraph
+	SimplifyReport rep = simplify_graph(be, max_iter, window, progress, user);
+	HIP_TRY(hipEventRecord(c->ev[4], s));
+
+	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays
+	be.read_ctr();
+	unsigned ne = st->h_ctr[CTR_NE];
+	st->flag.ensure((size_t)ne * 4 + 16); st->segidx.ensure((size_t)ne * 4 + 16); st->newidx.ensure((size_t)ne * 4 + 16);
+	k_seg_flags<<<nblocks(ne, 256), 256, 0, s>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), ne, st->flag.as<unsigned>());
+	scan_u32(c, st, st->flag.as<unsigned>(), st->segidx.as<unsigned>(), (size_t)ne + 1);
+	unsigned nseg = 0;
+	HIP_TRY(hipMemcpyAsync(&nseg, st->segidx.as<unsigned>() + ne, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	SBL_CHECK(nseg >= 1, SBL_ERR_INTERNAL, "copy-back: empty list");
+	st->seg_head.ensure((size_t)nseg * 4); st->seg_len.ensure((size_t)nseg * 4); st->seg_succ_elem.ensure((size_t)nseg * 4);
+	for (int t = 0; t < 2; t++) { st->succ[t].ensure((size_t)nseg * 4); st->dist[t].ensure((size_t)nseg * 8); }
+	k_seg_tails<<<nblocks(ne, 256), 256, 0, s>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), ne, st->flag.as<unsigned>(), st->segidx.as<unsigned>(),
+	                                            st->seg_head.as<unsigned>(), st->seg_len.as<unsigned>(), st->seg_succ_elem.as<unsigned>());
+	k_seg_finish<<<nblocks(nseg, 256), 256, 0, s>>>(nseg, st->seg_head.as<unsigned>(), st->seg_len.as<unsigned>(), st->seg_succ_elem.as<unsigned>(),
+	                                               st->flag.as<unsigned>(), st->segidx.as<unsigned>(), st->succ[0].as<unsigned>(), st->dist[0].as<unsigned long long>());
+	int cur = 0;
+	for (unsigned span = 1; span < nseg; span <<= 1, cur ^= 1)
+		k_seg_jump<<<nblocks(nseg, 256), 256, 0, s>>>(nseg, st->succ[cur].as<unsigned>(), st->dist[cur].as<unsigned long long>(),
+		                                             st->succ[cur ^ 1].as<unsigned>(), st->dist[cur ^ 1].as<unsigned long long>());
+	// segment 0 starts with element 0 (the first '$'), the head of the whole list: dist[0] = new total length
+	unsigned long long total = 0;
+	HIP_TRY(hipMemcpyAsync(&total, st->dist[cur].p, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	size_t Enew = (size_t)total, Epad = (Enew + 31) / 32 * 32 + 64;
+	st->ch_out.ensure(Epad); st->op_out.ensure(Enew * 4 + 16);
+	k_scatter_linear<<<nblocks(ne, 256), 256, 0, s>>>(st->ch.as<uint8_t>(), st->op.as<unsigned>(), ne, st->flag.as<unsigned>(), st->segidx.as<unsigned>(),
+	                                                 st->seg_head.as<unsigned>(), st->dist[cur].as<unsigned long long>(), total,
+	                                                 st->ch_out.as<uint8_t>(), st->op_out.as<unsigned>(), st->newidx.as<unsigned>());
+	k_fill_bytes<<<nblocks(Epad - Enew, 256), 256, 0, s>>>(st->ch_out.as<uint8_t>(), (uint8_t)'$', Enew, Epad);
+	k_remap_seps<<<nblocks(c->nchr + 1, 64), 64, 0, s>>>(st->newidx.as<unsigned>(), c->d_sepidx.as<unsigned>(), c->nchr + 1);
+	HIP_TRY(hipGetLastError());
+	std::swap(c->d_ch, st->ch_out);
+	std::swap(c->d_op, st->op_out);
+	HIP_TRY(hipMemcpyAsync(c->sepidx.data(), c->d_sepidx.p, (size_t)(c->nchr + 1) * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipEventRecord(c->ev[5], s));
+	HIP_TRY(hipStreamSynchronize(s));
+	c->nelem = Enew;
+
+	float ms_enum = 0, ms_simp = 0, ms_copy = 0;
+	HIP_TRY(hipEventElapsedTime(&ms_enum, c->ev[2], c->ev[3]));
+	HIP_TRY(hipEventElapsedTime(&ms_simp, c->ev[3], c->ev[4]));
+	HIP_TRY(hipEventElapsedTime(&ms_copy, c->ev[4], c->ev[5]));
+	c->stats.enumerate_ms = ms_enum; c->stats.simplify_ms = ms_simp; c->stats.copyback_ms = ms_copy;
+	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
+	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays;
+	*bulges = rep.bulges;
+}

@@ -1,0 +1,108 @@
+// simplify_driver.h -- host orchestration of SimplifyGraph (reference src/blockfinder.cpp:16-51).
+//
+// The driver only sequences launches and reads a handful of counters back per round; all graph
+// work is done by the backend's kernels (simplify.hip).  It is a template so that tests/hostsim can
+// drive the very same control flow over a host-memory backend.
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include <vector>
+
+#include "simplify_steps.h"
+
+struct SimplifyCounters {
+	uint32_t v[CTR_COUNT];
+};
+
+struct SimplifyReport {
+	uint64_t bulges = 0;
+	uint32_t iterations = 0, rounds = 0, replays = 0, solo = 0, grow_replays = 0;
+	uint64_t executed = 0;
+};
+
+// Backend concept:
+//   uint32_t nid();                                  number of bifurcation ids
+//   void checkpoint(); void restore();               iteration-level copy of every mutable array
+//   void snapshot_all();                             need[id] = AnyBulges verdict, for every id
+//   void reset_round_state(bool stamps_too);         own/lock = 0xFFFFFFFF (and rmax/wmax = 0)
+//   void clear_counters();                           ctr[ERR, BULGES, VIOL, BIG, COMMITTED] reset (VIOL = NONE)
+//   void select(lo, limit, W, &nwin, &newlo, &solo); lowest pending ids in [lo, limit]
+//   void reserve(nwin, round); void commit(nwin, round, solo);
+//   SimplifyCounters counters();                     device -> host
+//   bool grow(uint32_t err);                         enlarge element / node capacity after BT_ERR_*_CAP
+template <class Backend>
+SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, sbl_progress_fn progress, void *user)
+{
+	SimplifyReport rep;
+	const uint32_t nid = be.nid();
+	const uint64_t per_iter = (uint64_t)nid + 1;                      // ids 0 .. GetMaxId() inclusive
+	const uint64_t threshold = ((uint64_t)nid * max_iter) / 50;       // PROGRESS_STRIDE, blockfinder.cpp:28
+	uint64_t progress_calls = 0, total_progress = 0;
+	auto report_progress = [&](uint64_t processed) {
+		if (!progress) return;
+		uint64_t due = threshold ? processed / threshold : processed;
+		for (; progress_calls < due; progress_calls++) {
+			total_progress = std::min<uint64_t>(total_progress + 1, 50);
+			progress((size_t)total_progress, SBL_PROGRESS_RUN, user);
+		}
+	};
+	if (progress) progress(0, SBL_PROGRESS_START, user);
+	if (window == 0) window = 1;
+	if (window > (1u << 20) - 1) window = (1u << 20) - 1;
+	do {
+		rep.iterations++;
+		if (nid) {
+			be.checkpoint();
+			std::vector<uint32_t> fences;                                 // ids that must not be overtaken
+			uint64_t iter_bulges = 0;
+			for (;;) {                                                    // replay loop
+				bool replay = false;
+				be.snapshot_all();
+				be.reset_round_state(true);
+				be.clear_counters();
+				std::sort(fences.begin(), fences.end());
+				uint32_t lo = 0, round = 0;
+				size_t fi = 0;
+				for (;;) {
+					while (fi < fences.size() && fences[fi] < lo) fi++;
+					uint32_t limit = fi < fences.size() ? fences[fi] : nid - 1;
+					uint32_t nwin = 0, newlo = lo, solo = 0;
+					be.select(lo, limit, window, &nwin, &newlo, &solo);
+					if (nwin == 0) {
+						if (limit >= nid - 1) break;
+						lo = limit + 1;                                       // the fence's turn has passed
+						continue;
+					}
+					lo = newlo;
+					if (++round > SS_ROUND_MAX) { be.reset_round_state(false); round = 1; }
+					rep.rounds++;
+					if (solo) rep.solo++;
+					else be.reserve(nwin, round);
+					be.commit(nwin, round, solo != 0);
+					SimplifyCounters c = be.counters();
+					if (c.v[CTR_ERR]) {
+						if (!be.grow(c.v[CTR_ERR])) throw SblError{SBL_ERR_INTERNAL, "bulge removal: unrecoverable capacity error"};
+						replay = true; rep.grow_replays++;
+					} else if (c.v[CTR_VIOL] != BT_NONE) {
+						fences.push_back(c.v[CTR_VIOL]);
+						replay = true;
+					}
+					if (replay) break;
+					report_progress((uint64_t)(rep.iterations - 1) * per_iter + lo);
+				}
+				if (!replay) {
+					SimplifyCounters c = be.counters();
+					iter_bulges = c.v[CTR_BULGES];
+					rep.executed += c.v[CTR_COMMITTED];
+					break;
+				}
+				rep.replays++;
+				be.restore();
+			}
+			rep.bulges += iter_bulges;
+		}
+		report_progress((uint64_t)rep.iterations * per_iter);
+	} while (rep.bulges > 0 && rep.iterations < max_iter);
+	if (progress) progress(50, SBL_PROGRESS_END, user);
+	return rep;
+}

@@ -1,0 +1,64 @@
+// simplify_steps.h -- per-thread bodies of the simplification kernels (simplify.hip).
+//
+// SimplifyGraph (reference src/blockfinder.cpp:16-51) is strictly ordered: for iter, for id ascending,
+// RemoveBulges(id).  On the GPU one iteration becomes
+//   1. snapshot:  AnyBulges verdict of EVERY id against the graph at iteration start, one thread per id
+//                 (replaces ~instances x (D-1) x iterations cache-cold window steps of the reference);
+//   2. ordered rounds over the ids that need to run (verdict true, or made stale by an earlier commit):
+//        select   the W lowest pending ids,
+//        reserve  each claims every id marked in its neighbourhood with atomicMin(round | rank),
+//        commit   a transaction that owns its whole neighbourhood runs RemoveBulges for real; ids whose
+//                 windows or lists it changed are marked pending if they are still ahead in the order.
+//      A committed transaction is isolated inside its round (nobody else owns anything it can reach) and
+//      no lower pending id can reach what it touches, so the result equals the sequential order.
+//   3. validation: commits publish per-32-element-block and per-id read/write stamps; touching something
+//      a HIGHER id already wrote (or, for writers, read) means a lower id became pending too late -- the
+//      host then restores the iteration checkpoint and replays with that id as a fence.
+// Results are therefore exact by construction + detection, never by assumption.
+#pragma once
+#include "bulge_txn.h"
+
+#define SS_ROUND_MAX 4095u
+
+__host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uint8_t *arena, uint32_t arena_bytes)
+{
+	Txn t;
+	t.init(g, id, 0, 0, arena, arena_bytes);
+	bool v = bt_has_bulges(t);
+	if (t.err & BT_ERR_SCRATCH) v = true;      // undecidable in the small arena: let the ordered phase run it
+	g.need[id] = v ? 1 : 0;
+}
+
+__host__ __device__ inline void ss_reserve(const GraphView &g, uint32_t widx)
+{
+	uint32_t id = g.win[widx], st = g.round_bits | widx;
+	bt_footprint(g, id, [&](uint32_t b) { bt_atomic_min(&g.own[b], st); });
+}
+
+__host__ __device__ inline void ss_commit(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes, bool solo)
+{
+	uint32_t id = g.win[widx], st = g.round_bits | widx;
+	if (!solo) {
+		bool owner = true;
+		bt_footprint(g, id, [&](uint32_t b) { if (g.own[b] != st) owner = false; });
+		if (!owner) return;                    // stays pending
+	}
+	g.need[id] = 0;                            // cleared BEFORE running: a later push must survive
+	Txn t;
+	t.init(g, id, widx, 1, arena, arena_bytes);
+	bool has = bt_has_bulges(t);
+	if (t.err & BT_ERR_SCRATCH) {              // nothing written yet: hand over to the big-arena path
+		g.big[id] = 1; g.need[id] = 1;
+		bt_atomic_add(&g.ctr[CTR_BIG], 1u);
+		return;
+	}
+	bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u);
+	if (!has) return;
+	t.init(g, id, widx, 2, arena, arena_bytes);
+	uint32_t r = bt_remove_bulges(t);
+	if (t.err) {
+		if (!t.wrote && (t.err == BT_ERR_SCRATCH)) { g.big[id] = 1; g.need[id] = 1; bt_atomic_add(&g.ctr[CTR_BIG], 1u); return; }
+		bt_atomic_or(&g.ctr[CTR_ERR], t.err);
+	}
+	bt_atomic_add(&g.ctr[CTR_BULGES], r);
+}

@@ -1,0 +1,188 @@
+// hostsim.hip -- TEST INFRASTRUCTURE: runs the product's bulge-removal transaction code
+// (sibelia_amd/csrc/bulge_txn.h, simplify_steps.h, simplify_driver.h) on the HOST, one "thread" at a
+// time, so that the ordered-commit scheme can be checked against the oracle without a GPU
+// (tests/test_hostsim.py, CPU suite).  It is never linked into libsibelia_amd.so and is not a
+// fallback: the shipped library calls the same __host__ __device__ functions from kernels only.
+//
+// The window entries of a round are executed in ascending, descending or shuffled order to show
+// that the committed result does not depend on the execution order inside a round.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../sibelia_amd/csrc/sbl_common.h"
+#include "../../sibelia_amd/csrc/simplify_driver.h"
+
+namespace {
+
+struct HostBackend {
+	GraphView g{};
+	std::vector<uint8_t> ch, ndead, need, big;
+	std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, nclr, head[2], lsize[2], ctr, own, lock, rmax, wmax, win;
+	uint32_t nid_ = 0;
+	int order_mode = 0;
+	uint32_t arena_bytes = 1u << 16, big_arena_bytes = 1u << 26;
+	std::vector<uint8_t> arena, big_arena;
+	uint64_t rng = 88172645463325252ull;
+	// checkpoint
+	struct Ck { std::vector<uint8_t> ch, ndead; std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, head[2], lsize[2]; uint32_t ne, nn; } ck;
+
+	void bind()
+	{
+		g.ch = ch.data(); g.op = op.data(); g.nx = nx.data(); g.pv = pv.data();
+		for (int s = 0; s < 2; s++) { g.bif[s] = bif[s].data(); g.nodeof[s] = nodeof[s].data(); g.head[s] = head[s].data(); g.lsize[s] = lsize[s].data(); }
+		g.nslot = nslot.data(); g.nnext = nnext.data(); g.nclr = nclr.data(); g.ndead = ndead.data();
+		g.ctr = ctr.data(); g.need = need.data(); g.big = big.data();
+		g.own = own.data(); g.lock = lock.data(); g.rmax = rmax.data(); g.wmax = wmax.data();
+		g.cap_e = (uint32_t)ch.size(); g.cap_n = (uint32_t)nslot.size();
+		g.nblk = (g.cap_e >> BT_BLOCK_SHIFT) + 1;
+		g.win = win.data();
+	}
+	uint32_t nid() { return nid_; }
+	void checkpoint()
+	{
+		ck.ne = ctr[CTR_NE]; ck.nn = ctr[CTR_NN];
+		ck.ch = ch; ck.ndead = ndead; ck.op = op; ck.nx = nx; ck.pv = pv; ck.nslot = nslot; ck.nnext = nnext;
+		for (int s = 0; s < 2; s++) { ck.bif[s] = bif[s]; ck.nodeof[s] = nodeof[s]; ck.head[s] = head[s]; ck.lsize[s] = lsize[s]; }
+	}
+	void restore()
+	{
+		auto cp = [](auto &dst, const auto &src) { std::copy(src.begin(), src.end(), dst.begin()); };
+		cp(ch, ck.ch); cp(ndead, ck.ndead); cp(op, ck.op); cp(nx, ck.nx); cp(pv, ck.pv); cp(nslot, ck.nslot); cp(nnext, ck.nnext);
+		for (int s = 0; s < 2; s++) { cp(bif[s], ck.bif[s]); cp(nodeof[s], ck.nodeof[s]); cp(head[s], ck.head[s]); cp(lsize[s], ck.lsize[s]); }
+		ctr[CTR_NE] = ck.ne; ctr[CTR_NN] = ck.nn;
+	}
+	void snapshot_all()
+	{
+		for (uint32_t id = 0; id < nid_; id++) ss_snapshot(g, id, arena.data(), 1u << 14);
+	}
+	void reset_round_state(bool stamps_too)
+	{
+		std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
+		std::fill(lock.begin(), lock.end(), 0xFFFFFFFFu);
+		if (stamps_too) { std::fill(rmax.begin(), rmax.end(), 0u); std::fill(wmax.begin(), wmax.end(), 0u); }
+	}
+	void clear_counters()
+	{
+		ctr[CTR_ERR] = 0; ctr[CTR_BULGES] = 0; ctr[CTR_VIOL] = BT_NONE; ctr[CTR_BIG] = 0; ctr[CTR_COMMITTED] = 0;
+	}
+	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
+	{
+		uint32_t n = 0;
+		*solo = 0; *newlo = lo;
+		bool first = true;
+		for (uint32_t id = lo; id <= limit && n < W; id++) {
+			if (!need[id]) continue;
+			if (first) { *newlo = id; first = false; }
+			if (big[id]) { if (n == 0) { win[n++] = id; *solo = 1; } break; }
+			win[n++] = id;
+		}
+		*nwin = n;
+	}
+	std::vector<uint32_t> order(uint32_t n)
+	{
+		std::vector<uint32_t> o(n);
+		for (uint32_t i = 0; i < n; i++) o[i] = order_mode == 1 ? n - 1 - i : i;
+		if (order_mode == 2)
+			for (uint32_t i = n; i > 1; i--) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; std::swap(o[i - 1], o[rng % i]); }
+		return o;
+	}
+	void reserve(uint32_t nwin, uint32_t round)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		for (uint32_t w : order(nwin)) ss_reserve(g, w);
+	}
+	void commit(uint32_t nwin, uint32_t round, bool solo)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		if (solo) { ss_commit(g, 0, big_arena.data(), big_arena_bytes, true); return; }
+		for (uint32_t w : order(nwin)) ss_commit(g, w, arena.data(), arena_bytes, false);
+	}
+	SimplifyCounters counters() { SimplifyCounters c; memcpy(c.v, ctr.data(), sizeof c.v); return c; }
+	bool grow(uint32_t err)
+	{
+		if (err & BT_ERR_ELEM_CAP) {
+			size_t n = ch.size() * 2;
+			ch.resize(n); op.resize(n); nx.resize(n); pv.resize(n);
+			for (int s = 0; s < 2; s++) { bif[s].resize(n, BT_NONE); nodeof[s].resize(n); }
+			lock.assign((n >> BT_BLOCK_SHIFT) + 1 + nid_ + 1, 0xFFFFFFFFu); rmax.assign(lock.size(), 0); wmax.assign(lock.size(), 0);
+		}
+		if (err & BT_ERR_NODE_CAP) { size_t n = nslot.size() * 2; nslot.resize(n); nnext.resize(n); nclr.resize(n); ndead.resize(n); }
+		if (err & ~(uint32_t)(BT_ERR_ELEM_CAP | BT_ERR_NODE_CAP)) return false;
+		bind();
+		return true;
+	}
+};
+
+}  // namespace
+
+// Input: sanitised sequences + original positions, the enumeration (instances sorted by (chr,pos) per strand,
+// negative strand in reverse-complement coordinates).  Output: post-stage sequences / positions.
+// stats: [0]=iterations [1]=rounds [2]=replays [3]=solo rounds [4]=executed transactions
+extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uint32_t *const *opos, const uint64_t *len,
+                             uint32_t k, uint32_t D, uint32_t max_iter, uint32_t bif_count,
+                             const uint32_t *pos_inst, uint64_t n0, const uint32_t *neg_inst, uint64_t n1,
+                             uint32_t window, int order_mode, uint32_t arena_bytes, uint32_t slack_elems,
+                             uint8_t **out_seq, uint32_t **out_op, uint64_t *out_len, uint64_t *bulges, uint64_t *stats)
+{
+	try {
+		HostBackend be;
+		size_t L = 0;
+		for (uint32_t c = 0; c < nchr; c++) L += len[c];
+		size_t E = L + nchr + 1, ne0 = (E + 31) / 32 * 32, cap = ne0 + slack_elems;
+		be.nid_ = bif_count; be.order_mode = order_mode; be.arena_bytes = arena_bytes;
+		be.ch.assign(cap, BT_DEAD_CHAR); be.op.assign(cap, 0); be.nx.assign(cap, BT_NONE); be.pv.assign(cap, BT_NONE);
+		for (int s = 0; s < 2; s++) {
+			be.bif[s].assign(cap, BT_NONE); be.nodeof[s].assign(cap, BT_NONE);
+			be.head[s].assign((size_t)bif_count + 1, BT_NONE); be.lsize[s].assign((size_t)bif_count + 1, 0);
+		}
+		size_t ncap = n0 + n1 + 1024;
+		be.nslot.assign(ncap, 0); be.nnext.assign(ncap, BT_NONE); be.nclr.assign(ncap, BT_NONE); be.ndead.assign(ncap, 0);
+		be.ctr.assign(CTR_COUNT, 0); be.need.assign((size_t)bif_count + 1, 0); be.big.assign((size_t)bif_count + 1, 0);
+		be.own.assign((size_t)bif_count + 1, 0xFFFFFFFFu);
+		be.lock.assign((cap >> BT_BLOCK_SHIFT) + 1 + bif_count + 1, 0xFFFFFFFFu);
+		be.rmax.assign(be.lock.size(), 0); be.wmax.assign(be.lock.size(), 0);
+		be.win.assign(window ? window : 1, 0);
+		be.arena.assign(std::max<uint32_t>(arena_bytes, 1u << 14), 0); be.big_arena.assign(be.big_arena_bytes, 0);
+		std::vector<uint32_t> sep(nchr + 1);
+		size_t e = 0;
+		be.ch[e] = BT_SEP; sep[0] = 0; e++;
+		for (uint32_t c = 0; c < nchr; c++) {
+			for (uint64_t j = 0; j < len[c]; j++, e++) { be.ch[e] = seq[c][j]; be.op[e] = opos[c][j] & BT_POS_MASK; }
+			be.ch[e] = BT_SEP; be.op[e] = (uint32_t)len[c] & BT_POS_MASK; sep[c + 1] = (uint32_t)e; e++;
+		}
+		for (size_t i = 0; i < E; i++) { be.nx[i] = i + 1 < E ? (uint32_t)(i + 1) : BT_NONE; be.pv[i] = i ? (uint32_t)(i - 1) : BT_NONE; }
+		be.ctr[CTR_NE] = (uint32_t)ne0;
+		be.bind();
+		be.g.k = k; be.g.D = D; be.g.nid = bif_count;
+		// marking loop (reference src/indexedsequence.cpp:49-67): (chr,pos) ascending, front insertion
+		uint32_t nn = 0;
+		for (int s = 0; s < 2; s++) {
+			const uint32_t *inst = s ? neg_inst : pos_inst;
+			uint64_t n = s ? n1 : n0;
+			for (uint64_t i = 0; i < n; i++) {
+				uint32_t id = inst[3 * i], c = inst[3 * i + 1], p = inst[3 * i + 2];
+				uint32_t el = s == 0 ? sep[c] + 1 + p : sep[c + 1] - 1 - p;
+				uint32_t nd = nn++;
+				be.nslot[nd] = el; be.nnext[nd] = be.head[s][id]; be.head[s][id] = nd; be.lsize[s][id]++;
+				be.bif[s][el] = id; be.nodeof[s][el] = nd;
+			}
+		}
+		be.ctr[CTR_NN] = nn;
+		SimplifyReport rep = simplify_graph(be, max_iter, window, nullptr, nullptr);
+		for (uint32_t c = 0; c < nchr; c++) {
+			std::vector<uint8_t> s; std::vector<uint32_t> p;
+			for (uint32_t x = be.nx[sep[c]]; x != sep[c + 1]; x = be.nx[x]) { s.push_back(be.ch[x]); p.push_back(be.op[x] & BT_POS_MASK); }
+			out_len[c] = s.size();
+			out_seq[c] = (uint8_t *)malloc(s.size() + 1); out_op[c] = (uint32_t *)malloc(s.size() * 4 + 4);
+			memcpy(out_seq[c], s.data(), s.size()); memcpy(out_op[c], p.data(), p.size() * 4);
+		}
+		*bulges = rep.bulges;
+		stats[0] = rep.iterations; stats[1] = rep.rounds; stats[2] = rep.replays; stats[3] = rep.solo; stats[4] = rep.executed; stats[5] = rep.grow_replays;
+		return 0;
+	} catch (const SblError &err) {
+		fprintf(stderr, "hostsim: %s\n", err.msg.c_str());
+		return (int)err.st;
+	}
+}
+extern "C" void hostsim_free(void *p) { free(p); }

@@ -1,0 +1,84 @@
+"""HIP path vs the reference's golden vectors and vs the CPU oracle (needs an MI355X: -m gpu).
+
+Every call goes through the C ABI of libsibelia_amd.so (sibelia_amd.api.BlockFinder).  Bit-exact:
+bifurcation ids and instances, post-stage sequences, original positions, bulge counts, DOT text.
+"""
+import numpy as np
+import pytest
+
+from tests import vectors as V
+
+pytestmark = pytest.mark.gpu
+
+VECS = V.load_vectors()
+
+
+def _max_k(v):
+    return max(int(o["cmd"].split(":")[1]) for o in v["outputs"])
+
+
+SUPPORTED = [v for v in VECS if _max_k(v) <= 32]
+FAST = [v for v in SUPPORTED if not v["name"].startswith(("real/", "synth/strains2", "synth/strains8"))]
+BIG = [v for v in SUPPORTED if v["name"].startswith(("real/", "synth/strains2"))]
+
+
+def _bf(seqs):
+    from sibelia_amd import BlockFinder
+    return BlockFinder(seqs, device=0)
+
+
+@pytest.mark.parametrize("v", FAST, ids=[v["name"] for v in FAST])
+def test_hip_matches_reference(v):
+    V.replay(v, _bf)
+
+
+@pytest.mark.parametrize("v", BIG, ids=[v["name"] for v in BIG])
+def test_hip_matches_reference_genomes(v):
+    V.replay(v, _bf)
+
+
+@pytest.mark.parametrize("window", [1, 7, 100000])
+def test_window_size_does_not_change_results(window):
+    # the number of ids committed per ordered round is a pure performance knob
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=50_000, n=4, seed=5, inv_min=2000, inv_max=6000)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    bf.set_window(window)
+    assert bf.simplify_stage(25, 150, 4) == orc.simplify_stage(25, 150, 4)
+    (sa, pa), (sb, pb) = bf.state(), orc.state()
+    assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+
+
+def test_stage_cascade_matches_oracle_on_8_strains():
+    # config-3 shaped input at reduced length: 8 strains, stage (25,150) then (30,150) then (16,120)
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=300_000, n=8, seed=21, inv_min=5000, inv_max=20000)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    for k, d in ((25, 150), (30, 150), (16, 120)):
+        assert bf.simplify_stage(k, d, 4) == orc.simplify_stage(k, d, 4)
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    a, b = bf.enumerate(25), orc.enumerate(25)
+    assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+
+
+def test_progress_callback_contract():
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=20_000, n=2, seed=9, inv_min=500, inv_max=2000)
+    bf = _bf(seqs)
+    calls = []
+    bf.PerformGraphSimplifications(25, 150, 4, lambda p, s: calls.append((p, s)))
+    assert calls[0] == (0, 0) and calls[-1] == (50, 2)          # (0,start) ... (50,end), reference blockfinder.cpp:23-48
+    runs = [p for p, s in calls if s == 1]
+    assert runs == sorted(runs) and all(1 <= p <= 50 for p in runs)
+
+
+def test_errors_cross_the_abi_as_codes():
+    from sibelia_amd import SibeliaError
+    bf = _bf([b"ACGTACGTAC"])
+    with pytest.raises(SibeliaError):
+        bf.enumerate(1)                                          # k < 2 is rejected (reference src/util.cpp:38-41)
+    with pytest.raises(SibeliaError):
+        bf.simplify_stage(33, 100, 4)                            # long-k path not in this build yet
