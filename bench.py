@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s of the BlockFinder stage (graph build + simplify) on MI355X.
+
+A "step" is one PerformGraphSimplifications(k=25, D=150, maxIterations=4) over the workload
+BASELINE.json's metric is quoted on: 8 E. coli-like strains (synthetic, sibelia_amd.workloads.gen_strains,
+4.6 Mbp each, seed 1 -- real E. coli genomes are not available offline), k = 25.
+Inputs are resident in HBM when the timed region starts (sbl_restore_state is a device-to-device copy
+of the saved stage-boundary state and is inside the timed region).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 (launched through torch.distributed.run, one rank per GPU over RCCL): the bulge-removal order is
+global, so the path does not shard in this round -- every rank runs the whole job on its own strain set
+("replicas only", weak scaling, no data-path collective); value = strand-k-mers of all ranks / max time.
+
+The JSON line also carries
+  roofline      the dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/, a bit-exact port of the reference algorithm) timed on rank 0 on a
+                bounded sample of the same workload (8 strains, shorter genomes)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--strains", type=int, default=8)
+    ap.add_argument("--L0", type=int, default=4_600_000)
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--D", type=int, default=150)
+    ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--cpu-sample-L0", type=int, default=1_200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no host compute path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import __graft_entry__ as G
+    if rank == 0:
+        G.build()
+    if world > 1:
+        dist.barrier()
+    from sibelia_amd import BlockFinder, workloads as W
+
+    # every rank owns its own strain set (same generator, rank-specific seed): independent jobs, no collective
+    seqs = W.gen_strains(L0=a.L0, n=a.strains, seed=1 + rank)
+    N = W.strand_kmers(seqs, a.k)
+    bf = BlockFinder(seqs, device=local)
+    if a.window:
+        bf.set_window(a.window)
+    bf.save_state()
+
+    def step():
+        bf.restore_state()
+        return bf.PerformGraphSimplifications(a.k, a.D, a.iters)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agg = {}
+    for _ in range(a.steps):
+        bulges = step()
+        st = bf.stats()
+        for key, v in st.items():
+            if key.endswith("_ms"):
+                agg[key] = agg.get(key, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        nt = torch.tensor([float(N)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+        Ntot = float(nt.item())
+    else:
+        Ntot = float(N)
+
+    if rank == 0:
+        st = bf.stats()
+        ms_step = 1000.0 * dt / a.steps
+        # dominant kernel by accumulated HIP-event time
+        per = {"k_kmer_table_build": agg.get("kmer_table_ms", 0.0) / a.steps,
+               "k_snapshot": agg.get("snapshot_ms", 0.0) / a.steps,
+               "k_reserve": agg.get("reserve_ms", 0.0) / a.steps,
+               "k_commit": agg.get("commit_ms", 0.0) / a.steps}
+        launches = {"k_kmer_table_build": 1, "k_snapshot": max(1, st["iterations"] + st["replays"]),
+                    "k_reserve": max(1, st["rounds"]), "k_commit": max(1, st["rounds"])}
+        # algorithmic HBM bytes per launch: table build = 32 B per base position + packed
+        # sequence; snapshot = 4 B per strand-k-mer (one pass over the dense mark arrays);
+        # reserve/commit = 4 B x 2 strands x neighbourhood (3(D+k)+k elements) per instance of every executed id
+        nbh = 3 * (a.D + a.k) + a.k
+        inst_per_launch = st["instances"] / max(1, st["bif_count"]) * st["executed"] / max(1, st["rounds"])
+        alg = {"k_kmer_table_build": float(st["kmer_table_bytes"]), "k_snapshot": 4.0 * N,
+               "k_reserve": 8.0 * nbh * inst_per_launch, "k_commit": 8.0 * (a.D + a.k) * inst_per_launch}
+        dom = max(per, key=lambda kk: per[kk])
+        dur_ms = per[dom] / launches[dom]
+        achieved = alg[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        out = {
+            "metric": "k-mers/sec in BlockFinder graph-build+simplify, 8xE.coli k=25",
+            "value": Ntot / (dt / a.steps), "unit": "strand-k-mers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1, 1%% SNP, indels, inversions), "
+                                   "k=%d D=%d maxIterations=%d, one full stage" % (a.strains, a.L0 / 1e6, a.k, a.D, a.iters),
+                       "strand_kmers_per_gpu": N, "parallelism": "replicas only (x%d)" % world if world > 1 else "1 GPU",
+                       "bulges": bulges, "bif_ids": st["bif_count"], "instances": st["instances"],
+                       "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"]},
+            "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg[dom],
+                         "all_kernels_ms_per_step": per},
+        }
+        if not a.no_cpu_baseline:
+            from oracle.oracle import Oracle
+            sample = W.gen_strains(L0=a.cpu_sample_L0, n=a.strains, seed=1)
+            o = Oracle(sample)
+            t1 = time.perf_counter()
+            ob = o.simplify_stage(a.k, a.D, a.iters)
+            cdt = time.perf_counter() - t1
+            Ns = W.strand_kmers(sample, a.k)
+            out["cpu_baseline"] = {"value": Ns / cdt, "unit": "strand-k-mers/s", "cores": 1, "kind": "port",
+                                   "sample": "%d strains x %.1f Mbp from the same generator (%d strand-k-mers, %.1f s, %d bulges); "
+                                             "the oracle is ~8x faster than the reference binary on 8 strains (BASELINE.md: 0.147 M/s)"
+                                             % (a.strains, a.cpu_sample_L0 / 1e6, Ns, cdt, ob)}
+            if a.check:
+                g2 = BlockFinder(sample, device=local)
+                gb = g2.PerformGraphSimplifications(a.k, a.D, a.iters)
+                (sa, pa), (sb, pb) = g2.state(), o.state()
+                import numpy as np
+                ok = gb == ob and sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+                out["parity_check"] = "bit-exact vs oracle on the CPU sample" if ok else "MISMATCH"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,8 @@ typedef struct {
 	double enumerate_ms, simplify_ms, copyback_ms, total_ms;
 	double kmer_table_ms;            /* duration of the dominant kernel (k-mer table build) */
 	uint64_t kmer_table_bytes;       /* its algorithmic HBM bytes */
+	double snapshot_ms, reserve_ms, commit_ms;   /* SimplifyGraph kernel time by phase */
+	uint64_t executed;               /* RemoveBulges transactions run in ordered rounds */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).
@@ -97,6 +99,11 @@ uint32_t sbl_nchr(const sbl_ctx *ctx);
 /* Replaces BlockFinder::ListEdges on a fresh index at k (src/serialization.cpp:56-86), the
  * observation channel behind SerializeCondensedGraph (src/serialization.cpp:88-110). */
 sbl_status sbl_list_edges(sbl_ctx *ctx, uint32_t k, const sbl_edge **edges, uint64_t *n);
+
+/* Stage-boundary checkpoint of the resident state (sequences + original positions), device to device.
+ * The reference keeps no resumable state; the stage boundary is the natural one. */
+sbl_status sbl_save_state(sbl_ctx *ctx);
+sbl_status sbl_restore_state(sbl_ctx *ctx);
 
 sbl_status sbl_last_stats(const sbl_ctx *ctx, sbl_stage_stats *out);
 const char *sbl_last_error(const sbl_ctx *ctx);

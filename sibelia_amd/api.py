@@ -22,14 +22,16 @@ EDGE_DTYPE = formats.EDGE_DTYPE
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
-           "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window"]
+           "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
+           "sbl_save_state", "sbl_restore_state"]
 
 
 class StageStats(C.Structure):
     _fields_ = [("strand_kmers", C.c_uint64), ("bif_count", C.c_uint64), ("instances", C.c_uint64), ("bulges", C.c_uint64),
                 ("iterations", C.c_uint32), ("rounds", C.c_uint32), ("replays", C.c_uint32), ("reserved_", C.c_uint32),
                 ("enumerate_ms", C.c_double), ("simplify_ms", C.c_double), ("copyback_ms", C.c_double), ("total_ms", C.c_double),
-                ("kmer_table_ms", C.c_double), ("kmer_table_bytes", C.c_uint64)]
+                ("kmer_table_ms", C.c_double), ("kmer_table_bytes", C.c_uint64),
+                ("snapshot_ms", C.c_double), ("reserve_ms", C.c_double), ("commit_ms", C.c_double), ("executed", C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved_"}
@@ -67,6 +69,8 @@ def load_library():
         L.sbl_strerror.argtypes = [C.c_int]
         L.sbl_strerror.restype = C.c_char_p
         L.sbl_set_window.argtypes = [C.c_void_p, C.c_uint32]
+        L.sbl_save_state.argtypes = [C.c_void_p]
+        L.sbl_restore_state.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -151,6 +155,12 @@ class BlockFinder:
         s = StageStats()
         self.L.sbl_last_stats(self.h, C.byref(s))
         return s.as_dict()
+
+    def save_state(self) -> None:
+        self._check(self.L.sbl_save_state(self.h), "sbl_save_state")
+
+    def restore_state(self) -> None:
+        self._check(self.L.sbl_restore_state(self.h), "sbl_restore_state")
 
     def set_window(self, w: int) -> None:
         self.L.sbl_set_window(self.h, w)

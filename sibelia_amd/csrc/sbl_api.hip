@@ -247,7 +247,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_simplify_free(c);
 	DevBuf *bufs[] = { &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -414,6 +414,34 @@ extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **se
 		if (seq) *seq = c->h_seq[chr].data();
 		if (orig_pos) *orig_pos = c->h_op[chr].data();
 		if (len) *len = c->h_seq[chr].size();
+	});
+}
+
+extern "C" sbl_status sbl_save_state(sbl_ctx *c)
+{
+	return guarded(c, [&] {
+		size_t Epad = (c->nelem + 31) / 32 * 32 + 64;
+		c->d_save_ch.ensure(Epad); c->d_save_op.ensure(c->nelem * 4 + 16);
+		HIP_TRY(hipMemcpyAsync(c->d_save_ch.p, c->d_ch.p, Epad, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_save_op.p, c->d_op.p, c->nelem * 4, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->save_nelem = c->nelem; c->save_sepidx = c->sepidx; c->save_amb_elem = c->amb_elem; c->save_amb_orig = c->amb_orig;
+		c->save_rng = c->rng; c->saved = true;
+	});
+}
+extern "C" sbl_status sbl_restore_state(sbl_ctx *c)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(c->saved, SBL_ERR_BAD_ARG, "no saved state");
+		size_t Epad = (c->save_nelem + 31) / 32 * 32 + 64;
+		c->d_ch.ensure(Epad); c->d_op.ensure(c->save_nelem * 4 + 16);
+		HIP_TRY(hipMemcpyAsync(c->d_ch.p, c->d_save_ch.p, Epad, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_op.p, c->d_save_op.p, c->save_nelem * 4, hipMemcpyDeviceToDevice, c->stream));
+		c->nelem = c->save_nelem; c->sepidx = c->save_sepidx; c->amb_elem = c->save_amb_elem; c->amb_orig = c->save_amb_orig;
+		c->rng = c->save_rng;
+		HIP_TRY(hipMemcpyAsync(c->d_sepidx.p, c->sepidx.data(), c->sepidx.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		drop_host_state(c);
 	});
 }
 

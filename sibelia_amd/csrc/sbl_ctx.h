@@ -21,6 +21,14 @@ struct sbl_ctx {
 	std::vector<uint8_t> amb_orig;       // their original characters
 	DevBuf d_amb_elem, d_amb_char;
 
+	// stage-boundary checkpoint (sbl_save_state / sbl_restore_state)
+	DevBuf d_save_ch, d_save_op;
+	size_t save_nelem = 0;
+	std::vector<uint32_t> save_sepidx, save_amb_elem;
+	std::vector<uint8_t> save_amb_orig;
+	GlibcRand save_rng;
+	bool saved = false;
+
 	// host mirrors for sbl_get_state
 	bool host_state_valid = false;
 	std::vector<std::vector<uint8_t>> h_seq;

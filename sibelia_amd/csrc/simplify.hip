@@ -112,15 +112,85 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 	}
 }
 
-__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin)
+// ---- wave-cooperative neighbourhood scan -----------------------------------------------------------------
+// The list is almost everywhere laid out consecutively (nx[e] == e + 1), so 64 lanes test 64 consecutive
+// slots at once, keep the prefix whose links are intact, and only re-anchor at a real link break
+// (an insertion or deletion made by an earlier collapse).  Visits exactly the elements bt_footprint visits.
+#define CLAIM_CAP 4096u                      // ids a window entry can list; beyond that commit re-walks serially
+
+struct ClaimList { unsigned *buf; unsigned n; };
+
+__device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
 {
-	unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
-	if (w < nwin) ss_reserve(g, w);
+	bool has = b != BT_NONE;
+	if (has) atomicMin(&g.own[b], st);
+	unsigned long long m = __ballot(has);
+	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
+	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b;
+	cl.n += __popcll(m);
 }
-__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo)
+
+__device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
+                                                ClaimList &cl, unsigned st)
 {
-	unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
-	if (w < nwin) ss_commit(g, w, arena + (size_t)w * arena_bytes, arena_bytes, solo != 0);
+	unsigned cur = first, done = 0;
+	while (done < maxcount && cur != BT_NONE) {
+		bool inr = done + lane < maxcount && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
+		unsigned c = dir ? cur - lane : cur + lane;
+		bool link = inr && (lane == 0 || (dir ? g.pv[c + 1] == c : g.nx[c - 1] == c));
+		unsigned long long ml = __ballot(link);
+		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);      // intact prefix, >= 1
+		bool mine = lane < pre;
+		unsigned chv = mine ? g.ch[c] : 0u;
+		unsigned long long ms = __ballot(mine && chv == BT_SEP);
+		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
+		bool proc = lane < pre && lane < stop;
+		unsigned b0 = proc ? g.bif[0][c] : BT_NONE, b1 = proc ? g.bif[1][c] : BT_NONE;
+		wave_claim(g, cl, st, b0, lane);
+		wave_claim(g, cl, st, b1, lane);
+		if (stop < pre) break;
+		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
+		cur = __shfl(lnk, pre - 1);
+		done += pre;
+	}
+}
+
+// one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
+__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims)
+{
+	unsigned w = blockIdx.x, lane = threadIdx.x;
+	if (w >= nwin) return;
+	unsigned id = g.win[w], st = g.round_bits | w;
+	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0;
+	wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
+	unsigned back = g.D + g.k, fwd = 2 * (g.D + g.k) + g.k;
+	for (unsigned s = 0; s < 2; s++)
+		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+			if (g.ndead[nd]) continue;
+			unsigned e0 = g.nslot[nd];
+			wave_walk_claim(g, e0, s, fwd + 1, lane, cl, st);
+			wave_walk_claim(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, cl, st);
+		}
+	if (lane == 0) cl.buf[0] = cl.n;
+}
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims)
+{
+	unsigned w = blockIdx.x, lane = threadIdx.x;
+	if (w >= nwin) return;
+	if (!solo) {
+		const unsigned *cb = claims + (size_t)w * (CLAIM_CAP + 1);
+		unsigned n = cb[0], st = g.round_bits | w;
+		bool owner = true;
+		if (n <= CLAIM_CAP) {
+			for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != st) owner = false;
+			owner = !__any(!owner);
+		} else {
+			if (lane == 0) owner = ss_owns_footprint(g, w);      // list overflowed: serial re-walk
+			owner = __shfl((int)owner, 0) != 0;
+		}
+		if (!owner) return;
+	}
+	if (lane == 0) ss_commit_run(g, w, arena + (size_t)w * arena_bytes, arena_bytes);
 }
 
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
@@ -199,7 +269,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena;
+	DevBuf arena, snap_arena, big_arena, claims;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
@@ -215,6 +285,9 @@ struct DeviceBackend {
 	uint32_t window = 0, arena_bytes = 1u << 16, snap_arena_bytes = 1u << 13, snap_threads = 256 * 256;
 	uint32_t big_arena_bytes = 1u << 28;
 	size_t nres = 0;
+	hipEvent_t ev[6] = {};
+	bool timed_reserve = false, timed_commit = false;
+	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0;
 
 	uint32_t nid() { return nid_; }
 	void bind()
@@ -271,8 +344,14 @@ struct DeviceBackend {
 	void snapshot_all()
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
+		HIP_TRY(hipEventRecord(ev[4], c->stream));
 		k_snapshot<<<snap_threads / 256, 256, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
+		HIP_TRY(hipEventRecord(ev[5], c->stream));
 		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5]));
+		snapshot_ms += ms;
 	}
 	void reset_round_state(bool stamps_too)
 	{
@@ -300,22 +379,31 @@ struct DeviceBackend {
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		k_reserve<<<nblocks(nwin, 64), 64, 0, c->stream>>>(g, nwin);
+		HIP_TRY(hipEventRecord(ev[0], c->stream));
+		k_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>());
+		HIP_TRY(hipEventRecord(ev[1], c->stream));
+		timed_reserve = true;
 		HIP_TRY(hipGetLastError());
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
-			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1);
+			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr);
 		} else
-			k_commit<<<nblocks(nwin, 64), 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0);
+			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>());
+		HIP_TRY(hipEventRecord(ev[3], c->stream));
+		timed_commit = true;
 		HIP_TRY(hipGetLastError());
 	}
 	SimplifyCounters counters()
 	{
 		read_ctr();
+		float ms = 0;
+		if (timed_reserve) { HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); reserve_ms += ms; timed_reserve = false; }
+		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_ms += ms; timed_commit = false; }
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
 		return r;
@@ -329,6 +417,10 @@ struct DeviceBackend {
 			SBL_CHECK(n < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
 			st->ch.grow_keep(n, cap_e, s); st->op.grow_keep(n * 4, (size_t)cap_e * 4, s); st->nx.grow_keep(n * 4, (size_t)cap_e * 4, s); st->pv.grow_keep(n * 4, (size_t)cap_e * 4, s);
 			for (int k = 0; k < 2; k++) { c->d_bif[k].grow_keep(n * 4, (size_t)cap_e * 4, s); st->nodeof[k].grow_keep(n * 4, (size_t)cap_e * 4, s); }
+			HIP_TRY(hipMemsetAsync(st->ch.as<uint8_t>() + cap_e, 0, n - cap_e, s));
+			HIP_TRY(hipMemsetAsync(st->nx.as<unsigned>() + cap_e, 0xFF, (n - cap_e) * 4, s));
+			HIP_TRY(hipMemsetAsync(st->pv.as<unsigned>() + cap_e, 0xFF, (n - cap_e) * 4, s));
+			for (int k = 0; k < 2; k++) HIP_TRY(hipMemsetAsync(c->d_bif[k].as<unsigned>() + cap_e, 0xFF, (n - cap_e) * 4, s));
 			cap_e = (uint32_t)n;
 		}
 		if (err & BT_ERR_NODE_CAP) {
@@ -349,7 +441,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -446,6 +538,8 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	be.window = window;
 	st->win.ensure((size_t)window * 4 + 16);
 	st->arena.ensure((size_t)window * be.arena_bytes);
+	st->claims.ensure((size_t)window * (CLAIM_CAP + 1) * 4);
+	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.bind();
 	be.g.k = k; be.g.D = D;
 	HIP_TRY(hipEventRecord(c->ev[3], s));
@@ -500,5 +594,8 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.enumerate_ms = ms_enum; c->stats.simplify_ms = ms_simp; c->stats.copyback_ms = ms_copy;
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays;
+	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms;
+	c->stats.executed = rep.executed;
+	for (auto &e : be.ev) (void)hipEventDestroy(e);
 	*bulges = rep.bulges;
 }

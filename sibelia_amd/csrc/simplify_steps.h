@@ -35,14 +35,10 @@ __host__ __device__ inline void ss_reserve(const GraphView &g, uint32_t widx)
 	bt_footprint(g, id, [&](uint32_t b) { bt_atomic_min(&g.own[b], st); });
 }
 
-__host__ __device__ inline void ss_commit(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes, bool solo)
+// the transaction proper, for a window entry that owns its whole neighbourhood
+__host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
 {
-	uint32_t id = g.win[widx], st = g.round_bits | widx;
-	if (!solo) {
-		bool owner = true;
-		bt_footprint(g, id, [&](uint32_t b) { if (g.own[b] != st) owner = false; });
-		if (!owner) return;                    // stays pending
-	}
+	uint32_t id = g.win[widx];
 	g.need[id] = 0;                            // cleared BEFORE running: a later push must survive
 	Txn t;
 	t.init(g, id, widx, 1, arena, arena_bytes);
@@ -61,4 +57,18 @@ __host__ __device__ inline void ss_commit(const GraphView &g, uint32_t widx, uin
 		bt_atomic_or(&g.ctr[CTR_ERR], t.err);
 	}
 	bt_atomic_add(&g.ctr[CTR_BULGES], r);
+}
+
+__host__ __device__ inline bool ss_owns_footprint(const GraphView &g, uint32_t widx)
+{
+	uint32_t id = g.win[widx], st = g.round_bits | widx;
+	bool owner = true;
+	bt_footprint(g, id, [&](uint32_t b) { if (g.own[b] != st) owner = false; });
+	return owner;
+}
+
+__host__ __device__ inline void ss_commit(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes, bool solo)
+{
+	if (!solo && !ss_owns_footprint(g, widx)) return;      // stays pending
+	ss_commit_run(g, widx, arena, arena_bytes);
 }
