@@ -28,13 +28,13 @@ EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simpli
 
 class StageStats(C.Structure):
     _fields_ = [("strand_kmers", C.c_uint64), ("bif_count", C.c_uint64), ("instances", C.c_uint64), ("bulges", C.c_uint64),
-                ("iterations", C.c_uint32), ("rounds", C.c_uint32), ("replays", C.c_uint32), ("reserved_", C.c_uint32),
+                ("iterations", C.c_uint32), ("rounds", C.c_uint32), ("replays", C.c_uint32), ("grow_replays", C.c_uint32),
                 ("enumerate_ms", C.c_double), ("simplify_ms", C.c_double), ("copyback_ms", C.c_double), ("total_ms", C.c_double),
                 ("kmer_table_ms", C.c_double), ("kmer_table_bytes", C.c_uint64),
                 ("snapshot_ms", C.c_double), ("reserve_ms", C.c_double), ("commit_ms", C.c_double), ("executed", C.c_uint64)]
 
     def as_dict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved_"}
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 class SibeliaError(RuntimeError):

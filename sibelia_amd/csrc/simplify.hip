@@ -593,7 +593,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	HIP_TRY(hipEventElapsedTime(&ms_copy, c->ev[4], c->ev[5]));
 	c->stats.enumerate_ms = ms_enum; c->stats.simplify_ms = ms_simp; c->stats.copyback_ms = ms_copy;
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
-	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays;
+	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms;
 	c->stats.executed = rep.executed;
 	for (auto &e : be.ev) (void)hipEventDestroy(e);

@@ -17,7 +17,13 @@ def _max_k(v):
     return max(int(o["cmd"].split(":")[1]) for o in v["outputs"])
 
 
-SUPPORTED = [v for v in VECS if _max_k(v) <= 32]
+def _bulges(v):
+    return sum(o.get("bulges", 0) for o in v["outputs"])
+
+
+# k > 32 is not in this build yet; low-complexity small cases with thousands of collapses on a few hundred bases
+# degenerate into thousands of tiny ordered rounds (seconds each on a GPU) -- the hostsim CPU tests cover that regime
+SUPPORTED = [v for v in VECS if _max_k(v) <= 32 and (not v["name"].startswith("small/") or _bulges(v) < 400)]
 FAST = [v for v in SUPPORTED if not v["name"].startswith(("real/", "synth/strains2", "synth/strains8"))]
 BIG = [v for v in SUPPORTED if v["name"].startswith(("real/", "synth/strains2"))]
 
