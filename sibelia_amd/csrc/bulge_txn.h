@@ -31,7 +31,7 @@ enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
 struct GraphView {
 	uint8_t *ch; uint32_t *op, *nx, *pv;
 	uint32_t *bif[2], *nodeof[2];
-	uint32_t *nslot, *nnext, *nclr; uint8_t *ndead;   // nclr: chain of nodes erased by the running transaction
+	uint32_t *nslot, *nnext, *nidst, *nclr; uint8_t *ndead;   // nidst: (id << 1) | strand of the node's list; nclr: chain of nodes erased by the running transaction
 	uint32_t *head[2], *lsize[2];
 	uint32_t *ctr;
 	uint32_t cap_e, cap_n;
@@ -143,7 +143,7 @@ struct Txn {
 		uint32_t nd = bt_atomic_add(&g.ctr[CTR_NN], 1u);
 		if (nd >= g.cap_n) { err |= BT_ERR_NODE_CAP; return; }
 		tw(a.e); iw(b);
-		g.nslot[nd] = a.e; g.ndead[nd] = 0;
+		g.nslot[nd] = a.e; g.ndead[nd] = 0; g.nidst[nd] = (b << 1) | a.d;
 		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
 		g.lsize[a.d][b]++;
 		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
@@ -158,15 +158,14 @@ struct Txn {
 		tw(a.e); iw(b);
 		uint32_t nd = g.nodeof[a.d][a.e];
 		g.bif[a.d][a.e] = BT_NONE;
-		g.ndead[nd] = 1;
-		g.nslot[nd] = (b << 1) | a.d;        // a dead node is never dereferenced again: remember its list instead
+		g.ndead[nd] = 1;                     // the node keeps its element: a proxy that is already in use stays dereferenceable
 		g.nclr[nd] = tc_head; tc_head = nd;
 		push_dirty(b);
 	}
 	// Cleanup, bifurcationstorage.cpp:33-41
 	__host__ __device__ void cleanup()
 	{
-		for (uint32_t nd = tc_head; nd != BT_NONE; nd = g.nclr[nd]) g.lsize[g.nslot[nd] & 1][g.nslot[nd] >> 1]--;
+		for (uint32_t nd = tc_head; nd != BT_NONE; nd = g.nclr[nd]) g.lsize[g.nidst[nd] & 1][g.nidst[nd] >> 1]--;
 		tc_head = BT_NONE;
 	}
 	__host__ __device__ __forceinline__ uint32_t count_bif(uint32_t b) { ir(b); return g.lsize[0][b] + g.lsize[1][b]; }   // :71-75
@@ -274,17 +273,33 @@ __host__ __device__ inline void bt_sort_u32(uint32_t *a, uint32_t n)
 }
 
 // ------------------------------------------------------------------------------------------- the transaction
+// AnyBulges result: group g's members are grp_mem[grp_off[g] .. grp_off[g+1]), in unordered_map iteration order.
+struct AnyBulgesOut { uint32_t ngroups; uint32_t *grp_off; uint32_t *grp_mem; };
+
 struct BulgeWork {
 	uint32_t n;                  // instances of the id
 	uint32_t *start;             // (node << 1) | strand, list order: + list then - list (ListPositions, bifurcationstorage.h:59-72)
 	char *endc;                  // endChar
+	// Window cache: what instance i sees walking its own strand, steps 0 .. ws-1 (step 0 = the instance).
+	// Filled by bt_scan_instance (one thread) or by the wave-cooperative scan of simplify.hip (64 lanes);
+	// all decision logic below reads the cache, never the graph, so the serial part has no pointer chasing.
+	uint32_t ws;                 // stride = D + k + 2
+	uint32_t *wel, *wbf;         // element, own-strand mark per step
+	uint8_t *wch;                // raw character per step
+	uint32_t *wlen;              // number of leading steps before the first separator (<= ws)
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
+	AnyBulgesOut ab;
+	// resumable loop state of RemoveBulges (a collapse interrupts the loops for a window rescan)
+	uint32_t gi, idI, idJ, ret;
+	bool inI, need_fill;
 };
 
 __host__ __device__ __forceinline__ SIt bt_deref(Txn &t, uint32_t packed) { SIt a; a.e = t.g.nslot[packed >> 1]; a.d = packed & 1; return a; }
 __host__ __device__ __forceinline__ bool bt_pvalid(Txn &t, uint32_t packed) { return !t.g.ndead[packed >> 1]; }      // IteratorProxy::Valid :23-26
+__host__ __device__ __forceinline__ char bt_wchar(const BulgeWork &w, uint32_t i, uint32_t step)
+{ char c = (char)w.wch[(size_t)i * w.ws + step]; return (w.start[i] & 1) ? bt_comp(c) : c; }
 
 // number of live instances of an id (skipping nodes erased by an earlier Cleanup)
 __host__ __device__ inline uint32_t bt_count_instances(const GraphView &g, uint32_t id)
@@ -295,14 +310,66 @@ __host__ __device__ inline uint32_t bt_count_instances(const GraphView &g, uint3
 	return n;
 }
 
+// ListPositions (bulgeremoval.cpp:335) + all scratch of the transaction.  False when fewer than two instances.
+__host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w)
+{
+	GraphView &g = t.g;
+	uint32_t k = g.k, D = g.D;
+	t.ir(t.id);
+	uint32_t n = bt_count_instances(g, t.id);
+	w.n = n;
+	if (n < 2) return false;
+	w.ws = D + k + 2;
+	w.start = (uint32_t *)t.alloc(n * 4);
+	w.endc = (char *)t.alloc(n);
+	w.wlen = (uint32_t *)t.alloc(n * 4);
+	w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
+	w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
+	w.wch = (uint8_t *)t.alloc(n * w.ws);
+	w.visit_cap = D; w.occ_cap = D + k;
+	w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
+	w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
+	w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+	if (t.err) return false;
+	n = 0;
+	for (uint32_t s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][t.id]; nd != BT_NONE; nd = g.nnext[nd])
+			if (!g.ndead[nd]) w.start[n++] = (nd << 1) | s;
+	return true;
+}
+
+// one thread fills instance i's window from the live graph (the wave version in simplify.hip writes the same values)
+__host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t i)
+{
+	size_t base = (size_t)i * w.ws;
+	SIt a = bt_deref(t, w.start[i]);
+	uint32_t s = 0;
+	for (; s < w.ws; s++) {
+		t.tr(a.e);
+		uint8_t c = t.g.ch[a.e];
+		w.wel[base + s] = a.e; w.wch[base + s] = c; w.wbf[base + s] = t.g.bif[a.d][a.e];
+		if (c == BT_SEP) break;
+		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
+	}
+	w.wlen[i] = s;
+}
+__host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w) { for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
+
+// endChar (bulgeremoval.cpp:340-347, ProperKMer(k + 1) dnasequence.h:154-165)
+__host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
+{
+	uint32_t k = t.g.k;
+	for (uint32_t i = 0; i < w.n; i++) w.endc[i] = w.wlen[i] >= k + 1 ? bt_wchar(w, i, k) : ' ';
+}
+
 // FillVisit, bulgeremoval.cpp:122-146
-__host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, SIt kmer)
+__host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 {
 	uint32_t D = t.g.D, n = 0;
-	uint32_t start = t.getbif(kmer);
-	kmer = t.next(kmer);
-	for (uint32_t step = 1; step < D && t.valid(kmer); kmer = t.next(kmer), step++) {
-		uint32_t b = t.getbif(kmer);
+	const uint32_t *bf = w.wbf + (size_t)i * w.ws;
+	uint32_t start = bf[0], len = w.wlen[i];
+	for (uint32_t step = 1; step < D && step < len; step++) {
+		uint32_t b = bf[step];
 		if (b == start) break;
 		if (b != BT_NONE) {
 			if (n >= w.visit_cap) { t.err |= BT_ERR_SCRATCH; break; }
@@ -314,27 +381,28 @@ __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, SIt kmer)
 }
 
 // Overlap, bulgeremoval.cpp:97-120
-__host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, SIt si, uint32_t di, SIt sj, uint32_t dj)
+__host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
 {
 	uint32_t k = t.g.k, n = di + k;
 	if (n > w.occ_cap) { t.err |= BT_ERR_SCRATCH; return true; }
-	for (uint32_t i = 0; i < n; i++, si = t.next(si)) w.occ[i] = si.e;
+	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
+	for (uint32_t x = 0; x < n; x++) w.occ[x] = ei[x];
 	bt_sort_u32(w.occ, n);
-	for (uint32_t i = 0; i < dj + k; i++, sj = t.next(sj)) {
-		uint32_t lo = 0, hi = n;
-		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.occ[mid] < sj.e) lo = mid + 1; else hi = mid; }
-		if (lo < n && w.occ[lo] == sj.e) return true;
+	for (uint32_t x = 0; x < dj + k; x++) {
+		uint32_t e = ej[x], lo = 0, hi = n;
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.occ[mid] < e) lo = mid + 1; else hi = mid; }
+		if (lo < n && w.occ[lo] == e) return true;
 	}
 	return false;
 }
 
 // MaxBifurcationMultiplicity, bulgeremoval.cpp:39-53
-__host__ __device__ inline uint32_t bt_max_mult(Txn &t, SIt a, uint32_t distance)
+__host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i, uint32_t distance)
 {
 	uint32_t r = 0;
-	for (uint32_t i = 0; i + 1 < distance; i++) {
-		a = t.next(a);
-		uint32_t b = t.getbif(a);
+	const uint32_t *bf = w.wbf + (size_t)i * w.ws;
+	for (uint32_t x = 1; x < distance; x++) {
+		uint32_t b = bf[x];
 		if (b != BT_NONE) { uint32_t c = t.count_bif(b); if (c > r) r = c; }
 	}
 	return r;
@@ -462,12 +530,9 @@ __host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK,
 	bt_push_neighbourhood(t, tt, dS);
 }
 
-// AnyBulges (bulgeremoval.cpp:158-218) into a BoostMap + per-entry member lists.
-// Returns the number of groups with more than one member; group g's members are written to
-// grp_off[g] .. grp_off[g+1] of grp_mem, in unordered_map iteration order.
-struct AnyBulgesOut { uint32_t ngroups; uint32_t *grp_off; uint32_t *grp_mem; };
-
-__host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, AnyBulgesOut *out, bool verdict_only)
+// AnyBulges (bulgeremoval.cpp:158-218) into a BoostMap + per-entry member lists, reading the window cache.
+// verdict_only: stop at the first group that gets a second member.
+__host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict_only)
 {
 	uint32_t D = t.g.D, n = w.n;
 	// capacity: whatever scratch is left, split between the map and the member log
@@ -488,11 +553,10 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, AnyBulgesOut
 	bool any = false;
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
-		SIt kmer = bt_deref(t, w.start[i]);
-		uint32_t start = t.getbif(kmer);
-		kmer = t.next(kmer);
-		for (uint32_t step = 1; step < D && t.valid(kmer); kmer = t.next(kmer), step++) {
-			uint32_t b = t.getbif(kmer);
+		const uint32_t *bf = w.wbf + (size_t)i * w.ws;
+		uint32_t start = bf[0], len = w.wlen[i];
+		for (uint32_t step = 1; step < D && step < len; step++) {
+			uint32_t b = bf[step];
 			if (b == start) break;
 			if (b == BT_NONE) continue;
 			int32_t kt = bm_find(m, b);
@@ -515,80 +579,52 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, AnyBulgesOut
 	if (!any || verdict_only) return any;
 	uint32_t ng = 0, total = 0;
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (mcnt[p] > 1) { ng++; total += mcnt[p]; }
-	out->grp_off = (uint32_t *)t.alloc((ng + 1) * 4);
-	out->grp_mem = (uint32_t *)t.alloc(total * 4);
+	w.ab.grp_off = (uint32_t *)t.alloc((ng + 1) * 4);
+	w.ab.grp_mem = (uint32_t *)t.alloc(total * 4);
 	if (t.err) return false;
 	uint32_t gi = 0, o = 0;
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) {
 		if (mcnt[p] <= 1) continue;
-		out->grp_off[gi++] = o;
-		for (uint32_t l = mhead[p]; l != BT_NONE; l = log_next[l]) out->grp_mem[o++] = log_inst[l];
+		w.ab.grp_off[gi++] = o;
+		for (uint32_t l = mhead[p]; l != BT_NONE; l = log_next[l]) w.ab.grp_mem[o++] = log_inst[l];
 	}
-	out->grp_off[gi] = o;
-	out->ngroups = ng;
+	w.ab.grp_off[gi] = o;
+	w.ab.ngroups = ng;
 	return true;
 }
 
-// ListPositions + endChar (bulgeremoval.cpp:335-347).  Returns false when there are fewer than two instances.
-__host__ __device__ inline bool bt_list_instances(Txn &t, BulgeWork &w)
+// RemoveBulges, bulgeremoval.cpp:330-430, as a resumable routine over the window cache.
+//   bt_rb_begin: endChar + AnyBulges on freshly scanned windows; false = nothing to do.
+//   bt_rb_run:   runs the group / I / J loops until a collapse has been applied (returns true: the caller must
+//                rescan the windows and call again) or everything is done (returns false, Cleanup performed).
+__host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w)
 {
-	GraphView &g = t.g;
-	uint32_t k = g.k, n = 0;
-	t.ir(t.id);
-	n = bt_count_instances(g, t.id);
-	w.n = n;
-	if (n < 2) return false;
-	w.start = (uint32_t *)t.alloc(n * 4);
-	w.endc = (char *)t.alloc(n);
-	if (t.err) return false;
-	n = 0;
-	for (uint32_t s = 0; s < 2; s++)
-		for (uint32_t nd = g.head[s][t.id]; nd != BT_NONE; nd = g.nnext[nd])
-			if (!g.ndead[nd]) w.start[n++] = (nd << 1) | s;
-	for (uint32_t i = 0; i < n; i++) {              // ProperKMer(k + 1), dnasequence.h:154-165
-		SIt a = bt_deref(t, w.start[i]);
-		bool ok = true;
-		for (uint32_t j = 0; j < k + 1; j++) { if (!t.valid(a)) { ok = false; break; } if (j < k) a = t.next(a); }
-		w.endc[i] = ok ? t.chr(a) : ' ';
-	}
-	return true;
-}
-
-// Verdict of AnyBulges for one id against the current graph (read only).
-__host__ __device__ inline bool bt_has_bulges(Txn &t)
-{
-	BulgeWork w;
-	if (!bt_list_instances(t, w)) return false;
-	return bt_any_bulges(t, w, nullptr, true);
-}
-
-// RemoveBulges, bulgeremoval.cpp:330-430.  Returns the number of bulges collapsed.
-__host__ __device__ inline uint32_t bt_remove_bulges(Txn &t)
-{
-	GraphView &g = t.g;
-	uint32_t k = g.k, D = g.D, ret = 0;
-	BulgeWork w;
-	if (!bt_list_instances(t, w)) return 0;
-	w.visit_cap = D; w.occ_cap = D + k;
-	w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
-	w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
-	w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
-	if (t.err) return 0;
-	AnyBulgesOut ab;
-	if (!bt_any_bulges(t, w, &ab, false)) return 0;
+	bt_end_chars(t, w);
+	if (!bt_any_bulges(t, w, false)) return false;
 	t.iw(t.id);
-	for (uint32_t gi = 0; gi < ab.ngroups; gi++) {
-		uint32_t gb = ab.grp_off[gi], ge = ab.grp_off[gi + 1];
-		for (uint32_t idI = gb; idI < ge; idI++) {
-			uint32_t kmerI = ab.grp_mem[idI];
-			if (!bt_pvalid(t, w.start[kmerI])) continue;
-			bt_fill_visit(t, w, bt_deref(t, w.start[kmerI]));
-			for (uint32_t idJ = idI + 1; idJ < ge; idJ++) {
-				uint32_t kmerJ = ab.grp_mem[idJ];
+	w.gi = 0; w.idI = w.ab.grp_off[0]; w.idJ = 0; w.ret = 0; w.inI = false; w.need_fill = false;
+	return true;
+}
+
+__host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
+{
+	const uint32_t D = t.g.D;
+	while (w.gi < w.ab.ngroups) {
+		const uint32_t ge = w.ab.grp_off[w.gi + 1];
+		while (w.idI < ge) {
+			const uint32_t kmerI = w.ab.grp_mem[w.idI];
+			if (!w.inI) {
+				if (!bt_pvalid(t, w.start[kmerI])) { w.idI++; continue; }
+				bt_fill_visit(t, w, kmerI);
+				w.inI = true; w.idJ = w.idI + 1;
+			} else if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; }
+			while (w.idJ < ge) {
+				const uint32_t kmerJ = w.ab.grp_mem[w.idJ++];
 				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
-				SIt kmer = t.next(bt_deref(t, w.start[kmerJ]));
-				for (uint32_t step = 1; t.valid(kmer) && step < D; kmer = t.next(kmer), step++) {
-					uint32_t nowBif = t.getbif(kmer);
+				const uint32_t *bfJ = w.wbf + (size_t)kmerJ * w.ws;
+				const uint32_t lenJ = w.wlen[kmerJ];
+				for (uint32_t step = 1; step < lenJ && step < D; step++) {
+					uint32_t nowBif = bfJ[step];
 					if (nowBif == BT_NONE) continue;
 					if (nowBif == t.id) break;
 					uint32_t lo = 0, hi = w.nvisit;                  // lower_bound(BifurcationMark(nowBif, 0))
@@ -596,28 +632,31 @@ __host__ __device__ inline uint32_t bt_remove_bulges(Txn &t)
 					while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.visit[mid] < probe) lo = mid + 1; else hi = mid; }
 					if (lo < w.nvisit && (uint32_t)(w.visit[lo] >> 32) == nowBif) {
 						uint32_t dJ = step, dI = (uint32_t)w.visit[lo];
-						if (bt_overlap(t, w, bt_deref(t, w.start[kmerI]), dI, bt_deref(t, w.start[kmerJ]), dJ)) break;
-						if (t.err) return ret;
-						++ret;
-						uint32_t imlp = bt_max_mult(t, bt_deref(t, w.start[kmerI]), dI);
-						uint32_t jmlp = bt_max_mult(t, bt_deref(t, w.start[kmerJ]), dJ);
+						if (bt_overlap(t, w, kmerI, dI, kmerJ, dJ)) break;
+						if (t.err) return false;
+						++w.ret;
+						uint32_t imlp = bt_max_mult(t, w, kmerI, dI);
+						uint32_t jmlp = bt_max_mult(t, w, kmerJ, dJ);
 						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
 							w.endc[kmerJ] = w.endc[kmerI];
 							bt_collapse(t, w, kmerI, dI, kmerJ, dJ);
 						} else {
 							w.endc[kmerI] = w.endc[kmerJ];
 							bt_collapse(t, w, kmerJ, dJ, kmerI, dI);
-							bt_fill_visit(t, w, bt_deref(t, w.start[kmerI]));
+							w.need_fill = true;                      // FillVisit(I) again, on the rescanned window
 						}
-						if (t.err) return ret;
-						break;
+						if (t.err) return false;
+						return true;                                 // graph changed: rescan, then continue with the next J
 					}
 				}
 			}
+			w.inI = false; w.idI++;
 		}
+		w.gi++;
+		if (w.gi < w.ab.ngroups) w.idI = w.ab.grp_off[w.gi];
 	}
 	t.cleanup();
-	return ret;
+	return false;
 }
 
 // ------------------------------------------------------------------------------------------- reservation footprint

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_instance_keys(const unsigned *__restric
 }
 
 __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ selem, unsigned n,
-                                                     unsigned node_base, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext,
+                                                     unsigned node_base, unsigned strand, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext, unsigned *__restrict__ nidst,
                                                      uint8_t *__restrict__ ndead, unsigned *__restrict__ head, unsigned *__restrict__ lsize,
                                                      unsigned *__restrict__ nodeof)
 {
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *_
 	unsigned id = (unsigned)(skeys[i] >> 32), nd = node_base + i, e = selem[i];
 	bool last = i + 1 >= n || (unsigned)(skeys[i + 1] >> 32) != id;
 	bool first = i == 0 || (unsigned)(skeys[i - 1] >> 32) != id;
-	nslot[nd] = e; ndead[nd] = 0;
+	nslot[nd] = e; ndead[nd] = 0; nidst[nd] = (id << 1) | strand;
 	nnext[nd] = last ? SBL_NONE : nd + 1;
 	nodeof[e] = nd;
 	if (first) head[id] = nd;
@@ -56,11 +56,73 @@ __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *_
 }
 
 // ------------------------------------------------------------------------------------------- SimplifyGraph kernels
-__global__ void __launch_bounds__(256) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes)
+// ---- wave-cooperative window scan ---------------------------------------------------------------------------
+// Fills instance i's window cache (bulge_txn.h: BulgeWork) with 64 lanes: the same values bt_scan_instance
+// writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
+__device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r)
 {
-	unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-	uint8_t *mine = arena + (size_t)tid * arena_bytes;
-	for (unsigned id = tid; id < g.nid; id += nthreads) ss_snapshot(g, id, mine, arena_bytes);
+	unsigned old = atomicMin(&g.lock[r], stampv);
+	bool bad = old != stampv && (old >> 20) == (stampv >> 20);
+	unsigned other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
+	if (mode == 2) atomicMax(&g.rmax[r], tid);
+	if (g.wmax[r] > tid) bad = true;
+	if (bad) atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+}
+
+__device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
+                                                   unsigned stampv, unsigned tid, unsigned mode, unsigned id)
+{
+	const size_t base = (size_t)i * w.ws;
+	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
+	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws;
+	while (done < ws && cur != BT_NONE) {
+		bool inr = done + lane < ws && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
+		unsigned c = dir ? cur - lane : cur + lane;
+		bool link = inr && (lane == 0 || (dir ? g.pv[c + 1] == c : g.nx[c - 1] == c));
+		unsigned long long ml = __ballot(link);
+		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+		bool mine = lane < pre;
+		unsigned chv = mine ? g.ch[c] : 0u;
+		unsigned long long ms = __ballot(mine && chv == BT_SEP);
+		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+		bool st = mine && lane <= stop;                               // the separator step itself is cached too
+		if (st) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = g.bif[dir][c]; }
+		if (mode) {
+			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
+			if (st && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
+		}
+		if (stop < pre) { wl = done + stop; break; }
+		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
+		cur = __shfl(lnk, pre - 1);
+		done += pre;
+	}
+	if (lane == 0) w.wlen[i] = wl < ws ? wl : ws;
+}
+
+// AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
+// lane 0 evaluates the Boost-ordered map on the cached marks).
+__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ int ok;
+	const unsigned lane = threadIdx.x;
+	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
+	for (unsigned id = blockIdx.x; id < g.nid; id += gridDim.x) {
+		__syncthreads();
+		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); ok = bt_setup(t, w) ? 1 : 0; }
+		__syncthreads();
+		if (ok) {
+			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
+			__syncthreads();
+		}
+		if (lane == 0) {
+			bool v = false;
+			if (ok) { bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }
+			if (t.err & BT_ERR_SCRATCH) v = true;
+			g.need[id] = v ? 1 : 0;
+		}
+	}
 }
 
 // one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
@@ -173,24 +235,69 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 		}
 	if (lane == 0) cl.buf[0] = cl.n;
 }
+// One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
+// the decisions on the cached windows and all lanes rescanning them after every collapse.
 __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims)
 {
-	unsigned w = blockIdx.x, lane = threadIdx.x;
-	if (w >= nwin) return;
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ int flag;
+	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	if (wi >= nwin) return;
+	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
 	if (!solo) {
-		const unsigned *cb = claims + (size_t)w * (CLAIM_CAP + 1);
-		unsigned n = cb[0], st = g.round_bits | w;
+		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
+		unsigned n = cb[0];
 		bool owner = true;
 		if (n <= CLAIM_CAP) {
-			for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != st) owner = false;
+			for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != stampv) owner = false;
 			owner = !__any(!owner);
 		} else {
-			if (lane == 0) owner = ss_owns_footprint(g, w);      // list overflowed: serial re-walk
+			if (lane == 0) owner = ss_owns_footprint(g, wi);      // list overflowed: serial re-walk
 			owner = __shfl((int)owner, 0) != 0;
 		}
-		if (!owner) return;
+		if (!owner) return;                                       // stays pending
 	}
-	if (lane == 0) ss_commit_run(g, w, arena + (size_t)w * arena_bytes, arena_bytes);
+	uint8_t *mine = arena + (size_t)wi * arena_bytes;
+	// ---- read-only pass: exclusive block locks, nothing read may have been written by a higher id
+	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); flag = bt_setup(t, w) ? 1 : 0; }
+	__syncthreads();
+	if (flag) {
+		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
+		__syncthreads();
+	}
+	if (lane == 0) {
+		bool has = false;
+		if (flag) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+		if (t.err & BT_ERR_SCRATCH) { ss_mark_big(g, id); has = false; }
+		else atomicAdd(&g.ctr[CTR_COMMITTED], 1u);
+		flag = has ? 1 : 0;
+	}
+	__syncthreads();
+	if (!flag) return;
+	// ---- writer pass: reads and writes are published for order validation
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
+	__syncthreads();
+	if (flag) {
+		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+		__syncthreads();
+		if (lane == 0) flag = bt_rb_begin(t, w) && !t.err ? 1 : 0;
+		__syncthreads();
+		while (flag) {
+			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
+			__syncthreads();
+			if (!flag) break;
+			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+			__syncthreads();
+		}
+	}
+	if (lane == 0) {
+		if (t.err) {
+			if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
+			atomicOr(&g.ctr[CTR_ERR], t.err);
+		}
+		atomicAdd(&g.ctr[CTR_BULGES], w.ret);
+	}
 }
 
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
@@ -267,7 +374,7 @@ __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_
 // ------------------------------------------------------------------------------------------- device backend
 struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
-	DevBuf nslot, nnext, nclr, ndead, head[2], lsize[2];
+	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, own, lock, rmax, wmax, win;
 	DevBuf arena, snap_arena, big_arena, claims;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
@@ -282,7 +389,7 @@ struct DeviceBackend {
 	GraphView g{};
 	uint32_t cap_e = 0, cap_n = 0, nid_ = 0;
 	uint32_t ck_ne = 0, ck_nn = 0;
-	uint32_t window = 0, arena_bytes = 1u << 16, snap_arena_bytes = 1u << 13, snap_threads = 256 * 256;
+	uint32_t window = 0, arena_bytes = 1u << 17, snap_arena_bytes = 1u << 17, snap_threads = 256 * 32;   // snap_threads = resident waves
 	uint32_t big_arena_bytes = 1u << 28;
 	size_t nres = 0;
 	hipEvent_t ev[6] = {};
@@ -297,7 +404,7 @@ struct DeviceBackend {
 			g.bif[s] = c->d_bif[s].as<uint32_t>(); g.nodeof[s] = st->nodeof[s].as<uint32_t>();
 			g.head[s] = st->head[s].as<uint32_t>(); g.lsize[s] = st->lsize[s].as<uint32_t>();
 		}
-		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
+		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nidst = st->nidst.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
 		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>();
 		g.own = st->own.as<uint32_t>(); g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 		g.cap_e = cap_e; g.cap_n = cap_n; g.nid = nid_;
@@ -345,7 +452,7 @@ struct DeviceBackend {
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[4], c->stream));
-		k_snapshot<<<snap_threads / 256, 256, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
+		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[5], c->stream));
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -426,7 +533,7 @@ struct DeviceBackend {
 		if (err & BT_ERR_NODE_CAP) {
 			size_t n = (size_t)cap_n * 2;
 			SBL_CHECK(n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
-			st->nslot.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nnext.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nclr.grow_keep(n * 4, (size_t)cap_n * 4, s);
+			st->nslot.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nnext.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nclr.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nidst.grow_keep(n * 4, (size_t)cap_n * 4, s);
 			st->ndead.grow_keep(n, cap_n, s);
 			cap_n = (uint32_t)n;
 		}
@@ -439,7 +546,7 @@ void sbl_simplify_free(sbl_ctx *c)
 {
 	SimplifyState *st = c->simp;
 	if (!st) return;
-	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nclr, &st->ndead,
+	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
@@ -500,7 +607,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	size_t cap_n = 4 * ninst + (1u << 20);
 	SBL_CHECK(cap_n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
 	be.cap_n = (uint32_t)cap_n;
-	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);
+	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nidst.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);
 	size_t nidp = (size_t)be.nid_ + 1;
 	for (int t = 0; t < 2; t++) {
 		st->head[t].ensure(nidp * 4); st->lsize[t].ensure(nidp * 4);
@@ -515,8 +622,8 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		k_instance_keys<<<nblocks(n, 256), 256, 0, s>>>(c->d_melem[t].as<unsigned>(), c->d_mid[t].as<unsigned>(), n, (unsigned)t,
 		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, st->keys.as<unsigned long long>());
 		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), c->d_melem[t].as<unsigned>(), st->selem.as<unsigned>(), n);
-		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), n, t ? (unsigned)n0 : 0u,
-		                                             st->nslot.as<unsigned>(), st->nnext.as<unsigned>(), st->ndead.as<uint8_t>(),
+		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), n, t ? (unsigned)n0 : 0u, (unsigned)t,
+		                                             st->nslot.as<unsigned>(), st->nnext.as<unsigned>(), st->nidst.as<unsigned>(), st->ndead.as<uint8_t>(),
 		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>());
 	}
 	HIP_TRY(hipGetLastError());

@@ -20,11 +20,14 @@
 
 #define SS_ROUND_MAX 4095u
 
+// ---- one-thread forms (tests/hostsim); simplify.hip runs the same steps with 64 lanes scanning the windows
 __host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uint8_t *arena, uint32_t arena_bytes)
 {
 	Txn t;
+	BulgeWork w;
 	t.init(g, id, 0, 0, arena, arena_bytes);
-	bool v = bt_has_bulges(t);
+	bool v = false;
+	if (bt_setup(t, w)) { bt_scan_all(t, w); bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }
 	if (t.err & BT_ERR_SCRATCH) v = true;      // undecidable in the small arena: let the ordered phase run it
 	g.need[id] = v ? 1 : 0;
 }
@@ -35,28 +38,40 @@ __host__ __device__ inline void ss_reserve(const GraphView &g, uint32_t widx)
 	bt_footprint(g, id, [&](uint32_t b) { bt_atomic_min(&g.own[b], st); });
 }
 
+__host__ __device__ inline void ss_mark_big(const GraphView &g, uint32_t id)
+{
+	g.big[id] = 1; g.need[id] = 1;
+	bt_atomic_add(&g.ctr[CTR_BIG], 1u);
+}
+
 // the transaction proper, for a window entry that owns its whole neighbourhood
 __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
 {
 	uint32_t id = g.win[widx];
 	g.need[id] = 0;                            // cleared BEFORE running: a later push must survive
 	Txn t;
+	BulgeWork w;
 	t.init(g, id, widx, 1, arena, arena_bytes);
-	bool has = bt_has_bulges(t);
-	if (t.err & BT_ERR_SCRATCH) {              // nothing written yet: hand over to the big-arena path
-		g.big[id] = 1; g.need[id] = 1;
-		bt_atomic_add(&g.ctr[CTR_BIG], 1u);
-		return;
-	}
+	bool has = false;
+	if (bt_setup(t, w)) { bt_scan_all(t, w); bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+	if (t.err & BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }   // nothing written yet: big-arena path
 	bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u);
 	if (!has) return;
-	t.init(g, id, widx, 2, arena, arena_bytes);
-	uint32_t r = bt_remove_bulges(t);
+	t.init(g, id, widx, 2, arena, arena_bytes);                   // writer pass: publish reads and writes
+	w.ret = 0;
+	bt_setup(t, w);
+	bt_scan_all(t, w);
+	bool more = !t.err && bt_rb_begin(t, w);
+	while (more) {
+		more = bt_rb_run(t, w);
+		if (t.err) break;
+		if (more) bt_scan_all(t, w);
+	}
 	if (t.err) {
-		if (!t.wrote && (t.err == BT_ERR_SCRATCH)) { g.big[id] = 1; g.need[id] = 1; bt_atomic_add(&g.ctr[CTR_BIG], 1u); return; }
+		if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
 		bt_atomic_or(&g.ctr[CTR_ERR], t.err);
 	}
-	bt_atomic_add(&g.ctr[CTR_BULGES], r);
+	bt_atomic_add(&g.ctr[CTR_BULGES], w.ret);
 }
 
 __host__ __device__ inline bool ss_owns_footprint(const GraphView &g, uint32_t widx)

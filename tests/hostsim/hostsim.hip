@@ -18,7 +18,7 @@ namespace {
 struct HostBackend {
 	GraphView g{};
 	std::vector<uint8_t> ch, ndead, need, big;
-	std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, nclr, head[2], lsize[2], ctr, own, lock, rmax, wmax, win;
+	std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, nidst, nclr, head[2], lsize[2], ctr, own, lock, rmax, wmax, win;
 	uint32_t nid_ = 0;
 	int order_mode = 0;
 	uint32_t arena_bytes = 1u << 16, big_arena_bytes = 1u << 26;
@@ -31,7 +31,7 @@ struct HostBackend {
 	{
 		g.ch = ch.data(); g.op = op.data(); g.nx = nx.data(); g.pv = pv.data();
 		for (int s = 0; s < 2; s++) { g.bif[s] = bif[s].data(); g.nodeof[s] = nodeof[s].data(); g.head[s] = head[s].data(); g.lsize[s] = lsize[s].data(); }
-		g.nslot = nslot.data(); g.nnext = nnext.data(); g.nclr = nclr.data(); g.ndead = ndead.data();
+		g.nslot = nslot.data(); g.nnext = nnext.data(); g.nidst = nidst.data(); g.nclr = nclr.data(); g.ndead = ndead.data();
 		g.ctr = ctr.data(); g.need = need.data(); g.big = big.data();
 		g.own = own.data(); g.lock = lock.data(); g.rmax = rmax.data(); g.wmax = wmax.data();
 		g.cap_e = (uint32_t)ch.size(); g.cap_n = (uint32_t)nslot.size();
@@ -107,7 +107,7 @@ struct HostBackend {
 			for (int s = 0; s < 2; s++) { bif[s].resize(n, BT_NONE); nodeof[s].resize(n); }
 			lock.assign((n >> BT_BLOCK_SHIFT) + 1 + nid_ + 1, 0xFFFFFFFFu); rmax.assign(lock.size(), 0); wmax.assign(lock.size(), 0);
 		}
-		if (err & BT_ERR_NODE_CAP) { size_t n = nslot.size() * 2; nslot.resize(n); nnext.resize(n); nclr.resize(n); ndead.resize(n); }
+		if (err & BT_ERR_NODE_CAP) { size_t n = nslot.size() * 2; nslot.resize(n); nnext.resize(n); nidst.resize(n); nclr.resize(n); ndead.resize(n); }
 		if (err & ~(uint32_t)(BT_ERR_ELEM_CAP | BT_ERR_NODE_CAP)) return false;
 		bind();
 		return true;
@@ -137,7 +137,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 			be.head[s].assign((size_t)bif_count + 1, BT_NONE); be.lsize[s].assign((size_t)bif_count + 1, 0);
 		}
 		size_t ncap = n0 + n1 + 1024;
-		be.nslot.assign(ncap, 0); be.nnext.assign(ncap, BT_NONE); be.nclr.assign(ncap, BT_NONE); be.ndead.assign(ncap, 0);
+		be.nslot.assign(ncap, 0); be.nidst.assign(ncap, 0); be.nnext.assign(ncap, BT_NONE); be.nclr.assign(ncap, BT_NONE); be.ndead.assign(ncap, 0);
 		be.ctr.assign(CTR_COUNT, 0); be.need.assign((size_t)bif_count + 1, 0); be.big.assign((size_t)bif_count + 1, 0);
 		be.own.assign((size_t)bif_count + 1, 0xFFFFFFFFu);
 		be.lock.assign((cap >> BT_BLOCK_SHIFT) + 1 + bif_count + 1, 0xFFFFFFFFu);
@@ -164,7 +164,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 				uint32_t id = inst[3 * i], c = inst[3 * i + 1], p = inst[3 * i + 2];
 				uint32_t el = s == 0 ? sep[c] + 1 + p : sep[c + 1] - 1 - p;
 				uint32_t nd = nn++;
-				be.nslot[nd] = el; be.nnext[nd] = be.head[s][id]; be.head[s][id] = nd; be.lsize[s][id]++;
+				be.nslot[nd] = el; be.nidst[nd] = (id << 1) | (uint32_t)s; be.nnext[nd] = be.head[s][id]; be.head[s][id] = nd; be.lsize[s][id]++;
 				be.bif[s][el] = id; be.nodeof[s][el] = nd;
 			}
 		}
