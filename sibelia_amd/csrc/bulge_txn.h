@@ -22,7 +22,7 @@
 #define BT_SEP '$'
 #define BT_DEAD_CHAR 0            // ch[] of an element that was erased from the list
 #define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
-#define BT_BLOCK_SHIFT 5          // validation granularity: 32 element slots
+#define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
        CTR_BIG = 8, CTR_PUSHED = 9, CTR_COUNT = 16 };
@@ -56,6 +56,14 @@ __host__ __device__ __forceinline__ uint32_t bt_atomic_or(uint32_t *p, uint32_t 
 struct SIt { uint32_t e; uint32_t d; };   // element + direction (0 positive, 1 negative); reference src/stranditerator.cpp
 
 __host__ __device__ __forceinline__ char bt_comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; }
+
+#if defined(BT_HOST_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+#include <stdio.h>
+#define BT_TRACE_VIOL(what, r, a, b) fprintf(stderr, "[viol] id %u mode %u %s res %u (%s %u) other %u %u\n", id, mode, what, r, \
+	(r) < g.nblk ? "block" : "id", (r) < g.nblk ? (r) : (r) - g.nblk, (unsigned)(a), (unsigned)(b))
+#else
+#define BT_TRACE_VIOL(what, r, a, b) ((void)0)
+#endif
 
 struct Txn {
 	GraphView g;
@@ -94,19 +102,20 @@ struct Txn {
 	__host__ __device__ void stamp_res(uint32_t r, bool write)
 	{
 		uint32_t old = bt_atomic_min(&g.lock[r], stamp);
-		if (old != stamp && (old >> 20) == (stamp >> 20)) violation(old & 0xFFFFFu);   // two transactions of one round share r
-		if (mode == 1) { if (g.wmax[r] > tid) violation(BT_NONE); return; }
+		if (old != stamp && (old >> 20) == (stamp >> 20)) { BT_TRACE_VIOL("lock", r, old, 0); violation(old & 0xFFFFFu); }   // two transactions of one round share r
+		if (mode == 1) { if (g.wmax[r] > tid) { BT_TRACE_VIOL("read-after-higher-write", r, g.wmax[r], 0); violation(BT_NONE); } return; }
 		if (write) {
 			uint32_t a = bt_atomic_max(&g.wmax[r], tid);
-			if (a > tid || g.rmax[r] > tid) violation(BT_NONE);
+			if (a > tid || g.rmax[r] > tid) { BT_TRACE_VIOL("write-after-higher-access", r, a, g.rmax[r]); violation(BT_NONE); }
 		} else {
 			bt_atomic_max(&g.rmax[r], tid);
-			if (g.wmax[r] > tid) violation(BT_NONE);
+			if (g.wmax[r] > tid) { BT_TRACE_VIOL("wread-after-higher-write", r, g.wmax[r], 0); violation(BT_NONE); }
 		}
 	}
+	// separators are immutable and shared by the two chromosomes they delimit: never stamped
 	__host__ __device__ __forceinline__ void tr(uint32_t e)     // element read
 	{
-		if (!mode) return;
+		if (!mode || g.ch[e] == BT_SEP) return;
 		uint32_t b = e >> BT_BLOCK_SHIFT;
 		if (b == last_r || b == last_w) return;
 		last_r = b; stamp_res(b, false);
@@ -114,7 +123,7 @@ struct Txn {
 	__host__ __device__ __forceinline__ void tw(uint32_t e)     // element write
 	{
 		wrote = true;
-		if (!mode) return;
+		if (!mode || g.ch[e] == BT_SEP) return;
 		uint32_t b = e >> BT_BLOCK_SHIFT;
 		if (b == last_w) return;
 		last_w = b; stamp_res(b, true);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		if (st) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = g.bif[dir][c]; }
 		if (mode) {
 			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
-			if (st && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
+			if (st && chv != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
 		}
 		if (stop < pre) { wl = done + stop; break; }
 		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;

@@ -5,6 +5,8 @@
 // drive the very same control flow over a host-memory backend.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -34,6 +36,7 @@ template <class Backend>
 SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, sbl_progress_fn progress, void *user)
 {
 	SimplifyReport rep;
+	const bool trace = getenv("SBL_TRACE") != nullptr;
 	const uint32_t nid = be.nid();
 	const uint64_t per_iter = (uint64_t)nid + 1;                      // ids 0 .. GetMaxId() inclusive
 	const uint64_t threshold = ((uint64_t)nid * max_iter) / 50;       // PROGRESS_STRIDE, blockfinder.cpp:28
@@ -80,6 +83,8 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					else be.reserve(nwin, round);
 					be.commit(nwin, round, solo != 0);
 					SimplifyCounters c = be.counters();
+					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",
+					                   rep.iterations, round, lo, limit, nwin, solo, c.v[CTR_COMMITTED], c.v[CTR_BULGES], c.v[CTR_BIG], (int)c.v[CTR_VIOL], c.v[CTR_ERR]);
 					if (c.v[CTR_ERR]) {
 						if (!be.grow(c.v[CTR_ERR])) throw SblError{SBL_ERR_INTERNAL, "bulge removal: unrecoverable capacity error"};
 						replay = true; rep.grow_replays++;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <set>
 
 #include "../../sibelia_amd/csrc/sbl_common.h"
 #include "../../sibelia_amd/csrc/simplify_driver.h"
@@ -87,16 +88,67 @@ struct HostBackend {
 			for (uint32_t i = n; i > 1; i--) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; std::swap(o[i - 1], o[rng % i]); }
 		return o;
 	}
+	// like k_reserve / k_commit: the ids claimed at RESERVATION time are remembered and checked at commit time
+	std::vector<std::vector<uint32_t>> claims;
+	std::vector<uint32_t> dbg_bif0, dbg_bif1; uint32_t dbg_nn = 0;
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		for (uint32_t w : order(nwin)) ss_reserve(g, w);
+		claims.assign(nwin, {});
+		if (getenv("HOSTSIM_DEBUG")) { dbg_bif0 = bif[0]; dbg_bif1 = bif[1]; dbg_nn = ctr[CTR_NN]; }
+		for (uint32_t w : order(nwin)) {
+			uint32_t st = g.round_bits | w;
+			bt_footprint(g, win[w], [&](uint32_t b) { bt_atomic_min(&g.own[b], st); claims[w].push_back(b); });
+		}
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		if (solo) { ss_commit(g, 0, big_arena.data(), big_arena_bytes, true); return; }
-		for (uint32_t w : order(nwin)) ss_commit(g, w, arena.data(), arena_bytes, false);
+		if (solo) { ss_commit_run(g, 0, big_arena.data(), big_arena_bytes); return; }
+		for (uint32_t w : order(nwin)) {
+			uint32_t st = g.round_bits | w;
+			bool owner = true;
+			for (uint32_t b : claims[w]) if (own[b] != st) { owner = false; break; }
+			uint32_t before = ctr[CTR_VIOL];
+			if (owner) ss_commit_run(g, w, arena.data(), arena_bytes);
+			if (getenv("HOSTSIM_DEBUG") && ctr[CTR_VIOL] != before) {
+				uint32_t a = win[w];
+				fprintf(stderr, "[dbg] violation while committing id %u (widx %u)\n", a, w);
+				for (uint32_t x = 0; x < nwin; x++) {
+					if (x == w) continue;
+					bool xo = true; for (uint32_t b : claims[x]) if (own[b] != (g.round_bits | x)) { xo = false; break; }
+					if (!xo) continue;
+					uint32_t b = win[x];
+					bool near = false;
+					for (int s1 = 0; s1 < 2; s1++) for (uint32_t n1 = g.head[s1][a]; n1 != BT_NONE; n1 = g.nnext[n1])
+						for (int s2 = 0; s2 < 2; s2++) for (uint32_t n2 = g.head[s2][b]; n2 != BT_NONE; n2 = g.nnext[n2]) {
+							long d = (long)g.nslot[n2] - (long)g.nslot[n1];
+							if (d > -400 && d < 400) near = true;
+						}
+					if (!near) continue;
+					bool ainx = false, xina = false;
+					for (uint32_t q : claims[x]) if (q == a) ainx = true;
+					for (uint32_t q : claims[w]) if (q == b) xina = true;
+					fprintf(stderr, "  co-winner id %u (widx %u) a-in-its-claims %d it-in-a-claims %d nclaims %zu/%zu\n", b, x, ainx, xina, claims[x].size(), claims[w].size());
+					for (uint32_t n1 = g.head[1][a]; n1 != BT_NONE; n1 = g.nnext[n1]) {
+						if (g.ndead[n1]) continue;
+						uint32_t e = g.nslot[n1];
+						for (uint32_t i = 0; i <= 2 * (g.D + g.k) + g.k; i++) {
+							if (i && g.ch[e] == BT_SEP) { fprintf(stderr, "     walk from %u hit SEP at step %u slot %u\n", g.nslot[n1], i, e); break; }
+							if (g.bif[0][e] == b || g.bif[1][e] == b) fprintf(stderr, "     walk from %u sees id %u at step %u slot %u\n", g.nslot[n1], b, i, e);
+							e = g.pv[e];
+							if (e == BT_NONE) break;
+						}
+					}
+					for (int which = 0; which < 2; which++) {
+						uint32_t id = which ? b : a;
+						for (int s1 = 0; s1 < 2; s1++) for (uint32_t n1 = g.head[s1][id]; n1 != BT_NONE; n1 = g.nnext[n1])
+							fprintf(stderr, "     id %u node %u%s strand %d slot %u dead %d  bif-at-slot now %d/%d at-reserve %d/%d\n", id, n1, n1 >= dbg_nn ? "(NEW this round)" : "", s1, g.nslot[n1], g.ndead[n1],
+							        (int)g.bif[0][g.nslot[n1]], (int)g.bif[1][g.nslot[n1]], (int)dbg_bif0[g.nslot[n1]], (int)dbg_bif1[g.nslot[n1]]);
+					}
+				}
+			}
+		}
 	}
 	SimplifyCounters counters() { SimplifyCounters c; memcpy(c.v, ctr.data(), sizeof c.v); return c; }
 	bool grow(uint32_t err)
