@@ -61,10 +61,10 @@ def main():
         G.build()
     if world > 1:
         dist.barrier()
-    from sibelia_amd import BlockFinder, workloads as W
+    from sibelia_amd import BlockFinder, workloads as W, dist as D
 
     # every rank owns its own strain set (same generator, rank-specific seed): independent jobs, no collective
-    seqs = W.gen_strains(L0=a.L0, n=a.strains, seed=1 + rank)
+    seqs = W.gen_strains(**D.rank_workload(rank, a.strains, a.L0))
     N = W.strand_kmers(seqs, a.k)
     bf = BlockFinder(seqs, device=local)
     if a.window:
@@ -92,15 +92,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        nt = torch.tensor([float(N)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
-        Ntot = float(nt.item())
-    else:
-        Ntot = float(N)
+    dt, Ntot = D.aggregate(dt, float(N), device="cuda" if world > 1 else None)
 
     if rank == 0:
         st = bf.stats()

@@ -1,0 +1,102 @@
+// blockfinder.hpp -- the reference's BlockFinder class surface on top of the C ABI (include/sibelia_amd.h).
+//
+// Mirrors SyntenyFinder::BlockFinder's public section (reference src/blockfinder.h:28-45) for the hot path:
+// same constructors (a FASTARecord only needs GetSequence()), same method names, argument order and meaning.
+// Header-only; link with -lsibelia_amd.  Errors that the reference cannot produce (no device, OOM, k > 32
+// in this build) are thrown as std::runtime_error, the only exception type the reference itself throws
+// (src/platform.cpp:40,79,118,126).
+#ifndef SIBELIA_AMD_BLOCKFINDER_HPP
+#define SIBELIA_AMD_BLOCKFINDER_HPP
+#include <cstdio>
+#include <functional>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../sibelia_amd.h"
+
+namespace SyntenyFinderAMD
+{
+	class BlockFinder
+	{
+	public:
+		enum State { start, run, end };                                   // blockfinder.h:31-36
+		typedef std::function<void(size_t, State)> ProgressCallBack;      // boost::function in the reference
+
+		template <class FASTARecordVector>
+		explicit BlockFinder(const FASTARecordVector &chrList, int device = -1) { Init(chrList, device); }
+		template <class FASTARecordVector>
+		BlockFinder(const FASTARecordVector &chrList, const std::string & /*tempDir: nothing is spilled*/, int device = -1) { Init(chrList, device); }
+		~BlockFinder() { sbl_destroy(ctx_); }
+		BlockFinder(const BlockFinder &) = delete;
+		BlockFinder &operator=(const BlockFinder &) = delete;
+
+		// blockfinder.cpp:78-98
+		size_t PerformGraphSimplifications(size_t k, size_t minBranchSize, size_t maxIterations, ProgressCallBack f = ProgressCallBack())
+		{
+			uint64_t bulges = 0;
+			Check(sbl_simplify_stage(ctx_, (uint32_t)k, (uint32_t)minBranchSize, (uint32_t)maxIterations,
+			                         f ? &Trampoline : nullptr, f ? &f : nullptr, &bulges), "PerformGraphSimplifications");
+			return (size_t)bulges;
+		}
+
+		// serialization.cpp:88-110 (same text, byte for byte)
+		void SerializeCondensedGraph(size_t k, std::ostream &out, ProgressCallBack = ProgressCallBack())
+		{
+			const sbl_edge *e = nullptr;
+			uint64_t n = 0;
+			Check(sbl_list_edges(ctx_, (uint32_t)k, &e, &n), "SerializeCondensedGraph");
+			out << "digraph G" << std::endl << "{" << std::endl << "rankdir=LR" << std::endl;
+			for (uint64_t i = 0; i < n; i++) {
+				char buf[256];
+				std::snprintf(buf, sizeof buf, "[color=\"%s\", label=\"chr=%i pos=%i len=%i orpos=%i orlen=%i  ch='%c'\"];",
+				              e[i].strand == 0 ? "blue" : "red", (int)e[i].chr, (int)e[i].pos, (int)e[i].len,
+				              (int)e[i].orig_pos, (int)e[i].orig_len, e[i].first_char);
+				out << e[i].start_vertex << " -> " << e[i].end_vertex << " " << buf << std::endl;
+			}
+			out << "}" << std::endl;
+		}
+
+		// rawSeq_ / originalPos_ (blockfinder.h:52-54) after the last stage
+		std::string Sequence(size_t chr) const
+		{
+			const uint8_t *s = nullptr; const uint32_t *p = nullptr; uint64_t n = 0;
+			Check(sbl_get_state(ctx_, (uint32_t)chr, &s, &p, &n), "Sequence");
+			return std::string(reinterpret_cast<const char *>(s), (size_t)n);
+		}
+		std::vector<uint32_t> OriginalPositions(size_t chr) const
+		{
+			const uint8_t *s = nullptr; const uint32_t *p = nullptr; uint64_t n = 0;
+			Check(sbl_get_state(ctx_, (uint32_t)chr, &s, &p, &n), "OriginalPositions");
+			return std::vector<uint32_t>(p, p + n);
+		}
+		sbl_ctx *Context() const { return ctx_; }
+
+	private:
+		template <class FASTARecordVector>
+		void Init(const FASTARecordVector &chrList, int device)       // blockfinder.cpp:65-76
+		{
+			sbl_status st = sbl_create(&ctx_, device);
+			if (st != SBL_OK) throw std::runtime_error(std::string("sibelia_amd: ") + sbl_strerror(st));
+			std::vector<const uint8_t *> ptr;
+			std::vector<uint64_t> len;
+			for (const auto &rec : chrList) {
+				const std::string &s = rec.GetSequence();
+				ptr.push_back(reinterpret_cast<const uint8_t *>(s.data()));
+				len.push_back(s.size());
+			}
+			Check(sbl_load(ctx_, (uint32_t)ptr.size(), ptr.data(), len.data()), "Init");
+		}
+		static void Trampoline(size_t progress, int state, void *user)
+		{
+			(*static_cast<ProgressCallBack *>(user))(progress, static_cast<State>(state));
+		}
+		void Check(sbl_status st, const char *what) const
+		{
+			if (st != SBL_OK) throw std::runtime_error(std::string("sibelia_amd: ") + what + ": " + sbl_strerror(st) + " (" + sbl_last_error(ctx_) + ")");
+		}
+		sbl_ctx *ctx_ = nullptr;
+	};
+}
+#endif

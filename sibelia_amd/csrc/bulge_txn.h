@@ -78,11 +78,14 @@ struct Txn {
 	uint32_t err;
 	uint32_t tc_head;                   // lazy erase chain (BifurcationStorage::toClear_), linked through g.nclr
 	bool wrote;                         // the graph has been modified by this transaction
+	bool defer_push;                    // the caller performs bt_push_neighbourhood's work itself (64 lanes, simplify.hip)
+	bool ext_stamps;                    // element stamps are done by the caller's wave-wide scans (reads) and post-collapse pass (writes)
+	uint32_t push_e, push_d, push_len;  // ... for this target instance / new branch length
 
 	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
 	{
 		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
-		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; err = 0; tc_head = BT_NONE; wrote = false;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; push_e = BT_NONE; push_d = 0; push_len = 0;
 	}
 	// ---- scratch
 	__host__ __device__ void *alloc(uint32_t bytes)
@@ -115,7 +118,7 @@ struct Txn {
 	// separators are immutable and shared by the two chromosomes they delimit: never stamped
 	__host__ __device__ __forceinline__ void tr(uint32_t e)     // element read
 	{
-		if (!mode || g.ch[e] == BT_SEP) return;
+		if (!mode || ext_stamps || g.ch[e] == BT_SEP) return;
 		uint32_t b = e >> BT_BLOCK_SHIFT;
 		if (b == last_r || b == last_w) return;
 		last_r = b; stamp_res(b, false);
@@ -123,7 +126,7 @@ struct Txn {
 	__host__ __device__ __forceinline__ void tw(uint32_t e)     // element write
 	{
 		wrote = true;
-		if (!mode || g.ch[e] == BT_SEP) return;
+		if (!mode || ext_stamps || g.ch[e] == BT_SEP) return;
 		uint32_t b = e >> BT_BLOCK_SHIFT;
 		if (b == last_w) return;
 		last_w = b; stamp_res(b, true);
@@ -536,7 +539,8 @@ __host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK,
 		b = t.getbif(sb);
 		if (b != BT_NONE) t.add_point(bmer, b);
 	}
-	bt_push_neighbourhood(t, tt, dS);
+	if (t.defer_push) { t.push_e = tt.e; t.push_d = tt.d; t.push_len = dS; }
+	else bt_push_neighbourhood(t, tt, dS);
 }
 
 // AnyBulges (bulgeremoval.cpp:158-218) into a BoostMap + per-entry member lists, reading the window cache.

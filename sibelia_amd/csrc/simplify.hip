@@ -182,18 +182,10 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 
 struct ClaimList { unsigned *buf; unsigned n; };
 
-__device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
-{
-	bool has = b != BT_NONE;
-	if (has) atomicMin(&g.own[b], st);
-	unsigned long long m = __ballot(has);
-	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
-	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b;
-	cl.n += __popcll(m);
-}
-
-__device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
-                                                ClaimList &cl, unsigned st)
+// Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
+// calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
+template <class F>
+__device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane, F f)
 {
 	unsigned cur = first, done = 0;
 	while (done < maxcount && cur != BT_NONE) {
@@ -207,14 +199,66 @@ __device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned fir
 		unsigned long long ms = __ballot(mine && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
 		bool proc = lane < pre && lane < stop;
-		unsigned b0 = proc ? g.bif[0][c] : BT_NONE, b1 = proc ? g.bif[1][c] : BT_NONE;
-		wave_claim(g, cl, st, b0, lane);
-		wave_claim(g, cl, st, b1, lane);
+		f(proc ? g.bif[0][c] : BT_NONE, proc ? g.bif[1][c] : BT_NONE);
 		if (stop < pre) break;
 		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
 	}
+}
+
+__device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
+{
+	bool has = b != BT_NONE;
+	if (has) atomicMin(&g.own[b], st);
+	unsigned long long m = __ballot(has);
+	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
+	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b;
+	cl.n += __popcll(m);
+}
+
+__device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
+                                                ClaimList &cl, unsigned st)
+{
+	wave_walk_marks(g, first, dir, maxcount, lane, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
+}
+
+// After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
+// look-forward flank had marks, characters, positions or links rewritten) and check that no higher id read them.
+__device__ __forceinline__ void wave_stamp_writes(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
+{
+	unsigned cur = e, done = 0, maxcount = newlen + 2 * g.k, tid = id + 1;
+	while (done < maxcount && cur != BT_NONE) {
+		bool inr = done + lane < maxcount && (d ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
+		unsigned c = d ? cur - lane : cur + lane;
+		bool link = inr && (lane == 0 || (d ? g.pv[c + 1] == c : g.nx[c - 1] == c));
+		unsigned long long ml = __ballot(link);
+		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+		bool mine = lane < pre;
+		unsigned chv = mine ? g.ch[c] : 0u;
+		unsigned long long ms = __ballot(mine && chv == BT_SEP);
+		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+		if (mine && lane < stop) {
+			unsigned a = atomicMax(&g.wmax[c], tid);
+			if (a > tid || g.rmax[c] > tid) atomicMin(&g.ctr[CTR_VIOL], id);
+		}
+		if (stop < pre) break;
+		unsigned lnk = mine ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
+		cur = __shfl(lnk, pre - 1);
+		done += pre;
+	}
+}
+
+// bt_push_neighbourhood with 64 lanes: every id marked around a rewritten region and still ahead in the order becomes pending
+__device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
+{
+	unsigned reach = g.D + g.k;
+	auto push = [&](unsigned b0, unsigned b1) {
+		if (b0 != BT_NONE && b0 > id && b0 < g.nid) g.need[b0] = 1;
+		if (b1 != BT_NONE && b1 > id && b1 < g.nid) g.need[b1] = 1;
+	};
+	wave_walk_marks(g, e, d ^ 1u, reach + 1, lane, push);
+	wave_walk_marks(g, e, d, newlen + 2 * g.k + reach + 1, lane, push);
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
@@ -260,7 +304,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	}
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
 	// ---- read-only pass: exclusive block locks, nothing read may have been written by a higher id
-	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); flag = bt_setup(t, w) ? 1 : 0; }
+	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w) ? 1 : 0; }
 	__syncthreads();
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
@@ -276,7 +320,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__syncthreads();
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
-	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
 	__syncthreads();
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
@@ -287,6 +331,8 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
 			__syncthreads();
 			if (!flag) break;
+			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
+			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			__syncthreads();
 		}
