@@ -299,6 +299,7 @@ struct BulgeWork {
 	uint32_t *wel, *wbf;         // element, own-strand mark per step
 	uint8_t *wch;                // raw character per step
 	uint32_t *wlen;              // number of leading steps before the first separator (<= ws)
+	uint64_t *wmk; uint32_t *wmn; // compact list of the marked steps >= 1 of each window: (step << 32) | id, and their number
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
@@ -338,6 +339,8 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w)
 	w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
 	w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
 	w.wch = (uint8_t *)t.alloc(n * w.ws);
+	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
+	w.wmn = (uint32_t *)t.alloc(n * 4);
 	w.visit_cap = D; w.occ_cap = D + k;
 	w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
 	w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
@@ -355,15 +358,17 @@ __host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t 
 {
 	size_t base = (size_t)i * w.ws;
 	SIt a = bt_deref(t, w.start[i]);
-	uint32_t s = 0;
+	uint32_t s = 0, nm = 0;
 	for (; s < w.ws; s++) {
 		t.tr(a.e);
 		uint8_t c = t.g.ch[a.e];
-		w.wel[base + s] = a.e; w.wch[base + s] = c; w.wbf[base + s] = t.g.bif[a.d][a.e];
+		uint32_t b = t.g.bif[a.d][a.e];
+		w.wel[base + s] = a.e; w.wch[base + s] = c; w.wbf[base + s] = b;
 		if (c == BT_SEP) break;
+		if (s && b != BT_NONE) w.wmk[base + nm++] = ((uint64_t)s << 32) | b;
 		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
 	}
-	w.wlen[i] = s;
+	w.wlen[i] = s; w.wmn[i] = nm;
 }
 __host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w) { for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
 
@@ -378,15 +383,13 @@ __host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
 __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 {
 	uint32_t D = t.g.D, n = 0;
-	const uint32_t *bf = w.wbf + (size_t)i * w.ws;
-	uint32_t start = bf[0], len = w.wlen[i];
-	for (uint32_t step = 1; step < D && step < len; step++) {
-		uint32_t b = bf[step];
-		if (b == start) break;
-		if (b != BT_NONE) {
-			if (n >= w.visit_cap) { t.err |= BT_ERR_SCRATCH; break; }
-			w.visit[n++] = ((uint64_t)b << 32) | step;
-		}
+	const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+	uint32_t start = w.wbf[(size_t)i * w.ws], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+	for (uint32_t j = 0; j < nm; j++) {
+		uint32_t step = (uint32_t)(mk[j] >> 32), b = (uint32_t)mk[j];
+		if (step >= lim || b == start) break;
+		if (n >= w.visit_cap) { t.err |= BT_ERR_SCRATCH; break; }
+		w.visit[n++] = ((uint64_t)b << 32) | step;
 	}
 	bt_sort_u64(w.visit, n);
 	w.nvisit = n;
@@ -411,11 +414,12 @@ __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uin
 // MaxBifurcationMultiplicity, bulgeremoval.cpp:39-53
 __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i, uint32_t distance)
 {
-	uint32_t r = 0;
-	const uint32_t *bf = w.wbf + (size_t)i * w.ws;
-	for (uint32_t x = 1; x < distance; x++) {
-		uint32_t b = bf[x];
-		if (b != BT_NONE) { uint32_t c = t.count_bif(b); if (c > r) r = c; }
+	uint32_t r = 0, nm = w.wmn[i];
+	const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+	for (uint32_t j = 0; j < nm; j++) {
+		if ((uint32_t)(mk[j] >> 32) >= distance) break;
+		uint32_t c = t.count_bif((uint32_t)mk[j]);
+		if (c > r) r = c;
 	}
 	return r;
 }
@@ -566,12 +570,11 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	bool any = false;
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
-		const uint32_t *bf = w.wbf + (size_t)i * w.ws;
-		uint32_t start = bf[0], len = w.wlen[i];
-		for (uint32_t step = 1; step < D && step < len; step++) {
-			uint32_t b = bf[step];
-			if (b == start) break;
-			if (b == BT_NONE) continue;
+		const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+		uint32_t start = w.wbf[(size_t)i * w.ws], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+		for (uint32_t j = 0; j < nm; j++) {
+			uint32_t b = (uint32_t)mk[j];
+			if ((uint32_t)(mk[j] >> 32) >= lim || b == start) break;
 			int32_t kt = bm_find(m, b);
 			if (kt < 0) {
 				kt = bm_insert(m, b);
@@ -634,11 +637,11 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 			while (w.idJ < ge) {
 				const uint32_t kmerJ = w.ab.grp_mem[w.idJ++];
 				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
-				const uint32_t *bfJ = w.wbf + (size_t)kmerJ * w.ws;
-				const uint32_t lenJ = w.wlen[kmerJ];
-				for (uint32_t step = 1; step < lenJ && step < D; step++) {
-					uint32_t nowBif = bfJ[step];
-					if (nowBif == BT_NONE) continue;
+				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.ws;
+				const uint32_t limJ = w.wlen[kmerJ] < D ? w.wlen[kmerJ] : D, nmJ = w.wmn[kmerJ];
+				for (uint32_t j = 0; j < nmJ; j++) {
+					uint32_t step = (uint32_t)(mkJ[j] >> 32), nowBif = (uint32_t)mkJ[j];
+					if (step >= limJ) break;
 					if (nowBif == t.id) break;
 					uint32_t lo = 0, hi = w.nvisit;                  // lower_bound(BifurcationMark(nowBif, 0))
 					uint64_t probe = (uint64_t)nowBif << 32;

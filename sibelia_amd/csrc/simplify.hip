@@ -74,7 +74,7 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 {
 	const size_t base = (size_t)i * w.ws;
 	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
-	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws;
+	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws, nm = 0;
 	while (done < ws && cur != BT_NONE) {
 		bool inr = done + lane < ws && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
@@ -86,7 +86,14 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		unsigned long long ms = __ballot(mine && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 		bool st = mine && lane <= stop;                               // the separator step itself is cached too
-		if (st) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = g.bif[dir][c]; }
+		unsigned bv = st ? g.bif[dir][c] : BT_NONE;
+		if (st) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = bv; }
+		{	// compact list of the marked steps (>= 1, before the separator), in step order
+			bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
+			unsigned long long mm = __ballot(marked);
+			if (marked) w.wmk[base + nm + __popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)(done + lane) << 32) | bv;
+			nm += __popcll(mm);
+		}
 		if (mode) {
 			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
 			if (st && chv != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
@@ -96,7 +103,7 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
 	}
-	if (lane == 0) w.wlen[i] = wl < ws ? wl : ws;
+	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; }
 }
 
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
