@@ -1,0 +1,228 @@
+// longk.hip -- bifurcation enumeration for vertex sizes k > 32 (stages (100,500), (500,1500), (1000,5000), (5000,15000)
+// of the reference's parameter sets, reference src/util.cpp:52-87).
+//
+// Replaces EnumerateBifurcationsSArrayInRAM (reference src/vertexenumeration.cpp:263-364) without a suffix array and
+// without fingerprints: EXACT rank doubling (Karp-Miller-Rosenberg).  rank_h[i] is the order-preserving dense rank of
+// S[i..i+h) in the reference's superGenome S = "#c0#c1#..#rc(c0)#rc(c1)#..#" (:269-286); rank_2h comes from a radix
+// sort of the pairs (rank_h[i], rank_h[i+h]); the k-windows are grouped and ordered by the pair
+// (rank_h[i], rank_h[i+k-h]), h = largest power of two <= k (overlapping halves compare like the whole window).
+// Groups in sorted order ARE the reference's lcp >= k runs in suffix-array order, so ids come out identical.
+// Every step is a data-parallel kernel, a radix sort, a scan or a segmented OR -- HBM-streaming integer work.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#include "sbl_ctx.h"
+
+static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// S position -> (strand, element) and window validity.  Forward half: S[i] = element i.  Reverse half of chromosome c
+// starts at E + sepidx[c] and holds the complement of elements sepidx[c+1]-1 downto sepidx[c]+1, then '#'.
+__device__ __forceinline__ unsigned lk_chr_of(const unsigned *__restrict__ sepidx, unsigned nchr, unsigned e)
+{
+	unsigned lo = 0, hi = nchr;
+	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (sepidx[mid] < e) lo = mid; else hi = mid; }
+	return lo;
+}
+
+__global__ void __launch_bounds__(256) k_lk_super(const uint8_t *__restrict__ ch, const unsigned *__restrict__ sepidx, unsigned nchr,
+                                                  unsigned E, unsigned n, unsigned np, unsigned *__restrict__ rank)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= np) return;
+	unsigned v = 0;
+	if (i < E) {
+		uint8_t c = ch[i];
+		v = c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 0;
+	} else if (i < n) {
+		unsigned r = i - E;                                   // offset inside the reverse half: block c = [sepidx[c], sepidx[c+1])
+		unsigned c = lk_chr_of(sepidx, nchr, r + 1);          // r in [sepidx[c], sepidx[c+1]-1]  <=>  sepidx[c] < r+1 <= sepidx[c+1]
+		unsigned j = r - sepidx[c];                           // 0 .. len_c ; j == len_c is the '#'
+		unsigned len = sepidx[c + 1] - sepidx[c] - 1;
+		if (j < len) {
+			uint8_t x = ch[sepidx[c + 1] - 1 - j];
+			v = x == 'A' ? 4 : x == 'C' ? 3 : x == 'G' ? 2 : x == 'T' ? 1 : 0;
+		}
+	}
+	rank[i] = v;
+}
+
+__global__ void __launch_bounds__(256) k_lk_pair_keys(const unsigned *__restrict__ rank, unsigned np, unsigned h,
+                                                      unsigned long long *__restrict__ keys, unsigned *__restrict__ idx)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= np) return;
+	unsigned hi = rank[i], lo = (unsigned long long)i + h < np ? rank[i + h] : 0u;
+	keys[i] = ((unsigned long long)hi << 32) | lo;
+	idx[i] = i;
+}
+__global__ void __launch_bounds__(256) k_lk_heads(const unsigned long long *__restrict__ skeys, unsigned n, unsigned *__restrict__ flag)
+{
+	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) flag[j] = (j == 0 || skeys[j] != skeys[j - 1]) ? 1u : 0u;
+}
+// rank[idx[j]] = (inclusive scan of head flags)[j] - 1
+__global__ void __launch_bounds__(256) k_lk_scatter_rank(const unsigned *__restrict__ sidx, const unsigned *__restrict__ scan, unsigned n,
+                                                         unsigned *__restrict__ rank)
+{
+	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) rank[sidx[j]] = scan[j] - 1;
+}
+
+// final keys of the k-windows; windows that contain a separator get the all-ones key and sort to the end
+__global__ void __launch_bounds__(256) k_lk_window_keys(const unsigned *__restrict__ rank, const unsigned *__restrict__ sepidx, unsigned nchr,
+                                                        unsigned E, unsigned n, unsigned k, unsigned h,
+                                                        unsigned long long *__restrict__ keys, unsigned *__restrict__ idx, unsigned *__restrict__ nvalid)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	bool valid = false;
+	if (i < E) {
+		unsigned c = lk_chr_of(sepidx, nchr, i);
+		valid = i > sepidx[c] && (unsigned long long)i + k <= sepidx[c + 1];
+	} else {
+		unsigned r = i - E, c = lk_chr_of(sepidx, nchr, r + 1);
+		unsigned j = r - sepidx[c], len = sepidx[c + 1] - sepidx[c] - 1;
+		valid = (unsigned long long)j + k <= len;
+	}
+	keys[i] = valid ? (((unsigned long long)rank[i] << 32) | rank[i + k - h]) : ~0ull;
+	idx[i] = i;
+	if (valid) atomicAdd(nvalid, 1u);
+}
+
+// per sorted window: prev / next character masks (bit 0-3 = A C G T, bit 4 = '#'; next in bits 8-12) and the group-head flag
+__global__ void __launch_bounds__(256) k_lk_masks(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ sidx, unsigned nv,
+                                                  const unsigned *__restrict__ sym /* rank_1 = S */, unsigned k,
+                                                  unsigned *__restrict__ mask, unsigned *__restrict__ flag)
+{
+	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nv) return;
+	unsigned i = sidx[j];
+	unsigned p = sym[i - 1], q = sym[i + k];                  // i >= 1 and i + k < n for every valid window
+	mask[j] = (1u << (p ? p - 1 : 4)) | (1u << (8 + (q ? q - 1 : 4)));
+	flag[j] = (j == 0 || skeys[j] != skeys[j - 1]) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_lk_group_bif(const unsigned *__restrict__ gmask, unsigned ngroups, unsigned *__restrict__ gbif)
+{
+	unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= ngroups) return;
+	unsigned m = gmask[g], p = m & 0x1F, q = (m >> 8) & 0x1F;
+	gbif[g] = ((p & 0x10) || (q & 0x10) || __popc(p & 0xF) > 1 || __popc(q & 0xF) > 1) ? 1u : 0u;
+}
+// marks: window at S position i -> bif[strand][element]
+__global__ void __launch_bounds__(256) k_lk_marks(const unsigned *__restrict__ sidx, const unsigned *__restrict__ gscan /* inclusive scan of head flags */,
+                                                  const unsigned *__restrict__ gbif, const unsigned *__restrict__ gid /* exclusive scan of gbif */, unsigned nv,
+                                                  const unsigned *__restrict__ sepidx, unsigned nchr, unsigned E,
+                                                  unsigned *__restrict__ bif0, unsigned *__restrict__ bif1)
+{
+	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nv) return;
+	unsigned g = gscan[j] - 1;
+	if (!gbif[g]) return;
+	unsigned i = sidx[j], id = gid[g];
+	if (i < E) bif0[i] = id;
+	else {
+		unsigned r = i - E, c = lk_chr_of(sepidx, nchr, r + 1), jj = r - sepidx[c];
+		bif1[sepidx[c + 1] - 1 - jj] = id;
+	}
+}
+
+struct LongKScratch {
+	DevBuf rank[2], keys, skeys, idx, sidx, flag, scan, mask, gkeys, gmask, gcount, gbif, gid, tmp, sym;
+};
+static LongKScratch g_lk;       // grow-only scratch shared by all contexts of the process (calls are serialised per device queue)
+
+static void lk_sort(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	g_lk.tmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(g_lk.tmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+}
+static void lk_inclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::inclusive_scan(nullptr, tmp, in, out, n, rocprim::plus<unsigned>(), c->stream));
+	g_lk.tmp.ensure(tmp);
+	HIP_TRY(rocprim::inclusive_scan(g_lk.tmp.p, tmp, in, out, n, rocprim::plus<unsigned>(), c->stream));
+}
+static void lk_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+	g_lk.tmp.ensure(tmp);
+	HIP_TRY(rocprim::exclusive_scan(g_lk.tmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+}
+
+struct BitOr { __host__ __device__ unsigned operator()(unsigned a, unsigned b) const { return a | b; } };
+
+void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
+{
+	hipStream_t s = c->stream;
+	const size_t E = c->nelem, n = 2 * E - 1, np = n + k;             // 2L + 2 nchr + 1 = 2E - 1; padded with k '#'
+	SBL_CHECK(np < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "input too large for 32-bit suffix ranks");
+	c->cur_k = k;
+	LongKScratch &L = g_lk;
+	for (int t = 0; t < 2; t++) L.rank[t].ensure((np + 1) * 4);
+	L.sym.ensure((np + 1) * 4);
+	L.keys.ensure(np * 8); L.skeys.ensure(np * 8); L.idx.ensure(np * 4); L.sidx.ensure(np * 4);
+	L.flag.ensure(np * 4); L.scan.ensure(np * 4); L.mask.ensure(np * 4);
+	c->d_counters.ensure(64 * 4);
+	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+
+	unsigned *rank = L.rank[0].as<unsigned>();
+	k_lk_super<<<nblocks(np, 256), 256, 0, s>>>(c->d_ch.as<uint8_t>(), c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, (unsigned)np, rank);
+	HIP_TRY(hipMemcpyAsync(L.sym.p, rank, np * 4, hipMemcpyDeviceToDevice, s));
+	size_t h = 1;
+	while (2 * h <= k) {
+		k_lk_pair_keys<<<nblocks(np, 256), 256, 0, s>>>(rank, (unsigned)np, (unsigned)h, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
+		lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), np);
+		k_lk_heads<<<nblocks(np, 256), 256, 0, s>>>(L.skeys.as<unsigned long long>(), (unsigned)np, L.flag.as<unsigned>());
+		lk_inclusive_scan(c, L.flag.as<unsigned>(), L.scan.as<unsigned>(), np);
+		k_lk_scatter_rank<<<nblocks(np, 256), 256, 0, s>>>(L.sidx.as<unsigned>(), L.scan.as<unsigned>(), (unsigned)np, rank);
+		h *= 2;
+	}
+	k_lk_window_keys<<<nblocks(n, 256), 256, 0, s>>>(rank, c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, k, (unsigned)h,
+	                                                L.keys.as<unsigned long long>(), L.idx.as<unsigned>(), c->d_counters.as<unsigned>());
+	lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), n);
+	unsigned nv = 0;
+	HIP_TRY(hipMemcpyAsync(&nv, c->d_counters.p, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	for (int st = 0; st < 2; st++) {
+		c->d_bif[st].ensure(elem_capacity * 4);
+		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
+	}
+	c->bif_count = 0;
+	c->stats.strand_kmers = nv;
+	c->stats.kmer_table_ms = 0; c->stats.kmer_table_bytes = 0;
+	if (nv) {
+		k_lk_masks<<<nblocks(nv, 256), 256, 0, s>>>(L.skeys.as<unsigned long long>(), L.sidx.as<unsigned>(), nv, L.sym.as<unsigned>(), k,
+		                                           L.mask.as<unsigned>(), L.flag.as<unsigned>());
+		lk_inclusive_scan(c, L.flag.as<unsigned>(), L.scan.as<unsigned>(), nv);
+		unsigned ngroups = 0;
+		HIP_TRY(hipMemcpyAsync(&ngroups, L.scan.as<unsigned>() + (nv - 1), 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		L.gkeys.ensure((size_t)ngroups * 4 + 16); L.gmask.ensure((size_t)ngroups * 4 + 16); L.gcount.ensure(16);
+		L.gbif.ensure((size_t)ngroups * 4 + 16); L.gid.ensure((size_t)ngroups * 4 + 16);
+		{	// segmented OR of the masks: key = group number (the scan), one output per group, in order
+			size_t tmp = 0;
+			HIP_TRY(rocprim::reduce_by_key(nullptr, tmp, L.scan.as<unsigned>(), L.mask.as<unsigned>(), nv, L.gkeys.as<unsigned>(), L.gmask.as<unsigned>(),
+			                               L.gcount.as<unsigned>(), BitOr(), rocprim::equal_to<unsigned>(), s));
+			L.tmp.ensure(tmp);
+			HIP_TRY(rocprim::reduce_by_key(L.tmp.p, tmp, L.scan.as<unsigned>(), L.mask.as<unsigned>(), nv, L.gkeys.as<unsigned>(), L.gmask.as<unsigned>(),
+			                               L.gcount.as<unsigned>(), BitOr(), rocprim::equal_to<unsigned>(), s));
+		}
+		k_lk_group_bif<<<nblocks(ngroups, 256), 256, 0, s>>>(L.gmask.as<unsigned>(), ngroups, L.gbif.as<unsigned>());
+		lk_exclusive_scan(c, L.gbif.as<unsigned>(), L.gid.as<unsigned>(), ngroups);
+		unsigned last_id = 0, last_bif = 0;
+		HIP_TRY(hipMemcpyAsync(&last_id, L.gid.as<unsigned>() + (ngroups - 1), 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(&last_bif, L.gbif.as<unsigned>() + (ngroups - 1), 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		c->bif_count = last_id + last_bif;
+		k_lk_marks<<<nblocks(nv, 256), 256, 0, s>>>(L.sidx.as<unsigned>(), L.scan.as<unsigned>(), L.gbif.as<unsigned>(), L.gid.as<unsigned>(), nv,
+		                                           c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	c->stats.bif_count = c->bif_count;
+}

@@ -113,7 +113,7 @@ static void device_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-	SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
+	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }
 	hipStream_t s = c->stream;
 	size_t E = c->nelem, nwords = (E + 31) / 32;
 	size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
@@ -300,7 +300,6 @@ extern "C" sbl_status sbl_enumerate(sbl_ctx *c, uint32_t k, uint32_t *bif_count,
 {
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
 		bool temp = sanitise_apply(c);
 		sbl_run_enumeration(c, k, c->nelem);
 		for (int st = 0; st < 2; st++) {
@@ -340,7 +339,6 @@ extern "C" sbl_status sbl_list_edges(sbl_ctx *c, uint32_t k, const sbl_edge **ed
 {
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
 		bool temp = sanitise_apply(c);
 		sbl_run_enumeration(c, k, c->nelem);
 		c->edges.clear();
@@ -383,7 +381,6 @@ extern "C" sbl_status sbl_simplify_stage(sbl_ctx *c, uint32_t k, uint32_t min_br
 {
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-		SBL_CHECK(k <= 32, SBL_ERR_UNSUPPORTED, "vertex size k > 32 is not supported by this build yet");
 		if (sanitise_apply(c)) sbl_sanitise_commit(c);       // the sanitised copy flows back through the copy-back (src/blockfinder.cpp:85-95)
 		uint64_t b = 0;
 		sbl_simplify_run(c, k, min_branch_size, max_iterations, progress, user, &b);

@@ -64,6 +64,8 @@ struct sbl_ctx {
 void sbl_pack(sbl_ctx *c);
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // fills d_bif[0..1], bif_count
 void sbl_compact_marks(sbl_ctx *c, int strand);
+// implemented in longk.hip
+void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k > 32: exact rank doubling
 // implemented in simplify.hip
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
 void sbl_simplify_free(sbl_ctx *c);

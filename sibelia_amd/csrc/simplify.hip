@@ -692,8 +692,19 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	st->need.ensure(nidp); st->big.ensure(nidp); st->own.ensure(nidp * 4);
 	HIP_TRY(hipMemsetAsync(st->need.p, 0, nidp, s));
 	HIP_TRY(hipMemsetAsync(st->big.p, 0, nidp, s));
+	// scratch arena per window entry: window caches of ~16 instances (17 B per step, D + k + 2 steps) + FillVisit / Overlap
+	// buffers + the AnyBulges map; ids that need more run alone in the big arena
+	{
+		size_t ws = (size_t)D + k + 2;
+		size_t need = 16 * 17 * ws + 12 * (size_t)D + 8 * (size_t)k + (64u << 10);
+		be.arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(need, 128u << 10), 1u << 30);
+		be.snap_arena_bytes = be.arena_bytes;
+		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes));
+		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
+	}
 	uint32_t window = c->window ? c->window : 16384;
 	window = std::min<uint32_t>(window, (1u << 20) - 1);
+	window = (uint32_t)std::min<size_t>(window, std::max<size_t>(64, (24ull << 30) / be.arena_bytes));
 	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
 	be.window = window;
 	st->win.ensure((size_t)window * 4 + 16);
