@@ -300,6 +300,8 @@ struct BulgeWork {
 	uint8_t *wch;                // raw character per step
 	uint32_t *wlen;              // number of leading steps before the first separator (<= ws)
 	uint64_t *wmk; uint32_t *wmn; // compact list of the marked steps >= 1 of each window: (step << 32) | id, and their number
+	uint32_t *wst; char *wck;     // mark at step 0 and (oriented) character at step k of each window
+	bool lite;                   // verdict-only use: wel / wbf / wch are not materialised
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
@@ -324,7 +326,7 @@ __host__ __device__ inline uint32_t bt_count_instances(const GraphView &g, uint3
 }
 
 // ListPositions (bulgeremoval.cpp:335) + all scratch of the transaction.  False when fewer than two instances.
-__host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w)
+__host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false)
 {
 	GraphView &g = t.g;
 	uint32_t k = g.k, D = g.D;
@@ -336,15 +338,21 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w)
 	w.start = (uint32_t *)t.alloc(n * 4);
 	w.endc = (char *)t.alloc(n);
 	w.wlen = (uint32_t *)t.alloc(n * 4);
-	w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
-	w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
-	w.wch = (uint8_t *)t.alloc(n * w.ws);
-	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
 	w.wmn = (uint32_t *)t.alloc(n * 4);
+	w.wst = (uint32_t *)t.alloc(n * 4);
+	w.wck = (char *)t.alloc(n);
+	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
+	w.lite = lite;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
-	w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
-	w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
-	w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+	if (!lite) {
+		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
+		w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
+		w.wch = (uint8_t *)t.alloc(n * w.ws);
+		w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
+		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
+		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+	}
 	if (t.err) return false;
 	n = 0;
 	for (uint32_t s = 0; s < 2; s++)
@@ -359,11 +367,14 @@ __host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t 
 	size_t base = (size_t)i * w.ws;
 	SIt a = bt_deref(t, w.start[i]);
 	uint32_t s = 0, nm = 0;
+	const uint32_t k = t.g.k;
 	for (; s < w.ws; s++) {
 		t.tr(a.e);
 		uint8_t c = t.g.ch[a.e];
 		uint32_t b = t.g.bif[a.d][a.e];
-		w.wel[base + s] = a.e; w.wch[base + s] = c; w.wbf[base + s] = b;
+		if (!w.lite) { w.wel[base + s] = a.e; w.wch[base + s] = c; w.wbf[base + s] = b; }
+		if (s == 0) w.wst[i] = b;
+		if (s == k) w.wck[i] = a.d ? bt_comp((char)c) : (char)c;
 		if (c == BT_SEP) break;
 		if (s && b != BT_NONE) w.wmk[base + nm++] = ((uint64_t)s << 32) | b;
 		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
@@ -376,7 +387,7 @@ __host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w) { for (uint32_
 __host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
 {
 	uint32_t k = t.g.k;
-	for (uint32_t i = 0; i < w.n; i++) w.endc[i] = w.wlen[i] >= k + 1 ? bt_wchar(w, i, k) : ' ';
+	for (uint32_t i = 0; i < w.n; i++) w.endc[i] = w.wlen[i] >= k + 1 ? w.wck[i] : ' ';
 }
 
 // FillVisit, bulgeremoval.cpp:122-146
@@ -384,7 +395,7 @@ __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 {
 	uint32_t D = t.g.D, n = 0;
 	const uint64_t *mk = w.wmk + (size_t)i * w.ws;
-	uint32_t start = w.wbf[(size_t)i * w.ws], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+	uint32_t start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
 	for (uint32_t j = 0; j < nm; j++) {
 		uint32_t step = (uint32_t)(mk[j] >> 32), b = (uint32_t)mk[j];
 		if (step >= lim || b == start) break;
@@ -571,7 +582,7 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
 		const uint64_t *mk = w.wmk + (size_t)i * w.ws;
-		uint32_t start = w.wbf[(size_t)i * w.ws], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+		uint32_t start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
 		for (uint32_t j = 0; j < nm; j++) {
 			uint32_t b = (uint32_t)mk[j];
 			if ((uint32_t)(mk[j] >> 32) >= lim || b == start) break;

@@ -87,7 +87,11 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 		bool st = mine && lane <= stop;                               // the separator step itself is cached too
 		unsigned bv = st ? g.bif[dir][c] : BT_NONE;
-		if (st) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = bv; }
+		if (st) {
+			if (!w.lite) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = bv; }
+			if (done + lane == 0) w.wst[i] = bv;
+			if (done + lane == g.k) w.wck[i] = dir ? bt_comp((char)chv) : (char)chv;
+		}
 		{	// compact list of the marked steps (>= 1, before the separator), in step order
 			bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
 			unsigned long long mm = __ballot(marked);
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
 	for (unsigned id = blockIdx.x; id < g.nid; id += gridDim.x) {
 		__syncthreads();
-		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); ok = bt_setup(t, w) ? 1 : 0; }
+		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); ok = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
 		if (ok) {
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
@@ -133,7 +137,8 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 }
 
 // one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
-// (and runs alone if it is the lowest).  out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
+// (and runs alone if it is the lowest).  Eight ids per thread and step (8-byte loads of the need / big flags).
+// out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
 __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, unsigned lo, unsigned limit, unsigned W)
 {
 	__shared__ unsigned s_wave[16];
@@ -141,35 +146,52 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	if (threadIdx.x == 0) { s_base = 0; s_first = SBL_NONE; s_stop = 0; s_solo = 0; }
 	__syncthreads();
-	for (unsigned long long start = lo; start <= limit; start += 1024) {
-		unsigned long long idl = start + threadIdx.x;
-		unsigned id = (unsigned)idl;
-		bool pend = idl <= limit && g.need[id];
-		bool isbig = pend && g.big[id];
+	for (unsigned long long start = lo & ~7ull; start <= limit; start += 8192) {
+		const unsigned long long id0 = start + 8ull * threadIdx.x;
+		unsigned long long nb = 0, bb = 0;                       // byte j = id0 + j: 1 = pending / pending and big
+		if (id0 <= limit) {
+			nb = *reinterpret_cast<const unsigned long long *>(g.need + id0);
+			bb = *reinterpret_cast<const unsigned long long *>(g.big + id0);
+#pragma unroll
+			for (int j = 0; j < 8; j++) if (id0 + j < lo || id0 + j > limit) nb &= ~(0xFFull << (8 * j));
+			nb = (nb | (nb >> 1) | (nb >> 2) | (nb >> 3) | (nb >> 4) | (nb >> 5) | (nb >> 6) | (nb >> 7)) & 0x0101010101010101ull;
+			bb = (bb | (bb >> 1) | (bb >> 2) | (bb >> 3) | (bb >> 4) | (bb >> 5) | (bb >> 6) | (bb >> 7)) & nb;
+		}
 		if (threadIdx.x == 0) s_bigid = SBL_NONE;
 		__syncthreads();
-		if (isbig) atomicMin(&s_bigid, id);
-		if (pend) atomicMin(&s_first, id);
+		if (bb) atomicMin(&s_bigid, (unsigned)(id0 + (__builtin_ctzll(bb) >> 3)));
+		if (nb) atomicMin(&s_first, (unsigned)(id0 + (__builtin_ctzll(nb) >> 3)));
 		__syncthreads();
-		unsigned bigid = s_bigid;
-		bool take = pend && id < bigid;
-		unsigned long long m = __ballot(take);
-		unsigned before = __popcll(m & ((1ull << lane) - 1ull));
-		if (lane == 0) s_wave[wv] = __popcll(m);
+		const unsigned bigid = s_bigid;
+		unsigned long long tk = nb;
+		if (bigid != SBL_NONE) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) if (id0 + j >= bigid) tk &= ~(0xFFull << (8 * j));
+		}
+		const unsigned cnt = __popcll(tk);
+		unsigned incl = cnt;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
+		if (lane == 63) s_wave[wv] = incl;
 		__syncthreads();
 		unsigned woff = 0, total = 0;
 		for (unsigned w = 0; w < 16; w++) { unsigned v = s_wave[w]; if (w < wv) woff += v; total += v; }
-		unsigned pos = s_base + woff + before;
-		if (take && pos < W) win[pos] = id;
+		unsigned pos = s_base + woff + incl - cnt;
+		while (tk) {
+			unsigned j = __builtin_ctzll(tk) >> 3;
+			if (pos < W) win[pos] = (unsigned)(id0 + j);
+			pos++;
+			tk &= tk - 1;
+		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			unsigned cnt = s_base + total;
-			if (cnt >= W) { cnt = W; s_stop = 1; }
+			unsigned c = s_base + total;
+			if (c >= W) { c = W; s_stop = 1; }
 			else if (bigid != SBL_NONE) {
 				s_stop = 1;
-				if (cnt == 0) { win[0] = bigid; cnt = 1; s_solo = 1; }
+				if (c == 0) { win[0] = bigid; c = 1; s_solo = 1; }
 			}
-			s_base = cnt;
+			s_base = c;
 		}
 		__syncthreads();
 		if (s_stop) break;
@@ -311,7 +333,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	}
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
 	// ---- read-only pass: exclusive block locks, nothing read may have been written by a higher id
-	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w) ? 1 : 0; }
+	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w, true) ? 1 : 0; }
 	__syncthreads();
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);

@@ -27,7 +27,7 @@ __host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uin
 	BulgeWork w;
 	t.init(g, id, 0, 0, arena, arena_bytes);
 	bool v = false;
-	if (bt_setup(t, w)) { bt_scan_all(t, w); bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }
+	if (bt_setup(t, w, true)) { bt_scan_all(t, w); bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }
 	if (t.err & BT_ERR_SCRATCH) v = true;      // undecidable in the small arena: let the ordered phase run it
 	g.need[id] = v ? 1 : 0;
 }
