@@ -331,7 +331,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	GraphView &g = t.g;
 	uint32_t k = g.k, D = g.D;
 	t.ir(t.id);
-	uint32_t n = bt_count_instances(g, t.id);
+	uint32_t n = g.lsize[0][t.id] + g.lsize[1][t.id];      // lists are clean on entry (Cleanup ran): live nodes = list sizes
 	w.n = n;
 	if (n < 2) return false;
 	w.ws = D + k + 2;
@@ -354,10 +354,11 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
 	}
 	if (t.err) return false;
-	n = 0;
+	uint32_t m = 0;
 	for (uint32_t s = 0; s < 2; s++)
 		for (uint32_t nd = g.head[s][t.id]; nd != BT_NONE; nd = g.nnext[nd])
-			if (!g.ndead[nd]) w.start[n++] = (nd << 1) | s;
+			if (!g.ndead[nd] && m < n) w.start[m++] = (nd << 1) | s;
+	if (m != n) { t.err |= BT_ERR_SCRATCH; return false; }     // cannot happen on a consistent graph
 	return true;
 }
 

@@ -110,12 +110,61 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; }
 }
 
+// AnyBulges VERDICT with 64 lanes.  "Some bulge group gets a second member" is an order-free predicate: there is an
+// id b that two instances with different endChars both reach (steps 1 .. min(D, window) - 1, before their own id
+// recurs) -- whichever iteration order boost::unordered_map has.  Marks are hashed into a small LDS table that
+// collects the set of endChars per reached id.  Returns -1 when the marks do not fit (caller falls back to lane 0).
+#define VT_SLOTS 1024u
+struct VerdictTable { unsigned key[VT_SLOTS]; unsigned mask[VT_SLOTS]; };
+
+__device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane)
+{
+	for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+	__syncthreads();
+	const unsigned D = g.D, k = g.k;
+	unsigned total = 0;
+	bool found = false;
+	for (unsigned i = 0; i < w.n; i++) {
+		const unsigned len = w.wlen[i];
+		if (len < k + 1) continue;                                     // endChar == ' '
+		const char ec = w.wck[i];
+		const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
+		const unsigned lim = len < D ? len : D, nm = w.wmn[i], start = w.wst[i];
+		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.ws;
+		for (unsigned j0 = 0; j0 < nm; j0 += 64) {
+			unsigned j = j0 + lane;
+			unsigned long long v = j < nm ? mk[j] : ~0ull;
+			unsigned b = (unsigned)v, step = (unsigned)(v >> 32);
+			bool stop = j >= nm || step >= lim || b == start;
+			unsigned long long ms = __ballot(stop);
+			unsigned upto = ms ? (unsigned)__builtin_ctzll(ms) : 64u;    // marks before the first stop condition
+			total += upto;
+			if (total > VT_SLOTS / 2) return -1;
+			if (lane < upto) {
+				unsigned h = (b * 2654435761u) >> 22;                    // 10 bits
+				for (;;) {
+					unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
+					if (old == BT_NONE || old == b) {
+						unsigned m = atomicOr(&vt.mask[h], bit) | bit;
+						if (m & (m - 1)) found = true;
+						break;
+					}
+					h = (h + 1) & (VT_SLOTS - 1);
+				}
+			}
+			if (upto < 64) break;
+		}
+	}
+	return __any(found) ? 1 : 0;
+}
+
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
 // lane 0 evaluates the Boost-ordered map on the cached marks).
 __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
+	__shared__ VerdictTable vt;
 	__shared__ int ok;
 	const unsigned lane = threadIdx.x;
 	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
@@ -127,9 +176,10 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
 			__syncthreads();
 		}
+		int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
 		if (lane == 0) {
-			bool v = false;
-			if (ok) { bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }
+			bool v = verdict > 0;
+			if (verdict < 0) { bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }      // too many marks for the LDS table
 			if (t.err & BT_ERR_SCRATCH) v = true;
 			g.need[id] = v ? 1 : 0;
 		}
@@ -314,6 +364,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
+	__shared__ VerdictTable vt;
 	__shared__ int flag;
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
@@ -339,9 +390,10 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
 		__syncthreads();
 	}
+	int verdict = flag ? wave_verdict(g, w, vt, lane) : 0;
 	if (lane == 0) {
-		bool has = false;
-		if (flag) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+		bool has = verdict > 0;
+		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 		if (t.err & BT_ERR_SCRATCH) { ss_mark_big(g, id); has = false; }
 		else atomicAdd(&g.ctr[CTR_COMMITTED], 1u);
 		flag = has ? 1 : 0;
