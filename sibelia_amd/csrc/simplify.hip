@@ -55,6 +55,15 @@ __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *_
 	atomicAdd(&lsize[id], 1u);
 }
 
+// largest number of instances of any id (sizes the per-transaction scratch arena)
+__global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restrict__ l0, const unsigned *__restrict__ l1, unsigned nid, unsigned *__restrict__ out)
+{
+	unsigned m = 0;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nid; i += gridDim.x * blockDim.x) { unsigned v = l0[i] + l1[i]; m = v > m ? v : m; }
+	for (int d = 32; d > 0; d >>= 1) { unsigned v = __shfl_down(m, d); m = v > m ? v : m; }
+	if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // ------------------------------------------------------------------------------------------- SimplifyGraph kernels
 // ---- wave-cooperative window scan ---------------------------------------------------------------------------
 // Fills instance i's window cache (bulge_txn.h: BulgeWork) with 64 lanes: the same values bt_scan_instance
@@ -769,8 +778,17 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	// scratch arena per window entry: window caches of ~16 instances (17 B per step, D + k + 2 steps) + FillVisit / Overlap
 	// buffers + the AnyBulges map; ids that need more run alone in the big arena
 	{
+		// instances per id: the arena holds the window caches of an id with up to 1.5x the typical maximum (ids with
+		// more -- repeat families -- run alone in the big arena)
+		unsigned maxn = 0;
+		HIP_TRY(hipMemsetAsync(st->ctr.as<unsigned>() + CTR_BIG, 0, 4, s));
+		if (be.nid_) k_max_instances<<<256, 256, 0, s>>>(st->lsize[0].as<unsigned>(), st->lsize[1].as<unsigned>(), be.nid_, st->ctr.as<unsigned>() + CTR_BIG);
+		HIP_TRY(hipMemcpyAsync(&maxn, st->ctr.as<unsigned>() + CTR_BIG, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		HIP_TRY(hipMemsetAsync(st->ctr.as<unsigned>() + CTR_BIG, 0, 4, s));
+		size_t slots = std::min<size_t>(std::max<size_t>(16, maxn + maxn / 2), 2048);
 		size_t ws = (size_t)D + k + 2;
-		size_t need = 16 * 17 * ws + 12 * (size_t)D + 8 * (size_t)k + (64u << 10);
+		size_t need = slots * 17 * ws + 12 * (size_t)D + 8 * (size_t)k + (64u << 10) + slots * 64;
 		be.arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(need, 128u << 10), 1u << 30);
 		be.snap_arena_bytes = be.arena_bytes;
 		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes));
