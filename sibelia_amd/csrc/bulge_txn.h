@@ -309,6 +309,9 @@ struct BulgeWork {
 	// resumable loop state of RemoveBulges (a collapse interrupts the loops for a window rescan)
 	uint32_t gi, idI, idJ, ret;
 	bool inI, need_fill;
+	// the collapse bt_rb_run has decided on (performed by the caller: bt_collapse on one thread, or 64 lanes in simplify.hip)
+	uint32_t c_src, c_dS, c_tgt, c_dT;
+	uint32_t *act;               // scratch for the wave-wide collapse: (strand, element, id) AddPoint actions
 };
 
 __host__ __device__ __forceinline__ SIt bt_deref(Txn &t, uint32_t packed) { SIt a; a.e = t.g.nslot[packed >> 1]; a.d = packed & 1; return a; }
@@ -343,7 +346,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc(n);
 	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
 	w.lite = lite;
-	w.wel = w.wbf = nullptr; w.wch = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
 	if (!lite) {
 		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
@@ -352,6 +355,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
 		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
 	}
 	if (t.err) return false;
 	uint32_t m = 0;
@@ -623,8 +627,9 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 
 // RemoveBulges, bulgeremoval.cpp:330-430, as a resumable routine over the window cache.
 //   bt_rb_begin: endChar + AnyBulges on freshly scanned windows; false = nothing to do.
-//   bt_rb_run:   runs the group / I / J loops until a collapse has been applied (returns true: the caller must
-//                rescan the windows and call again) or everything is done (returns false, Cleanup performed).
+//   bt_rb_run:   runs the group / I / J loops until a collapse has been decided (returns true: the caller performs
+//                CollapseBulgeGreedily(c_src -> c_tgt), rescans the windows and calls again) or everything is done
+//                (returns false, Cleanup performed).
 __host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w)
 {
 	bt_end_chars(t, w);
@@ -667,14 +672,13 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 						uint32_t jmlp = bt_max_mult(t, w, kmerJ, dJ);
 						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
 							w.endc[kmerJ] = w.endc[kmerI];
-							bt_collapse(t, w, kmerI, dI, kmerJ, dJ);
+							w.c_src = kmerI; w.c_dS = dI; w.c_tgt = kmerJ; w.c_dT = dJ;
 						} else {
 							w.endc[kmerI] = w.endc[kmerJ];
-							bt_collapse(t, w, kmerJ, dJ, kmerI, dI);
+							w.c_src = kmerJ; w.c_dS = dJ; w.c_tgt = kmerI; w.c_dT = dI;
 							w.need_fill = true;                      // FillVisit(I) again, on the rescanned window
 						}
-						if (t.err) return false;
-						return true;                                 // graph changed: rescan, then continue with the next J
+						return true;                                 // caller: collapse(c_src -> c_tgt), rescan, then call again (next J)
 					}
 				}
 			}

@@ -367,6 +367,143 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 		}
 	if (lane == 0) cl.buf[0] = cl.n;
 }
+// ---- wave-wide CollapseBulgeGreedily ------------------------------------------------------------------------
+// Same effect as bt_collapse (bulge_txn.h) = EraseBifurcations + DNASequence::Replace + UpdateBifurcations
+// (reference src/bulgeremoval.cpp:55-95, 238-327, src/dnasequence.cpp:189-252), but every element the reference reaches
+// by walking iterators is taken from the cached windows of the target (T) and source (S) instances, so the k + dT and
+// dS + 1 step loops run 64 steps at a time; only the order-dependent parts stay on lane 0: the ~10 AddPoint calls
+// (front insertion order matters) and the position interpolation (sequential double accumulation).
+__device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned stampv, unsigned tid, unsigned id, unsigned b)
+{
+	unsigned r = g.nblk + b;
+	unsigned old = atomicMin(&g.lock[r], stampv);
+	bool bad = old != stampv && (old >> 20) == (stampv >> 20);
+	unsigned other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
+	unsigned a = atomicMax(&g.wmax[r], tid);
+	if (a > tid || g.rmax[r] > tid) bad = true;
+	if (bad) atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+}
+// ErasePoint (bifurcationstorage.cpp:144-155) for one (strand, element) per lane; the lazy-erase chain head lives in LDS
+__device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned strand, unsigned e, unsigned stampv)
+{
+	unsigned b = g.bif[strand][e];
+	if (b == BT_NONE) return;
+	unsigned nd = g.nodeof[strand][e];
+	g.bif[strand][e] = BT_NONE;
+	g.ndead[nd] = 1;
+	g.nclr[nd] = atomicExch(&t.tc_head, nd);
+	if (t.mode) wave_stamp_id_write(g, stampv, t.tid, t.id, b);
+	if (b > t.id && b < g.nid) g.need[b] = 1;
+}
+
+__device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv)
+{
+	const unsigned k = g.k, ws = w.ws;
+	const unsigned src = w.c_src, dS = w.c_dS, tgt = w.c_tgt, dT = w.c_dT;
+	const unsigned d = w.start[tgt] & 1u, opp = d ^ 1u, ds = w.start[src] & 1u;
+	const unsigned *T = w.wel + (size_t)tgt * ws, *S = w.wel + (size_t)src * ws;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	// ---- EraseBifurcations, first loop: remember and erase the k-flanks (lookBack on the opposite strand, lookForward ahead)
+	unsigned nlb = 0, nlf = 0;
+	for (unsigned i0 = 0; i0 < k; i0 += 64) {
+		unsigned i = i0 + lane;
+		bool in = i < k;
+		unsigned ea = in ? T[k - 1 - i] : 0u, eb = in ? T[dT + i] : 0u;
+		unsigned ba = in ? g.bif[opp][ea] : BT_NONE, bb = in ? g.bif[d][eb] : BT_NONE;
+		unsigned long long ma = __ballot(ba != BT_NONE), mb = __ballot(bb != BT_NONE);
+		if (ba != BT_NONE) { unsigned o = nlb + __popcll(ma & lt); w.lb[2 * o] = i; w.lb[2 * o + 1] = ba; wave_erase(g, t, opp, ea, stampv); }
+		if (bb != BT_NONE) { unsigned o = nlf + __popcll(mb & lt); w.lf[2 * o] = i; w.lf[2 * o + 1] = bb; wave_erase(g, t, d, eb, stampv); }
+		nlb += __popcll(ma); nlf += __popcll(mb);
+	}
+	__syncthreads();
+	// ---- second loop: every own-strand mark after the target start and every opposite-strand mark over k + dT elements
+	for (unsigned i0 = 0; i0 < k + dT; i0 += 64) {
+		unsigned i = i0 + lane;
+		if (i < k + dT) { unsigned e = T[i]; if (i > 0) wave_erase(g, t, d, e, stampv); wave_erase(g, t, opp, e, stampv); }
+	}
+	__syncthreads();
+	// ---- DNASequence::Replace in + coordinates: P(j) = j-th element of the old span, C(j) = j-th new character
+	__shared__ unsigned s_newbase;
+	const unsigned common = dS < dT ? dS : dT;
+	if (lane == 0) {
+		t.wrote = true;
+		auto P = [&](unsigned j) { return d == 0 ? T[k + j] : T[k + dT - 1 - j]; };
+		auto OC = [&](unsigned x) { char c = (char)w.wch[(size_t)src * ws + x]; return ds ? bt_comp(c) : c; };
+		auto C = [&](unsigned j) { return d == 0 ? OC(k + j) : bt_comp(OC(k + dS - 1 - j)); };
+		const unsigned Eafter = d == 0 ? T[k + dT] : T[k - 1];
+		const unsigned firstPos = g.op[P(0)] & BT_POS_MASK, lastPos = g.op[Eafter] & BT_POS_MASK;
+		unsigned newbase = BT_NONE;
+		for (unsigned j = 0; j < common; j++) g.ch[P(j)] = (uint8_t)C(j);
+		if (dS < dT) {
+			for (unsigned j = dS; j < dT; j++) g.ch[P(j)] = BT_DEAD_CHAR;
+			unsigned before = P(dS - 1);
+			g.nx[before] = Eafter; g.pv[Eafter] = before;
+		} else if (dS > dT) {
+			unsigned m = dS - dT, span = (m + 31u) & ~31u;
+			unsigned base = atomicAdd(&g.ctr[CTR_NE], span);
+			if (base + span > g.cap_e) t.err |= BT_ERR_ELEM_CAP;
+			else {
+				unsigned before = P(dT - 1);
+				for (unsigned i = 0; i < span; i++) {
+					unsigned ne = base + i;
+					g.bif[0][ne] = g.bif[1][ne] = BT_NONE;
+					if (i < m) { g.ch[ne] = (uint8_t)C(dT + i); g.op[ne] = 0; g.nx[before] = ne; g.pv[ne] = before; before = ne; }
+					else g.ch[ne] = BT_DEAD_CHAR;
+				}
+				g.nx[before] = Eafter; g.pv[Eafter] = before;
+				newbase = base;
+			}
+		}
+		if (!t.err) {
+			double acc = (double)firstPos, ssize = (double)dT / (double)dS;     // dnasequence.cpp:221-227, same operation order
+			for (unsigned j = 0; j < dS; j++, acc += ssize) {
+				unsigned long long p = (unsigned long long)acc;
+				if (p > lastPos) p = lastPos;
+				unsigned e = j < common ? P(j) : newbase + (j - dT);
+				g.op[e] = (unsigned)p & BT_POS_MASK;
+			}
+		}
+		s_newbase = newbase;
+	}
+	__syncthreads();
+	if (t.err) return;
+	const unsigned newbase = s_newbase;
+	// element at step s of the target walk AFTER the replacement
+	auto newT = [&](unsigned s) -> unsigned {
+		if (s < k) return T[s];
+		if (s >= k + dS) return T[s - dS + dT];
+		unsigned idx = s - k, fj = d == 0 ? idx : dS - 1 - idx;
+		return fj < common ? (d == 0 ? T[k + fj] : T[k + dT - 1 - fj]) : newbase + (fj - dT);
+	};
+	// ---- UpdateBifurcations, second loop first as DATA: source marks to copy, in the reference's order (own strand, then opposite)
+	unsigned nact = 0;
+	for (unsigned i0 = 0; i0 <= dS; i0 += 64) {
+		unsigned i = i0 + lane;
+		bool in = i <= dS;
+		unsigned b1 = in ? w.wbf[(size_t)src * ws + i] : BT_NONE;
+		unsigned b2 = in ? g.bif[ds ^ 1u][S[dS + k - 1 - i]] : BT_NONE;
+		unsigned long long m1 = __ballot(b1 != BT_NONE), m2 = __ballot(b2 != BT_NONE);
+		unsigned o = nact + __popcll(m1 & lt) + __popcll(m2 & lt);
+		if (b1 != BT_NONE) { w.act[3 * o] = d; w.act[3 * o + 1] = newT(i); w.act[3 * o + 2] = b1; o++; }
+		if (b2 != BT_NONE) { w.act[3 * o] = opp; w.act[3 * o + 1] = newT(dS + k - 1 - i); w.act[3 * o + 2] = b2; }
+		nact += __popcll(m1) + __popcll(m2);
+	}
+	__syncthreads();
+	if (lane == 0) {
+		// first loop: restore the flanks (merge of the two index-sorted lists, look-back before look-forward at equal index)
+		unsigned a = 0, b = 0;
+		while (a < nlb || b < nlf) {
+			bool takeA = b >= nlf || (a < nlb && w.lb[2 * a] <= w.lf[2 * b]);
+			SIt p;
+			if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point(p, w.lb[2 * a + 1]); a++; }
+			else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point(p, w.lf[2 * b + 1]); b++; }
+		}
+		for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point(p, w.act[3 * x + 2]); }
+		t.push_e = T[0]; t.push_d = d; t.push_len = dS;
+	}
+	__syncthreads();
+}
+
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
 __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims)
@@ -421,6 +558,8 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
 			__syncthreads();
 			if (!flag) break;
+			wave_collapse(g, t, w, lane, stampv);
+			if (t.err) break;
 			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
 			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);

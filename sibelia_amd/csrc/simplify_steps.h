@@ -65,7 +65,7 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	while (more) {
 		more = bt_rb_run(t, w);
 		if (t.err) break;
-		if (more) bt_scan_all(t, w);
+		if (more) { bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT); if (t.err) break; bt_scan_all(t, w); }
 	}
 	if (t.err) {
 		if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
