@@ -22,6 +22,7 @@
 #define BT_SEP '$'
 #define BT_DEAD_CHAR 0            // ch[] of an element that was erased from the list
 #define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
+#define BT_MAX_BREAKS 16u
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
@@ -75,6 +76,7 @@ struct Txn {
 	uint32_t mode;
 	uint32_t last_r, last_w;            // one-entry caches of the last stamped blocks
 	uint8_t *scr; uint32_t scr_cap, scr_used;
+	uint8_t *fscr; uint32_t fscr_cap, fscr_used;   // optional small fast scratch (LDS in the kernels); falloc never fails loudly
 	uint32_t err;
 	uint32_t tc_head;                   // lazy erase chain (BifurcationStorage::toClear_), linked through g.nclr
 	bool wrote;                         // the graph has been modified by this transaction
@@ -85,7 +87,7 @@ struct Txn {
 	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
 	{
 		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
-		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; push_e = BT_NONE; push_d = 0; push_len = 0;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; push_e = BT_NONE; push_d = 0; push_len = 0;
 	}
 	// ---- scratch
 	__host__ __device__ void *alloc(uint32_t bytes)
@@ -95,6 +97,15 @@ struct Txn {
 		scr_used = a + bytes;
 		return scr + a;
 	}
+	__host__ __device__ void *falloc(uint32_t bytes)
+	{
+		uint32_t a = (fscr_used + 7u) & ~7u;
+		if (!fscr || a + bytes > fscr_cap || a + bytes < a) return nullptr;
+		fscr_used = a + bytes;
+		return fscr + a;
+	}
+	// fast scratch if it fits, the arena otherwise
+	__host__ __device__ void *alloc2(uint32_t bytes) { void *p = falloc(bytes); return p ? p : alloc(bytes); }
 	// ---- order validation (simplify.hip explains the protocol)
 	__host__ __device__ void violation(uint32_t other_prio)
 	{
@@ -301,6 +312,7 @@ struct BulgeWork {
 	uint32_t *wlen;              // number of leading steps before the first separator (<= ws)
 	uint64_t *wmk; uint32_t *wmn; // compact list of the marked steps >= 1 of each window: (step << 32) | id, and their number
 	uint32_t *wst; char *wck;     // mark at step 0 and (oriented) character at step k of each window
+	uint32_t *wbk, *wnb;          // steps at which the walk leaves consecutive slots (BT_MAX_BREAKS per window) and their number
 	bool lite;                   // verdict-only use: wel / wbf / wch are not materialised
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
@@ -346,13 +358,15 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc(n);
 	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
 	w.lite = lite;
-	w.wel = w.wbf = nullptr; w.wch = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
 	if (!lite) {
 		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
 		w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
 		w.wch = (uint8_t *)t.alloc(n * w.ws);
-		w.visit = (uint64_t *)t.alloc(w.visit_cap * 8);
+		w.wbk = (uint32_t *)t.alloc(n * BT_MAX_BREAKS * 4);
+		w.wnb = (uint32_t *)t.alloc(n * 4);
+		w.visit = (uint64_t *)t.alloc2(w.visit_cap * 8);
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
 		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
@@ -371,9 +385,11 @@ __host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t 
 {
 	size_t base = (size_t)i * w.ws;
 	SIt a = bt_deref(t, w.start[i]);
-	uint32_t s = 0, nm = 0;
+	uint32_t s = 0, nm = 0, nb = 0, prev = 0;
 	const uint32_t k = t.g.k;
 	for (; s < w.ws; s++) {
+		if (!w.lite && s && a.e != (a.d ? prev - 1 : prev + 1)) { if (nb < BT_MAX_BREAKS) w.wbk[i * BT_MAX_BREAKS + nb] = s; nb++; }
+		prev = a.e;
 		t.tr(a.e);
 		uint8_t c = t.g.ch[a.e];
 		uint32_t b = t.g.bif[a.d][a.e];
@@ -385,6 +401,7 @@ __host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t 
 		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
 	}
 	w.wlen[i] = s; w.wmn[i] = nm;
+	if (!w.lite) w.wnb[i] = nb;
 }
 __host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w) { for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
 
@@ -411,8 +428,10 @@ __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 	w.nvisit = n;
 }
 
-// Overlap, bulgeremoval.cpp:97-120
-__host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
+// Overlap, bulgeremoval.cpp:97-120: do the element sets [I, I + dI + k) and [J, J + dJ + k) intersect?
+// A window is a few runs of consecutive slots (breaks only where earlier collapses inserted or erased elements),
+// so the sets are compared as slot intervals; the sorted-set form is kept for windows with many breaks.
+__host__ __device__ inline bool bt_overlap_sets(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
 {
 	uint32_t k = t.g.k, n = di + k;
 	if (n > w.occ_cap) { t.err |= BT_ERR_SCRATCH; return true; }
@@ -423,6 +442,30 @@ __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uin
 		uint32_t e = ej[x], lo = 0, hi = n;
 		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.occ[mid] < e) lo = mid + 1; else hi = mid; }
 		if (lo < n && w.occ[lo] == e) return true;
+	}
+	return false;
+}
+__host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
+{
+	const uint32_t k = t.g.k, ni = di + k, nj = dj + k;
+	if (w.wnb[i] > BT_MAX_BREAKS || w.wnb[j] > BT_MAX_BREAKS) return bt_overlap_sets(t, w, i, di, j, dj);
+	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
+	const uint32_t *bi = w.wbk + i * BT_MAX_BREAKS, *bj = w.wbk + j * BT_MAX_BREAKS;
+	// runs of window i: [s0, s1) with s1 = next break (or ni)
+	uint32_t xi = 0;
+	for (uint32_t s0 = 0; s0 < ni;) {
+		while (xi < w.wnb[i] && bi[xi] <= s0) xi++;
+		uint32_t s1 = xi < w.wnb[i] && bi[xi] < ni ? bi[xi] : ni;
+		uint32_t a0 = ei[s0], a1 = ei[s1 - 1], alo = a0 < a1 ? a0 : a1, ahi = a0 < a1 ? a1 : a0;
+		uint32_t xj = 0;
+		for (uint32_t r0 = 0; r0 < nj;) {
+			while (xj < w.wnb[j] && bj[xj] <= r0) xj++;
+			uint32_t r1 = xj < w.wnb[j] && bj[xj] < nj ? bj[xj] : nj;
+			uint32_t b0 = ej[r0], b1 = ej[r1 - 1], blo = b0 < b1 ? b0 : b1, bhi = b0 < b1 ? b1 : b0;
+			if (alo <= bhi && blo <= ahi) return true;
+			r0 = r1;
+		}
+		s0 = s1;
 	}
 	return false;
 }
@@ -568,18 +611,28 @@ __host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK,
 __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict_only)
 {
 	uint32_t D = t.g.D, n = w.n;
-	// capacity: whatever scratch is left, split between the map and the member log
-	uint32_t left = t.scr_cap - ((t.scr_used + 7u) & ~7u);
-	uint32_t cap = left / 48;                        // key 4 + nxt 4 + echar 1 + head/tail/cnt 12 + buckets 2x4 + log 2x8 < 48
-	if (cap < 16) { t.err |= BT_ERR_SCRATCH; return false; }
+	// capacity: the number of marks in the windows bounds the number of map entries; it goes to the fast scratch
+	// (LDS) when it fits there, otherwise the map takes whatever arena is left
+	uint32_t marks = 0;
+	for (uint32_t i = 0; i < n; i++) marks += w.wmn[i];
+	uint32_t cap = marks < 16 ? 16 : marks;
+	bool fast = t.fscr && (t.fscr_cap - ((t.fscr_used + 7u) & ~7u)) / 48 >= cap + n / 2 + 2;
+	if (!fast) {
+		uint32_t left = t.scr_cap - ((t.scr_used + 7u) & ~7u);
+		uint32_t fit = left / 48;                    // key 4 + nxt 4 + echar 1 + head/tail/cnt 12 + buckets 2x4 + log 2x8 < 48
+		if (fit < 16) { t.err |= BT_ERR_SCRATCH; return false; }
+		if (cap > fit) cap = fit;
+	}
 	uint32_t bcap = bt_new_bucket_count(cap + 1);
 	if (bcap > 2 * cap) bcap >>= 1;
+	if (bcap < 16) bcap = 16;
 	BoostMap m;
-	m.key = (uint32_t *)t.alloc(cap * 4); m.nxt = (int32_t *)t.alloc(cap * 4); m.bprev = (int32_t *)t.alloc(bcap * 4);
-	char *echar = (char *)t.alloc(cap);
-	uint32_t *mhead = (uint32_t *)t.alloc(cap * 4), *mtail = (uint32_t *)t.alloc(cap * 4), *mcnt = (uint32_t *)t.alloc(cap * 4);
+	auto A = [&](uint32_t bytes) { return fast ? t.alloc2(bytes) : t.alloc(bytes); };
+	m.key = (uint32_t *)A(cap * 4); m.nxt = (int32_t *)A(cap * 4); m.bprev = (int32_t *)A(bcap * 4);
+	char *echar = (char *)A(cap);
+	uint32_t *mhead = (uint32_t *)A(cap * 4), *mtail = (uint32_t *)A(cap * 4), *mcnt = (uint32_t *)A(cap * 4);
 	uint32_t logcap = cap + n;
-	uint32_t *log_inst = (uint32_t *)t.alloc(logcap * 4), *log_next = (uint32_t *)t.alloc(logcap * 4);
+	uint32_t *log_inst = (uint32_t *)A(logcap * 4), *log_next = (uint32_t *)A(logcap * 4);
 	if (t.err) return false;
 	m.size = 0; m.cap = cap; m.bc = 0; m.bcap = bcap; m.first = -1; m.started = false;
 	uint32_t nlog = 0;
@@ -611,8 +664,8 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	if (!any || verdict_only) return any;
 	uint32_t ng = 0, total = 0;
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (mcnt[p] > 1) { ng++; total += mcnt[p]; }
-	w.ab.grp_off = (uint32_t *)t.alloc((ng + 1) * 4);
-	w.ab.grp_mem = (uint32_t *)t.alloc(total * 4);
+	w.ab.grp_off = (uint32_t *)t.alloc2((ng + 1) * 4);
+	w.ab.grp_mem = (uint32_t *)t.alloc2(total * 4);
 	if (t.err) return false;
 	uint32_t gi = 0, o = 0;
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) {

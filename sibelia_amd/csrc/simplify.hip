@@ -83,8 +83,12 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 {
 	const size_t base = (size_t)i * w.ws;
 	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
-	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws, nm = 0;
+	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws, nm = 0, nb = 0, lastc = 0;
 	while (done < ws && cur != BT_NONE) {
+		if (!w.lite && done && cur != (dir ? lastc - 1 : lastc + 1)) {      // the walk leaves consecutive slots here
+			if (lane == 0 && nb < BT_MAX_BREAKS) w.wbk[i * BT_MAX_BREAKS + nb] = done;
+			nb++;
+		}
 		bool inr = done + lane < ws && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
 		bool link = inr && (lane == 0 || (dir ? g.pv[c + 1] == c : g.nx[c - 1] == c));
@@ -114,16 +118,17 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		if (stop < pre) { wl = done + stop; break; }
 		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		cur = __shfl(lnk, pre - 1);
+		lastc = __shfl(c, pre - 1);
 		done += pre;
 	}
-	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; }
+	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; }
 }
 
 // AnyBulges VERDICT with 64 lanes.  "Some bulge group gets a second member" is an order-free predicate: there is an
 // id b that two instances with different endChars both reach (steps 1 .. min(D, window) - 1, before their own id
 // recurs) -- whichever iteration order boost::unordered_map has.  Marks are hashed into a small LDS table that
 // collects the set of endChars per reached id.  Returns -1 when the marks do not fit (caller falls back to lane 0).
-#define VT_SLOTS 1024u
+#define VT_SLOTS 512u
 struct VerdictTable { unsigned key[VT_SLOTS]; unsigned mask[VT_SLOTS]; };
 
 __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane)
@@ -150,7 +155,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 			total += upto;
 			if (total > VT_SLOTS / 2) return -1;
 			if (lane < upto) {
-				unsigned h = (b * 2654435761u) >> 22;                    // 10 bits
+				unsigned h = (b * 2654435761u) >> 23;                    // 9 bits
 				for (;;) {
 					unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
 					if (old == BT_NONE || old == b) {
@@ -512,6 +517,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int flag;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // FillVisit list + AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
@@ -547,7 +553,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__syncthreads();
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
-	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
 	__syncthreads();
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
