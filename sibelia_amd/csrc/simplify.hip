@@ -91,15 +91,17 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		}
 		bool inr = done + lane < ws && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
-		bool link = inr && (lane == 0 || (dir ? g.pv[c + 1] == c : g.nx[c - 1] == c));
-		unsigned long long ml = __ballot(link);
+		unsigned plink = inr && lane ? (dir ? g.pv[c + 1] : g.nx[c - 1]) : c;   // speculative loads, one round trip per 64 elements
+		unsigned chv = inr ? g.ch[c] : 0u;
+		unsigned bvl = inr ? g.bif[dir][c] : BT_NONE;
+		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
+		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
 		bool mine = lane < pre;
-		unsigned chv = mine ? g.ch[c] : 0u;
 		unsigned long long ms = __ballot(mine && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 		bool st = mine && lane <= stop;                               // the separator step itself is cached too
-		unsigned bv = st ? g.bif[dir][c] : BT_NONE;
+		unsigned bv = st ? bvl : BT_NONE;
 		if (st) {
 			if (!w.lite) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = bv; }
 			if (done + lane == 0) w.wst[i] = bv;
@@ -116,7 +118,6 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			if (st && chv != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
 		}
 		if (stop < pre) { wl = done + stop; break; }
-		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		cur = __shfl(lnk, pre - 1);
 		lastc = __shfl(c, pre - 1);
 		done += pre;
@@ -284,17 +285,18 @@ __device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned fir
 	while (done < maxcount && cur != BT_NONE) {
 		bool inr = done + lane < maxcount && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
-		bool link = inr && (lane == 0 || (dir ? g.pv[c + 1] == c : g.nx[c - 1] == c));
-		unsigned long long ml = __ballot(link);
+		// all loads of the step are issued together (speculatively for lanes past a link break): one memory round trip per 64 elements
+		unsigned plink = inr && lane ? (dir ? g.pv[c + 1] : g.nx[c - 1]) : c;
+		unsigned chv = inr ? g.ch[c] : 0u;
+		unsigned b0 = inr ? g.bif[0][c] : BT_NONE, b1 = inr ? g.bif[1][c] : BT_NONE;
+		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
+		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);      // intact prefix, >= 1
-		bool mine = lane < pre;
-		unsigned chv = mine ? g.ch[c] : 0u;
-		unsigned long long ms = __ballot(mine && chv == BT_SEP);
+		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
 		bool proc = lane < pre && lane < stop;
-		f(proc ? g.bif[0][c] : BT_NONE, proc ? g.bif[1][c] : BT_NONE);
+		f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
 		if (stop < pre) break;
-		unsigned lnk = mine ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
 	}
