@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 // (an insertion or deletion made by an earlier collapse).  Visits exactly the elements bt_footprint visits.
 #define CLAIM_CAP 4096u                      // ids a window entry can list; beyond that commit re-walks serially
 
-struct ClaimList { unsigned *buf; unsigned n; };
+#define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
+struct ClaimList { unsigned *buf; unsigned n; unsigned *seen; };
 
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
@@ -305,6 +306,17 @@ __device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned fir
 __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
 {
 	bool has = b != BT_NONE;
+	if (has) {                                                   // claim every id once per wave
+		unsigned h = (b * 2654435761u) >> 21;
+		has = false;
+		for (int probe = 0; probe < 8; probe++) {
+			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
+			if (old == BT_NONE) { has = true; break; }
+			if (old == b) break;
+			h = (h + 1) & (SEEN_SLOTS - 1);
+			if (probe == 7) has = true;                          // crowded table: claim again, harmless
+		}
+	}
 	if (has) atomicMin(&g.own[b], st);
 	unsigned long long m = __ballot(has);
 	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
@@ -361,8 +373,11 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 {
 	unsigned w = blockIdx.x, lane = threadIdx.x;
 	if (w >= nwin) return;
+	__shared__ unsigned seen[SEEN_SLOTS];
+	for (unsigned i = lane; i < SEEN_SLOTS; i += 64) seen[i] = BT_NONE;
+	__syncthreads();
 	unsigned id = g.win[w], st = g.round_bits | w;
-	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0;
+	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0; cl.seen = seen;
 	wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
 	unsigned back = g.D + g.k, fwd = 2 * (g.D + g.k) + g.k;
 	for (unsigned s = 0; s < 2; s++)
