@@ -66,7 +66,8 @@ typedef struct {
 	double kmer_table_ms;            /* duration of the dominant kernel (k-mer table build) */
 	uint64_t kmer_table_bytes;       /* its algorithmic HBM bytes */
 	double snapshot_ms, reserve_ms, commit_ms;   /* SimplifyGraph kernel time by phase */
-	uint64_t executed;               /* RemoveBulges transactions run in ordered rounds */
+	double probe_ms;
+	uint64_t executed;               /* pending ids examined in ordered rounds (retired by the probe or committed) */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

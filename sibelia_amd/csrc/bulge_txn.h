@@ -73,6 +73,7 @@ struct Txn {
 	// 0: no validation (snapshot verdicts, solo runs)
 	// 1: read-only pass of a round: exclusive block locks + "nothing I read was written by a higher id"
 	// 2: writer pass: additionally publishes its reads / writes in rmax / wmax
+	// 3: probe (no writer runs concurrently): only "nothing I read was written by a higher id"
 	uint32_t mode;
 	uint32_t last_r, last_w;            // one-entry caches of the last stamped blocks
 	uint8_t *scr; uint32_t scr_cap, scr_used;
@@ -115,6 +116,7 @@ struct Txn {
 	}
 	__host__ __device__ void stamp_res(uint32_t r, bool write)
 	{
+		if (mode == 3) { if (g.wmax[r] > tid) { BT_TRACE_VIOL("probe-read-after-higher-write", r, g.wmax[r], 0); violation(BT_NONE); } return; }
 		uint32_t old = bt_atomic_min(&g.lock[r], stamp);
 		if (old != stamp && (old >> 20) == (stamp >> 20)) { BT_TRACE_VIOL("lock", r, old, 0); violation(old & 0xFFFFFu); }   // two transactions of one round share r
 		if (mode == 1) { if (g.wmax[r] > tid) { BT_TRACE_VIOL("read-after-higher-write", r, g.wmax[r], 0); violation(BT_NONE); } return; }

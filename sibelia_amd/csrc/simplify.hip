@@ -70,9 +70,13 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 // writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
 __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r)
 {
-	unsigned old = atomicMin(&g.lock[r], stampv);
-	bool bad = old != stampv && (old >> 20) == (stampv >> 20);
-	unsigned other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
+	bool bad = false;
+	unsigned other = BT_NONE;
+	if (mode != 3) {                                              // 3 = probe: no writer is running, no exclusivity to establish
+		unsigned old = atomicMin(&g.lock[r], stampv);
+		bad = old != stampv && (old >> 20) == (stampv >> 20);
+		other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
+	}
 	if (mode == 2) atomicMax(&g.rmax[r], tid);
 	if (g.wmax[r] > tid) bad = true;
 	if (bad) atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
@@ -198,6 +202,33 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 			if (t.err & BT_ERR_SCRATCH) v = true;
 			g.need[id] = v ? 1 : 0;
 		}
+	}
+}
+
+// Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
+// without reservation (ss_probe); the others are flagged live and go through reserve / commit.
+__global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ VerdictTable vt;
+	__shared__ int ok;
+	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	if (wi >= nwin) return;
+	const unsigned id = g.win[wi], tid = id + 1;
+	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; ok = bt_setup(t, w, true) ? 1 : 0; }
+	__syncthreads();
+	if (ok) {
+		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+		__syncthreads();
+	}
+	int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
+	if (lane == 0) {
+		bool has = verdict > 0;
+		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
+		if (!has) { g.need[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }
+		live[wi] = has ? 1 : 0;
 	}
 }
 
@@ -369,10 +400,10 @@ __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsi
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
-__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims)
+__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
 	unsigned w = blockIdx.x, lane = threadIdx.x;
-	if (w >= nwin) return;
+	if (w >= nwin || !live[w]) return;
 	__shared__ unsigned seen[SEEN_SLOTS];
 	for (unsigned i = lane; i < SEEN_SLOTS; i += 64) seen[i] = BT_NONE;
 	__syncthreads();
@@ -528,7 +559,7 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
-__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims)
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -537,6 +568,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // FillVisit list + AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
+	if (!solo && !live[wi]) return;                                   // retired by the probe
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
 	if (!solo) {
 		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
@@ -552,22 +584,25 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		if (!owner) return;                                       // stays pending
 	}
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
-	// ---- read-only pass: exclusive block locks, nothing read may have been written by a higher id
-	if (lane == 0) { g.need[id] = 0; t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w, true) ? 1 : 0; }
-	__syncthreads();
-	if (flag) {
-		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
+	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
+	if (lane == 0) { g.need[id] = 0; flag = 1; }
+	if (solo) {
+		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
-	}
-	int verdict = flag ? wave_verdict(g, w, vt, lane) : 0;
-	if (lane == 0) {
-		bool has = verdict > 0;
-		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
-		if (t.err & BT_ERR_SCRATCH) { ss_mark_big(g, id); has = false; }
-		else atomicAdd(&g.ctr[CTR_COMMITTED], 1u);
-		flag = has ? 1 : 0;
+		if (flag) {
+			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
+			__syncthreads();
+		}
+		int verdict = flag ? wave_verdict(g, w, vt, lane) : 0;
+		if (lane == 0) {
+			bool has = verdict > 0;
+			if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+			if (t.err & BT_ERR_SCRATCH) { atomicOr(&g.ctr[CTR_ERR], BT_ERR_SCRATCH); has = false; }   // does not even fit the big arena
+			flag = has ? 1 : 0;
+		}
 	}
 	__syncthreads();
+	if (lane == 0) atomicAdd(&g.ctr[CTR_COMMITTED], 1u);
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
@@ -674,7 +709,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims;
+	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
@@ -690,9 +725,9 @@ struct DeviceBackend {
 	uint32_t window = 0, arena_bytes = 1u << 17, snap_arena_bytes = 1u << 17, snap_threads = 256 * 32;   // snap_threads = resident waves
 	uint32_t big_arena_bytes = 1u << 28;
 	size_t nres = 0;
-	hipEvent_t ev[6] = {};
-	bool timed_reserve = false, timed_commit = false;
-	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0;
+	hipEvent_t ev[8] = {};
+	bool timed_reserve = false, timed_commit = false, timed_probe = false;
+	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
 	uint32_t nid() { return nid_; }
 	void bind()
@@ -749,13 +784,13 @@ struct DeviceBackend {
 	void snapshot_all()
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
-		HIP_TRY(hipEventRecord(ev[4], c->stream));
+		HIP_TRY(hipEventRecord(ev[6], c->stream));
 		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
-		HIP_TRY(hipEventRecord(ev[5], c->stream));
+		HIP_TRY(hipEventRecord(ev[7], c->stream));
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		float ms = 0;
-		HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5]));
+		HIP_TRY(hipEventElapsedTime(&ms, ev[6], ev[7]));
 		snapshot_ms += ms;
 	}
 	void reset_round_state(bool stamps_too)
@@ -781,11 +816,20 @@ struct DeviceBackend {
 		read_ctr();
 		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
 	}
+	void probe(uint32_t nwin, uint32_t round)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		HIP_TRY(hipEventRecord(ev[4], c->stream));
+		k_probe<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
+		HIP_TRY(hipEventRecord(ev[5], c->stream));
+		timed_probe = true;
+		HIP_TRY(hipGetLastError());
+	}
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		HIP_TRY(hipEventRecord(ev[0], c->stream));
-		k_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>());
+		k_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[1], c->stream));
 		timed_reserve = true;
 		HIP_TRY(hipGetLastError());
@@ -796,9 +840,9 @@ struct DeviceBackend {
 		HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
-			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr);
+			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr);
 		} else
-			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>());
+			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[3], c->stream));
 		timed_commit = true;
 		HIP_TRY(hipGetLastError());
@@ -809,6 +853,7 @@ struct DeviceBackend {
 		float ms = 0;
 		if (timed_reserve) { HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); reserve_ms += ms; timed_reserve = false; }
 		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_ms += ms; timed_commit = false; }
+		if (timed_probe) { HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); probe_ms += ms; timed_probe = false; }
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
 		return r;
@@ -846,7 +891,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -956,7 +1001,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes));
 		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
 	}
-	uint32_t window = c->window ? c->window : 16384;
+	uint32_t window = c->window ? c->window : std::min<uint32_t>(16384, std::max<uint32_t>(1024, be.nid_ / 256));
 	window = std::min<uint32_t>(window, (1u << 20) - 1);
 	window = (uint32_t)std::min<size_t>(window, std::max<size_t>(64, (24ull << 30) / be.arena_bytes));
 	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
@@ -964,6 +1009,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	st->win.ensure((size_t)window * 4 + 16);
 	st->arena.ensure((size_t)window * be.arena_bytes);
 	st->claims.ensure((size_t)window * (CLAIM_CAP + 1) * 4);
+	st->live.ensure((size_t)window + 64);
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.bind();
 	be.g.k = k; be.g.D = D;
@@ -1019,7 +1065,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.enumerate_ms = ms_enum; c->stats.simplify_ms = ms_simp; c->stats.copyback_ms = ms_copy;
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
-	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms;
+	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
 	c->stats.executed = rep.executed;
 	for (auto &e : be.ev) (void)hipEventDestroy(e);
 	*bulges = rep.bulges;

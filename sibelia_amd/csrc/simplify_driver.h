@@ -29,7 +29,8 @@ struct SimplifyReport {
 //   void reset_round_state(bool stamps_too);         own/lock = 0xFFFFFFFF (and rmax/wmax = 0)
 //   void clear_counters();                           ctr[ERR, BULGES, VIOL, BIG, COMMITTED] reset (VIOL = NONE)
 //   void select(lo, limit, W, &nwin, &newlo, &solo); lowest pending ids in [lo, limit]
-//   void reserve(nwin, round); void commit(nwin, round, solo);
+//   void probe(nwin, round);                         retire window entries whose verdict is false now, flag the others
+//   void reserve(nwin, round); void commit(nwin, round, solo);   (flagged entries only)
 //   SimplifyCounters counters();                     device -> host
 //   bool grow(uint32_t err);                         enlarge element / node capacity after BT_ERR_*_CAP
 template <class Backend>
@@ -80,7 +81,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					if (++round > SS_ROUND_MAX) { be.reset_round_state(false); round = 1; }
 					rep.rounds++;
 					if (solo) rep.solo++;
-					else be.reserve(nwin, round);
+					else { be.probe(nwin, round); be.reserve(nwin, round); }
 					be.commit(nwin, round, solo != 0);
 					SimplifyCounters c = be.counters();
 					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",

@@ -44,6 +44,22 @@ __host__ __device__ inline void ss_mark_big(const GraphView &g, uint32_t id)
 	bt_atomic_add(&g.ctr[CTR_BIG], 1u);
 }
 
+// Probe of a pending id between rounds (no writer is running): ids whose AnyBulges verdict is false NOW are retired
+// without any reservation -- exactly like ids the snapshot found clean, they become pending again if a lower id later
+// rewrites something they can see.  Returns true when the id really has bulges (it then goes through reserve / commit).
+__host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
+{
+	uint32_t id = g.win[widx];
+	Txn t;
+	BulgeWork w;
+	t.init(g, id, widx, 3, arena, arena_bytes);
+	bool has = false;
+	if (bt_setup(t, w, true)) { bt_scan_all(t, w); bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+	if (t.err) return true;                    // undecidable here: let the commit path sort it out
+	if (!has) { g.need[id] = 0; bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u); }
+	return has;
+}
+
 // the transaction proper, for a window entry that owns its whole neighbourhood
 __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
 {

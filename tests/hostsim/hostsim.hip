@@ -91,12 +91,20 @@ struct HostBackend {
 	// like k_reserve / k_commit: the ids claimed at RESERVATION time are remembered and checked at commit time
 	std::vector<std::vector<uint32_t>> claims;
 	std::vector<uint32_t> dbg_bif0, dbg_bif1; uint32_t dbg_nn = 0;
+	std::vector<uint8_t> live;
+	void probe(uint32_t nwin, uint32_t round)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		live.assign(nwin, 0);
+		for (uint32_t w : order(nwin)) live[w] = ss_probe(g, w, arena.data(), arena_bytes) ? 1 : 0;
+	}
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		claims.assign(nwin, {});
 		if (getenv("HOSTSIM_DEBUG")) { dbg_bif0 = bif[0]; dbg_bif1 = bif[1]; dbg_nn = ctr[CTR_NN]; }
 		for (uint32_t w : order(nwin)) {
+			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
 			bt_footprint(g, win[w], [&](uint32_t b) { bt_atomic_min(&g.own[b], st); claims[w].push_back(b); });
 		}
@@ -106,6 +114,7 @@ struct HostBackend {
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		if (solo) { ss_commit_run(g, 0, big_arena.data(), big_arena_bytes); return; }
 		for (uint32_t w : order(nwin)) {
+			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
 			bool owner = true;
 			for (uint32_t b : claims[w]) if (own[b] != st) { owner = false; break; }
