@@ -168,7 +168,7 @@ __device__ __forceinline__ void tile_walk(const KmerTile &t, size_t tile, unsign
 static __global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const unsigned long long *__restrict__ pk,
                                                                  const unsigned *__restrict__ sp, size_t nwords, size_t nelem,
                                                                  unsigned k, KmerSlot *__restrict__ table, unsigned long long capmask,
-                                                                 size_t ntiles)
+                                                                 size_t ntiles, unsigned *__restrict__ used_count, unsigned *__restrict__ used_slots)
 {
 	__shared__ KmerTile t;
 	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -184,6 +184,7 @@ static __global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const un
 			unsigned long long h = kmer_hash(canon) & capmask;
 			for (;;) {
 				unsigned long long old = atomicCAS(&table[h].key, SBL_EMPTY_KEY, canon);
+				if (old == SBL_EMPTY_KEY) used_slots[atomicAdd(used_count, 1u)] = (unsigned)h;      // list of claimed slots: classification never scans the sparse table
 				if (old == SBL_EMPTY_KEY || old == canon) { atomicOr(&table[h].mask, m); break; }
 				h = (h + 1) & capmask;
 			}
@@ -202,15 +203,14 @@ static __global__ void __launch_bounds__(256) k_table_init(KmerSlot *__restrict_
 // K3: classify table slots, compact the bifurcation slots and emit their sort keys
 // (the canonical code and, unless palindromic, its reverse complement).
 // keyinfo payload = 2 * pairIndex + orientation (0 = canonical code, 1 = reverse complement).
-static __global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ table, size_t cap, unsigned k,
-                                                        unsigned *__restrict__ counters /* [0]=pairs [1]=keys [2]=used slots */,
+static __global__ void __launch_bounds__(256) k_classify_slots(KmerSlot *__restrict__ table, const unsigned *__restrict__ used_slots, unsigned nused, unsigned k,
+                                                        unsigned *__restrict__ counters /* [0]=pairs [1]=keys */,
                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ payload,
                                                         unsigned maxpairs)
 {
-	for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (size_t)gridDim.x * blockDim.x) {
+	for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < nused; u += (size_t)gridDim.x * blockDim.x) {
+		size_t s = used_slots[u];
 		KmerSlot sl = table[s];
-		if (sl.key == SBL_EMPTY_KEY) continue;
-		atomicAdd(&counters[2], 1u);
 		unsigned aux = SBL_NONE;
 		if (mask_is_bifurcation(sl.mask)) {
 			unsigned long long r = rc_code(sl.key, k);

@@ -120,9 +120,11 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	c->cur_k = k;
 	sbl_pack(c);
 
-	// table capacity: power of two >= 2 x number of base positions (an upper bound of the distinct canonical k-mers)
+	// table capacity: power of two >= 1.5 x number of base positions (an upper bound of the distinct canonical k-mers)
 	size_t cap = 1024;
-	while (cap < 2 * E) cap <<= 1;
+	while (cap < E + E / 2) cap <<= 1;
+	SBL_CHECK(cap <= 0xFFFFFFFFull, SBL_ERR_TOO_LARGE, "k-mer table too large for 32-bit slot indices");
+	c->d_usedslots.ensure(E * 4 + 64);
 	c->d_table.ensure(cap * sizeof(KmerSlot));
 	c->table_cap = cap;
 	c->d_counters.ensure(64 * 4);
@@ -132,13 +134,17 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 8);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
 	k_kmer_table_build<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, ntiles);
+	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, ntiles,
+	                                               c->d_counters.as<unsigned>() + 8, c->d_usedslots.as<unsigned>());
 	HIP_TRY(hipEventRecord(c->ev[1], s));
 	HIP_TRY(hipGetLastError());
 
-	// classify: first count, then emit keys into exactly sized buffers
-	unsigned cgrid = (unsigned)std::min<size_t>((cap + 255) / 256, 256 * 16);
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap, k, c->d_counters.as<unsigned>(), nullptr, nullptr, 0);
+	// classify the claimed slots: first count, then emit keys into exactly sized buffers
+	unsigned nused = 0;
+	HIP_TRY(hipMemcpyAsync(&nused, c->d_counters.as<unsigned>() + 8, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned cgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)nused + 255) / 256, 256 * 16));
+	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(), nullptr, nullptr, 0);
 	unsigned cnt[4];
 	HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
@@ -146,8 +152,8 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	c->d_keys.ensure((size_t)nkeys * 8 + 16); c->d_payload.ensure((size_t)nkeys * 4 + 16);
 	c->d_skeys.ensure((size_t)nkeys * 8 + 16); c->d_spayload.ensure((size_t)nkeys * 4 + 16);
 	c->d_pairids.ensure((size_t)npairs * 8 + 16);
-	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap, k, c->d_counters.as<unsigned>(),
+	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 8 * 4, s));
+	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(),
 	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), npairs);
 	if (nkeys) {
 		device_sort_pairs(c, c->d_keys.as<unsigned long long>(), c->d_skeys.as<unsigned long long>(),
@@ -247,7 +253,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_simplify_free(c);
 	DevBuf *bufs[] = { &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);

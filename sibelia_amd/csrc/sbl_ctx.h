@@ -37,6 +37,7 @@ struct sbl_ctx {
 	// ---- enumeration workspace
 	DevBuf d_pk, d_sp;                   // packed bases / separator bits
 	DevBuf d_table;                      // KmerSlot[cap]
+	DevBuf d_usedslots;                  // uint32 [positions]: slots claimed by the table build, in claim order
 	size_t table_cap = 0;
 	DevBuf d_counters;                   // small uint32 scratch block
 	DevBuf d_keys, d_payload, d_skeys, d_spayload, d_pairids, d_sorttmp;

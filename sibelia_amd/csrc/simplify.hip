@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
+	if (g.need[id] == 2) { if (lane == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
 	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; ok = bt_setup(t, w, true) ? 1 : 0; }
 	__syncthreads();
 	if (ok) {
@@ -228,6 +229,7 @@ __global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
 		if (!has) { g.need[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }
+		else if (!t.err) g.need[id] = 2;
 		live[wi] = has ? 1 : 0;
 	}
 }
@@ -1001,7 +1003,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes));
 		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
 	}
-	uint32_t window = c->window ? c->window : std::min<uint32_t>(16384, std::max<uint32_t>(1024, be.nid_ / 256));
+	uint32_t window = c->window ? c->window : std::min<uint32_t>(16384, std::max<uint32_t>(2048, be.nid_ / 64));
 	window = std::min<uint32_t>(window, (1u << 20) - 1);
 	window = (uint32_t)std::min<size_t>(window, std::max<size_t>(64, (24ull << 30) / be.arena_bytes));
 	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
