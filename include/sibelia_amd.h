@@ -68,6 +68,7 @@ typedef struct {
 	double snapshot_ms, reserve_ms, commit_ms;   /* SimplifyGraph kernel time by phase */
 	double probe_ms;
 	uint64_t executed;               /* pending ids examined in ordered rounds (retired by the probe or committed) */
+	uint64_t transactions;           /* ... of which RemoveBulges transactions that owned their neighbourhood and ran */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -26,7 +26,7 @@
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
-       CTR_BIG = 8, CTR_PUSHED = 9, CTR_COUNT = 16 };
+       CTR_BIG = 8, CTR_PUSHED = 9, CTR_TXN = 10, CTR_COUNT = 16 };
 enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
 
 struct GraphView {
@@ -446,6 +446,30 @@ __host__ __device__ inline bool bt_overlap_sets(Txn &t, BulgeWork &w, uint32_t i
 		if (lo < n && w.occ[lo] == e) return true;
 	}
 	return false;
+}
+// do the first ni steps of window i and the first nj steps of window j share an element?  (-1: too many breaks to tell)
+__host__ __device__ inline int bt_windows_intersect(const BulgeWork &w, uint32_t i, uint32_t ni, uint32_t j, uint32_t nj)
+{
+	if (w.wnb[i] > BT_MAX_BREAKS || w.wnb[j] > BT_MAX_BREAKS) return -1;
+	if (!ni || !nj) return 0;
+	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
+	const uint32_t *bi = w.wbk + i * BT_MAX_BREAKS, *bj = w.wbk + j * BT_MAX_BREAKS;
+	uint32_t xi = 0;
+	for (uint32_t s0 = 0; s0 < ni;) {
+		while (xi < w.wnb[i] && bi[xi] <= s0) xi++;
+		uint32_t s1 = xi < w.wnb[i] && bi[xi] < ni ? bi[xi] : ni;
+		uint32_t a0 = ei[s0], a1 = ei[s1 - 1], alo = a0 < a1 ? a0 : a1, ahi = a0 < a1 ? a1 : a0;
+		uint32_t xj = 0;
+		for (uint32_t r0 = 0; r0 < nj;) {
+			while (xj < w.wnb[j] && bj[xj] <= r0) xj++;
+			uint32_t r1 = xj < w.wnb[j] && bj[xj] < nj ? bj[xj] : nj;
+			uint32_t b0 = ej[r0], b1 = ej[r1 - 1], blo = b0 < b1 ? b0 : b1, bhi = b0 < b1 ? b1 : b0;
+			if (alo <= bhi && blo <= ahi) return 1;
+			r0 = r1;
+		}
+		s0 = s1;
+	}
+	return 0;
 }
 __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
 {

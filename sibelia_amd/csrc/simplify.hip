@@ -88,43 +88,62 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 	const size_t base = (size_t)i * w.ws;
 	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
 	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws, nm = 0, nb = 0, lastc = 0;
-	while (done < ws && cur != BT_NONE) {
+	bool finished = false;
+	while (done < ws && cur != BT_NONE && !finished) {
 		if (!w.lite && done && cur != (dir ? lastc - 1 : lastc + 1)) {      // the walk leaves consecutive slots here
 			if (lane == 0 && nb < BT_MAX_BREAKS) w.wbk[i * BT_MAX_BREAKS + nb] = done;
 			nb++;
 		}
-		bool inr = done + lane < ws && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
-		unsigned c = dir ? cur - lane : cur + lane;
-		unsigned plink = inr && lane ? (dir ? g.pv[c + 1] : g.nx[c - 1]) : c;   // speculative loads, one round trip per 64 elements
-		unsigned chv = inr ? g.ch[c] : 0u;
-		unsigned bvl = inr ? g.bif[dir][c] : BT_NONE;
-		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
-		unsigned long long ml = __ballot(inr && plink == c);
-		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-		bool mine = lane < pre;
-		unsigned long long ms = __ballot(mine && chv == BT_SEP);
-		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
-		bool st = mine && lane <= stop;                               // the separator step itself is cached too
-		unsigned bv = st ? bvl : BT_NONE;
-		if (st) {
-			if (!w.lite) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv; w.wbf[base + done + lane] = bv; }
-			if (done + lane == 0) w.wst[i] = bv;
-			if (done + lane == g.k) w.wck[i] = dir ? bt_comp((char)chv) : (char)chv;
+		// Burst: the loads of up to SCAN_BURST x 64 consecutive slots are issued together, assuming the list is laid out
+		// consecutively there (it almost always is); blocks are then consumed in order and the burst is abandoned at the
+		// first link break or separator.  One memory round trip per window instead of one per 64 elements.
+		enum { SCAN_BURST = 3 };
+		unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST];
+		bool inr[SCAN_BURST];
+#pragma unroll
+		for (int u = 0; u < SCAN_BURST; u++) {
+			unsigned off = lane + 64u * u;
+			inr[u] = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
+			cc[u] = dir ? cur - off : cur + off;
+			plink[u] = inr[u] && off ? (dir ? g.pv[cc[u] + 1] : g.nx[cc[u] - 1]) : cc[u];
+			chv[u] = inr[u] ? g.ch[cc[u]] : 0u;
+			bvl[u] = inr[u] ? g.bif[dir][cc[u]] : BT_NONE;
+			lnk[u] = inr[u] ? (dir ? g.pv[cc[u]] : g.nx[cc[u]]) : BT_NONE;
 		}
-		{	// compact list of the marked steps (>= 1, before the separator), in step order
-			bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
-			unsigned long long mm = __ballot(marked);
-			if (marked) w.wmk[base + nm + __popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)(done + lane) << 32) | bv;
-			nm += __popcll(mm);
+		const unsigned burst_done = done;
+#pragma unroll
+		for (int u = 0; u < SCAN_BURST; u++) {
+			if (burst_done + 64u * u >= ws) break;
+			const unsigned c = cc[u];
+			unsigned long long ml = __ballot(inr[u] && plink[u] == c);
+			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+			if (pre == 0) { cur = BT_NONE; finished = true; break; }     // cannot happen for u = 0; for u > 0 handled by the re-anchor below
+			bool mine = lane < pre;
+			unsigned long long ms = __ballot(mine && chv[u] == BT_SEP);
+			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			bool st = mine && lane <= stop;                               // the separator step itself is cached too
+			unsigned bv = st ? bvl[u] : BT_NONE;
+			if (st) {
+				if (!w.lite) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv[u]; w.wbf[base + done + lane] = bv; }
+				if (done + lane == 0) w.wst[i] = bv;
+				if (done + lane == g.k) w.wck[i] = dir ? bt_comp((char)chv[u]) : (char)chv[u];
+			}
+			{	// compact list of the marked steps (>= 1, before the separator), in step order
+				bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
+				unsigned long long mm = __ballot(marked);
+				if (marked) w.wmk[base + nm + __popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)(done + lane) << 32) | bv;
+				nm += __popcll(mm);
+			}
+			if (mode) {
+				unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
+				if (st && chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
+			}
+			if (stop < pre) { wl = done + stop; finished = true; break; }
+			cur = __shfl(lnk[u], pre - 1);
+			lastc = __shfl(c, pre - 1);
+			done += pre;
+			if (pre < 64 || cur != (dir ? lastc - 1 : lastc + 1)) break;      // link break: re-anchor with a fresh burst
 		}
-		if (mode) {
-			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
-			if (st && chv != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
-		}
-		if (stop < pre) { wl = done + stop; break; }
-		cur = __shfl(lnk, pre - 1);
-		lastc = __shfl(c, pre - 1);
-		done += pre;
 	}
 	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; }
 }
@@ -604,7 +623,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		}
 	}
 	__syncthreads();
-	if (lane == 0) atomicAdd(&g.ctr[CTR_COMMITTED], 1u);
+	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
@@ -618,11 +637,29 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
 			__syncthreads();
 			if (!flag) break;
+			// which cached windows see the region about to be rewritten (target start .. end of its look-forward flank)?
+			// only those are rescanned afterwards -- normally just the target's own window
+			unsigned long long dirty[4] = {0, 0, 0, 0};
+			const bool selective = w.n <= 256;
+			if (selective) {
+				const unsigned tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
+				for (unsigned i0 = 0; i0 < w.n; i0 += 64) {
+					unsigned i = i0 + lane;
+					bool d = false;
+					if (i < w.n) {
+						unsigned len = w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws;       // cached steps incl. the separator step
+						unsigned tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
+						d = i == tg || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0;
+					}
+					dirty[i0 >> 6] = __ballot(d);
+				}
+			}
 			wave_collapse(g, t, w, lane, stampv);
 			if (t.err) break;
 			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
 			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
-			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+			for (unsigned i = 0; i < w.n; i++)
+				if (!selective || ((dirty[i >> 6] >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			__syncthreads();
 		}
 	}
@@ -1068,7 +1105,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
-	c->stats.executed = rep.executed;
+	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions;
 	for (auto &e : be.ev) (void)hipEventDestroy(e);
 	*bulges = rep.bulges;
 }

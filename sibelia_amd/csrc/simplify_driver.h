@@ -19,7 +19,7 @@ struct SimplifyCounters {
 struct SimplifyReport {
 	uint64_t bulges = 0;
 	uint32_t iterations = 0, rounds = 0, replays = 0, solo = 0, grow_replays = 0;
-	uint64_t executed = 0;
+	uint64_t executed = 0, transactions = 0;
 };
 
 // Backend concept:
@@ -100,6 +100,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					SimplifyCounters c = be.counters();
 					iter_bulges = c.v[CTR_BULGES];
 					rep.executed += c.v[CTR_COMMITTED];
+					rep.transactions += c.v[CTR_TXN];
 					break;
 				}
 				rep.replays++;

@@ -72,6 +72,7 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	if (bt_setup(t, w)) { bt_scan_all(t, w); bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 	if (t.err & BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }   // nothing written yet: big-arena path
 	bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u);
+	bt_atomic_add(&g.ctr[CTR_TXN], 1u);
 	if (!has) return;
 	t.init(g, id, widx, 2, arena, arena_bytes);                   // writer pass: publish reads and writes
 	w.ret = 0;

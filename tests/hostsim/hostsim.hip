@@ -65,7 +65,7 @@ struct HostBackend {
 	}
 	void clear_counters()
 	{
-		ctr[CTR_ERR] = 0; ctr[CTR_BULGES] = 0; ctr[CTR_VIOL] = BT_NONE; ctr[CTR_BIG] = 0; ctr[CTR_COMMITTED] = 0;
+		ctr[CTR_ERR] = 0; ctr[CTR_BULGES] = 0; ctr[CTR_VIOL] = BT_NONE; ctr[CTR_BIG] = 0; ctr[CTR_COMMITTED] = 0; ctr[CTR_TXN] = 0;
 	}
 	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
 	{
