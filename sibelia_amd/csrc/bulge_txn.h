@@ -352,12 +352,12 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.n = n;
 	if (n < 2) return false;
 	w.ws = D + k + 2;
-	w.start = (uint32_t *)t.alloc(n * 4);
-	w.endc = (char *)t.alloc(n);
-	w.wlen = (uint32_t *)t.alloc(n * 4);
-	w.wmn = (uint32_t *)t.alloc(n * 4);
-	w.wst = (uint32_t *)t.alloc(n * 4);
-	w.wck = (char *)t.alloc(n);
+	w.start = (uint32_t *)t.alloc2(n * 4);          // small per-instance arrays: fast scratch (LDS) when there is one
+	w.endc = (char *)t.alloc2(n);
+	w.wlen = (uint32_t *)t.alloc2(n * 4);
+	w.wmn = (uint32_t *)t.alloc2(n * 4);
+	w.wst = (uint32_t *)t.alloc2(n * 4);
+	w.wck = (char *)t.alloc2(n);
 	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
 	w.lite = lite;
 	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;

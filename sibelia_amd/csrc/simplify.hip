@@ -204,11 +204,12 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int ok;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];       // per-instance window summaries of typical ids
 	const unsigned lane = threadIdx.x;
 	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
 	for (unsigned id = blockIdx.x; id < g.nid; id += gridDim.x) {
 		__syncthreads();
-		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); ok = bt_setup(t, w, true) ? 1 : 0; }
+		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
 		if (ok) {
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
@@ -232,11 +233,12 @@ __global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int ok;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (lane == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
-	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; ok = bt_setup(t, w, true) ? 1 : 0; }
+	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 	__syncthreads();
 	if (ok) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
