@@ -119,6 +119,14 @@ def main():
         dom = max(per, key=lambda kk: per[kk])
         dur_ms = per[dom] / launches[dom]
         achieved = alg[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        # HBM traffic of that kernel per launch from the last committed PMC passes (tools/profile_summary.py), same workload only
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc) and (a.strains, a.L0, a.k, a.D, a.iters) == (8, 4_600_000, 25, 150, 4):
+            try:
+                traffic = json.load(open(pmc))["kernels"][dom]["hbm_bytes_per_launch_est"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "k-mers/sec in BlockFinder graph-build+simplify, 8xE.coli k=25",
             "value": Ntot / (dt / a.steps), "unit": "strand-k-mers/s",
@@ -132,7 +140,7 @@ def main():
                        "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"]},
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg[dom],
                          "all_kernels_ms_per_step": per},
         }
