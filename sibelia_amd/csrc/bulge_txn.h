@@ -562,7 +562,7 @@ __host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t d
 // every id whose forward window can see the rewritten region must be re-examined at its turn
 __host__ __device__ inline void bt_push_neighbourhood(Txn &t, SIt tstart, uint32_t newlen)
 {
-	uint32_t reach = t.g.D + t.g.k, k = t.g.k;
+	uint32_t reach = t.g.D + t.g.k + 2, k = t.g.k;   // windows are scanned (and stamped) over D + k + 2 steps
 	// backwards from the target instance (opposite to its direction), then forwards across the region and beyond
 	SIt a = tstart;
 	a.d ^= 1;
@@ -778,7 +778,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 template <class F>
 __host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F f)
 {
-	uint32_t back = g.D + g.k, fwd = 2 * (g.D + g.k) + g.k;
+	uint32_t back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k;     // + 2: the scanned window length is D + k + 2
 	f(id);
 	for (uint32_t s = 0; s < 2; s++)
 		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {

@@ -78,8 +78,12 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 		other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
 	}
 	if (mode == 2) atomicMax(&g.rmax[r], tid);
-	if (g.wmax[r] > tid) bad = true;
-	if (bad) atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+	unsigned wm = g.wmax[r];
+	if (wm > tid) bad = true;
+	if (bad) {
+		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+		if (atomicCAS(&g.ctr[11], 0u, other != BT_NONE ? 1u : 2u) == 0u) { g.ctr[12] = r; g.ctr[13] = other != BT_NONE ? other : wm - 1; g.ctr[14] = id; g.ctr[15] = mode; }
+	}
 }
 
 __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
@@ -401,7 +405,11 @@ __device__ __forceinline__ void wave_stamp_writes(const GraphView &g, unsigned i
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 		if (mine && lane < stop) {
 			unsigned a = atomicMax(&g.wmax[c], tid);
-			if (a > tid || g.rmax[c] > tid) atomicMin(&g.ctr[CTR_VIOL], id);
+			unsigned rm = g.rmax[c];
+			if (a > tid || rm > tid) {
+				atomicMin(&g.ctr[CTR_VIOL], id);
+				if (atomicCAS(&g.ctr[11], 0u, 4u) == 0u) { g.ctr[12] = c; g.ctr[13] = (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
+			}
 		}
 		if (stop < pre) break;
 		unsigned lnk = mine ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
@@ -413,7 +421,7 @@ __device__ __forceinline__ void wave_stamp_writes(const GraphView &g, unsigned i
 // bt_push_neighbourhood with 64 lanes: every id marked around a rewritten region and still ahead in the order becomes pending
 __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
 {
-	unsigned reach = g.D + g.k;
+	unsigned reach = g.D + g.k + 2;
 	auto push = [&](unsigned b0, unsigned b1) {
 		if (b0 != BT_NONE && b0 > id && b0 < g.nid) g.need[b0] = 1;
 		if (b1 != BT_NONE && b1 > id && b1 < g.nid) g.need[b1] = 1;
@@ -433,7 +441,7 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 	unsigned id = g.win[w], st = g.round_bits | w;
 	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0; cl.seen = seen;
 	wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
-	unsigned back = g.D + g.k, fwd = 2 * (g.D + g.k) + g.k;
+	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k;
 	for (unsigned s = 0; s < 2; s++)
 		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
 			if (g.ndead[nd]) continue;
@@ -456,8 +464,12 @@ __device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned
 	bool bad = old != stampv && (old >> 20) == (stampv >> 20);
 	unsigned other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
 	unsigned a = atomicMax(&g.wmax[r], tid);
-	if (a > tid || g.rmax[r] > tid) bad = true;
-	if (bad) atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+	unsigned rm = g.rmax[r];
+	if (a > tid || rm > tid) bad = true;
+	if (bad) {
+		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
+		if (atomicCAS(&g.ctr[11], 0u, 3u) == 0u) { g.ctr[12] = r; g.ctr[13] = other != BT_NONE ? other : (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (other != BT_NONE ? 4u : 0u); }
+	}
 }
 // ErasePoint (bifurcationstorage.cpp:144-155) for one (strand, element) per lane; the lazy-erase chain head lives in LDS
 __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned strand, unsigned e, unsigned stampv)

@@ -47,9 +47,11 @@ def gen_strains(L0: int = 4_600_000, n: int = 8, seed: int = 1, snp: float = 0.0
                 p = min(L0, q + int(rng.integers(1, 21)))
         pieces.append(g[p:])
         g = np.concatenate(pieces)
+        imax = inv_max if inv_max < len(g) // 2 else max(2, len(g) // 8)      # short genomes: scaled-down inversions
+        imin = inv_min if inv_min < imax else max(1, imax // 4)
         for _ in range(inversions):
-            a = int(rng.integers(0, len(g) - inv_max))
-            b = a + int(rng.integers(inv_min, inv_max))
+            a = int(rng.integers(0, len(g) - imax))
+            b = a + int(rng.integers(imin, imax))
             g[a:b] = _COMP[g[a:b][::-1]]
         out.append(_ACGT[g].tobytes())
     return out
