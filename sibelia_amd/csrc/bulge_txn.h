@@ -144,8 +144,18 @@ struct Txn {
 		if (b == last_w) return;
 		last_w = b; stamp_res(b, true);
 	}
-	__host__ __device__ __forceinline__ void ir(uint32_t b) { if (mode) stamp_res(g.nblk + b, false); }   // id (list / count) read
-	__host__ __device__ __forceinline__ void iw(uint32_t b) { if (mode) stamp_res(g.nblk + b, true); }
+	// Id resources in the wave kernels (ext_stamps): the transaction OWNS every id it may touch (its claims), so exclusivity
+	// inside the round is checked against own[] with a plain load instead of a returning atomic on lock[].
+	__host__ __device__ void stamp_id_light(uint32_t b, bool write)
+	{
+		uint32_t r = g.nblk + b;
+		uint32_t ow = g.own[b], wm = g.wmax[r], rm = write ? g.rmax[r] : 0u;
+		if (mode != 3 && ow != stamp) violation(BT_NONE);                      // escaped its reservation
+		if (wm > tid || rm > tid) violation(BT_NONE);
+		if (mode == 2) { if (write) bt_atomic_max(&g.wmax[r], tid); else bt_atomic_max(&g.rmax[r], tid); }
+	}
+	__host__ __device__ __forceinline__ void ir(uint32_t b) { if (!mode) return; if (ext_stamps) stamp_id_light(b, false); else stamp_res(g.nblk + b, false); }   // id (list / count) read
+	__host__ __device__ __forceinline__ void iw(uint32_t b) { if (!mode) return; if (ext_stamps) stamp_id_light(b, true); else stamp_res(g.nblk + b, true); }
 
 	// ---- iterator primitives
 	__host__ __device__ __forceinline__ SIt next(SIt a) { tr(a.e); a.e = a.d ? g.pv[a.e] : g.nx[a.e]; return a; }     // operator++ :117-130
@@ -173,6 +183,17 @@ struct Txn {
 		g.lsize[a.d][b]++;
 		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
 		push_dirty(b);
+	}
+	// AddPoint with the node already allocated and the id already stamped by the caller (wave-wide collapse)
+	__host__ __device__ bool add_point_prepared(SIt a, uint32_t b, uint32_t nd)
+	{
+		if (g.bif[a.d][a.e] != BT_NONE || b == BT_NONE) return false;
+		g.nslot[nd] = a.e; g.ndead[nd] = 0; g.nidst[nd] = (b << 1) | a.d;
+		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
+		g.lsize[a.d][b]++;
+		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
+		push_dirty(b);
+		return true;
 	}
 	// ErasePoint, bifurcationstorage.cpp:144-155 (physical removal deferred to cleanup())
 	__host__ __device__ void erase_point(SIt a)

@@ -460,15 +460,12 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 __device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned stampv, unsigned tid, unsigned id, unsigned b)
 {
 	unsigned r = g.nblk + b;
-	unsigned old = atomicMin(&g.lock[r], stampv);
-	bool bad = old != stampv && (old >> 20) == (stampv >> 20);
-	unsigned other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
-	unsigned a = atomicMax(&g.wmax[r], tid);
-	unsigned rm = g.rmax[r];
-	if (a > tid || rm > tid) bad = true;
+	unsigned ow = g.own[b], wm = g.wmax[r], rm = g.rmax[r];
+	bool bad = ow != stampv || wm > tid || rm > tid;          // not in its claims (escaped the reservation), or a higher id was here first
+	atomicMax(&g.wmax[r], tid);
 	if (bad) {
-		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
-		if (atomicCAS(&g.ctr[11], 0u, 3u) == 0u) { g.ctr[12] = r; g.ctr[13] = other != BT_NONE ? other : (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (other != BT_NONE ? 4u : 0u); }
+		atomicMin(&g.ctr[CTR_VIOL], id);
+		if (atomicCAS(&g.ctr[11], 0u, 3u) == 0u) { g.ctr[12] = r; g.ctr[13] = (wm > rm ? wm : rm) - 1; g.ctr[14] = id; g.ctr[15] = (wm > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (ow != stampv ? 4u : 0u); }
 	}
 }
 // ErasePoint (bifurcationstorage.cpp:144-155) for one (strand, element) per lane; the lazy-erase chain head lives in LDS
@@ -577,24 +574,44 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		nact += __popcll(m1) + __popcll(m2);
 	}
 	__syncthreads();
+	// nodes for every AddPoint below in one allocation; the ids they touch are stamped by all lanes at once
+	__shared__ unsigned s_nodebase;
+	const unsigned total = nlb + nlf + nact;
 	if (lane == 0) {
+		unsigned base = total ? atomicAdd(&g.ctr[CTR_NN], total) : 0u;
+		if (total && base + total > g.cap_n) t.err |= BT_ERR_NODE_CAP;
+		s_nodebase = base;
+	}
+	if (t.mode)
+		for (unsigned x = lane; x < total; x += 64) {
+			unsigned b = x < nlb ? w.lb[2 * x + 1] : x < nlb + nlf ? w.lf[2 * (x - nlb) + 1] : w.act[3 * (x - nlb - nlf) + 2];
+			wave_stamp_id_write(g, stampv, t.tid, t.id, b);
+		}
+	__syncthreads();
+	if (t.err) return;
+	if (lane == 0) {
+		unsigned nd = s_nodebase;
 		// first loop: restore the flanks (merge of the two index-sorted lists, look-back before look-forward at equal index)
 		unsigned a = 0, b = 0;
 		while (a < nlb || b < nlf) {
 			bool takeA = b >= nlf || (a < nlb && w.lb[2 * a] <= w.lf[2 * b]);
 			SIt p;
-			if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point(p, w.lb[2 * a + 1]); a++; }
-			else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point(p, w.lf[2 * b + 1]); b++; }
+			if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point_prepared(p, w.lb[2 * a + 1], nd++); a++; }
+			else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point_prepared(p, w.lf[2 * b + 1], nd++); b++; }
 		}
-		for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point(p, w.act[3 * x + 2]); }
+		for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
 		t.push_e = T[0]; t.push_d = d; t.push_len = dS;
 	}
 	__syncthreads();
 }
 
+__device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
+#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull
+#define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
+
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
-__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live)
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -619,6 +636,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		if (!owner) return;                                       // stays pending
 	}
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
+	PH_T0();
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
 	if (lane == 0) { g.need[id] = 0; flag = 1; }
 	if (solo) {
@@ -642,14 +660,18 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
 	__syncthreads();
+	PH_ADD(0);
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 		__syncthreads();
+		PH_ADD(1);
 		if (lane == 0) flag = bt_rb_begin(t, w) && !t.err ? 1 : 0;
 		__syncthreads();
+		PH_ADD(2);
 		while (flag) {
 			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
 			__syncthreads();
+			PH_ADD(3);
 			if (!flag) break;
 			// which cached windows see the region about to be rewritten (target start .. end of its look-forward flank)?
 			// only those are rescanned afterwards -- normally just the target's own window
@@ -668,13 +690,18 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 					dirty[i0 >> 6] = __ballot(d);
 				}
 			}
+			PH_ADD(4);
 			wave_collapse(g, t, w, lane, stampv);
+			PH_ADD(5);
 			if (t.err) break;
 			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
+			PH_ADD(6);
 			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
+			PH_ADD(7);
 			for (unsigned i = 0; i < w.n; i++)
 				if (!selective || ((dirty[i >> 6] >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			__syncthreads();
+			PH_ADD(8);
 		}
 	}
 	if (lane == 0) {
@@ -780,6 +807,7 @@ struct DeviceBackend {
 	size_t nres = 0;
 	hipEvent_t ev[8] = {};
 	bool timed_reserve = false, timed_commit = false, timed_probe = false;
+	int prof = 0;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
 	uint32_t nid() { return nid_; }
@@ -878,6 +906,7 @@ struct DeviceBackend {
 		timed_probe = true;
 		HIP_TRY(hipGetLastError());
 	}
+	void mark_live(uint32_t nwin) { HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
@@ -893,9 +922,9 @@ struct DeviceBackend {
 		HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
-			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr);
+			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr, prof);
 		} else
-			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>());
+			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
 		HIP_TRY(hipEventRecord(ev[3], c->stream));
 		timed_commit = true;
 		HIP_TRY(hipGetLastError());
@@ -1064,6 +1093,8 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	st->claims.ensure((size_t)window * (CLAIM_CAP + 1) * 4);
 	st->live.ensure((size_t)window + 64);
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
+	be.prof = getenv("SBL_PHASES") ? 1 : 0;
+	if (be.prof) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z)); }
 	be.bind();
 	be.g.k = k; be.g.D = D;
 	HIP_TRY(hipEventRecord(c->ev[3], s));
@@ -1121,5 +1152,11 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions;
 	for (auto &e : be.ev) (void)hipEventDestroy(e);
+	if (be.prof) {
+		unsigned long long z[16];
+		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
+		const char *nm[9] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "stamp_writes", "push", "rescan"};
+		for (int i = 0; i < 9; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
+	}
 	*bulges = rep.bulges;
 }

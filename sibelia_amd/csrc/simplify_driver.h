@@ -30,6 +30,7 @@ struct SimplifyReport {
 //   void clear_counters();                           ctr[ERR, BULGES, VIOL, BIG, COMMITTED] reset (VIOL = NONE)
 //   void select(lo, limit, W, &nwin, &newlo, &solo); lowest pending ids in [lo, limit]
 //   void probe(nwin, round);                         retire window entries whose verdict is false now, flag the others
+//   void mark_live(nwin);                            flag every window entry live (solo rounds skip the probe)
 //   void reserve(nwin, round); void commit(nwin, round, solo);   (flagged entries only)
 //   SimplifyCounters counters();                     device -> host
 //   bool grow(uint32_t err);                         enlarge element / node capacity after BT_ERR_*_CAP
@@ -80,8 +81,9 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					lo = newlo;
 					if (++round > SS_ROUND_MAX) { be.reset_round_state(false); round = 1; }
 					rep.rounds++;
-					if (solo) rep.solo++;
-					else { be.probe(nwin, round); be.reserve(nwin, round); }
+					if (solo) { rep.solo++; be.mark_live(nwin); }       // a big id runs alone but still claims its neighbourhood
+					else be.probe(nwin, round);
+					be.reserve(nwin, round);
 					be.commit(nwin, round, solo != 0);
 					SimplifyCounters c = be.counters();
 					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",

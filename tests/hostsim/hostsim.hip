@@ -98,6 +98,7 @@ struct HostBackend {
 		live.assign(nwin, 0);
 		for (uint32_t w : order(nwin)) live[w] = ss_probe(g, w, arena.data(), arena_bytes) ? 1 : 0;
 	}
+	void mark_live(uint32_t nwin) { live.assign(nwin, 1); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;

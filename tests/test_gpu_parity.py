@@ -86,3 +86,48 @@ def test_errors_cross_the_abi_as_codes():
     bf = _bf([b"ACGTACGTAC"])
     with pytest.raises(SibeliaError):
         bf.enumerate(1)                                          # k < 2 is rejected (reference src/util.cpp:38-41)
+
+
+def test_fine_cascade_on_8_strains_matches_oracle():
+    # config 3 shape (8 strains, -s fine: (30,150)(100,500)(500,1500)) at reduced genome length; k > 32 uses the rank-doubling path
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=120_000, n=8, seed=33, inv_min=3000, inv_max=12000)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    for k, d in ((30, 150), (100, 500), (500, 1500)):
+        assert bf.simplify_stage(k, d, 4) == orc.simplify_stage(k, d, 4)
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    a, b = bf.enumerate(500), orc.enumerate(500)
+    assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+
+
+def test_full_size_stage_is_independent_of_the_speculation_window():
+    # BASELINE.json's metric workload at full size (8 strains x 4.6 Mbp, k=25, D=150): the result must not depend on how many
+    # ids are speculated per round, must be reproducible, and must reproduce the counts the reference binary reports for
+    # this input (1 120 044 ids, 7 089 276 instances, 334 284 bulges)
+    import hashlib
+    from sibelia_amd import workloads as W, formats as F
+    seqs = W.gen_strains(L0=4_600_000, n=8, seed=1)
+    digests = []
+    for window in (16384, 3000, 16384):
+        bf = _bf(seqs)
+        bf.set_window(window)
+        bulges = bf.simplify_stage(25, 150, 4)
+        st = bf.stats()
+        assert (bulges, st["bif_count"], st["instances"]) == (334284, 1120044, 7089276)
+        s, p = bf.state()
+        digests.append(hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest())
+        bf.close()
+    assert digests[0] == digests[1] == digests[2]
+
+
+def test_many_strains_small_genomes_match_oracle():
+    # config 4 shape (62 strains): ids with ~60-120 instances each
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=12_000, n=62, seed=4)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    assert bf.simplify_stage(25, 150, 4) == orc.simplify_stage(25, 150, 4)
+    (sa, pa), (sb, pb) = bf.state(), orc.state()
+    assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
