@@ -39,6 +39,7 @@ struct GraphView {
 	uint32_t k, D, nid;                 // ids 0 .. nid-1
 	uint8_t *need;                      // need[id] != 0: RemoveBulges(id) must run at its turn
 	uint8_t *big;                       // big[id] != 0: needs the large scratch arena (runs alone)
+	uint8_t *touch;                     // touch[id] != 0: windows or lists of the id changed since its verdict was last taken
 	// reservation (ordered-commit rounds) and order validation, see simplify.hip
 	uint32_t *own;                      // per id: round-stamped owner (atomicMin)
 	uint32_t *lock, *rmax, *wmax;       // per resource: blocks [0,nblk) then ids [nblk, nblk+nid]
@@ -168,7 +169,7 @@ struct Txn {
 
 	// a changed instance list makes that id's verdict stale: it must (re)run at its turn in this iteration
 	__host__ __device__ __forceinline__ void push_dirty(uint32_t b)
-	{ if (b > id && b < g.nid) g.need[b] = 1; }
+	{ if (b < g.nid) { g.touch[b] = 1; if (b > id) g.need[b] = 1; } }
 
 	// AddPoint, bifurcationstorage.cpp:113-126
 	__host__ __device__ void add_point(SIt a, uint32_t b)

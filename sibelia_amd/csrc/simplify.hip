@@ -202,7 +202,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
 // lane 0 evaluates the Boost-ordered map on the cached marks).
-__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes)
+__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -212,8 +212,10 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	const unsigned lane = threadIdx.x;
 	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
 	for (unsigned id = blockIdx.x; id < g.nid; id += gridDim.x) {
+		// incremental: an id nobody touched since its verdict was last taken is still clean
+		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }
 		__syncthreads();
-		if (lane == 0) { t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
+		if (lane == 0) { g.touch[id] = 0; t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
 		if (ok) {
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
@@ -423,8 +425,8 @@ __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsi
 {
 	unsigned reach = g.D + g.k + 2;
 	auto push = [&](unsigned b0, unsigned b1) {
-		if (b0 != BT_NONE && b0 > id && b0 < g.nid) g.need[b0] = 1;
-		if (b1 != BT_NONE && b1 > id && b1 < g.nid) g.need[b1] = 1;
+		if (b0 != BT_NONE && b0 < g.nid) { g.touch[b0] = 1; if (b0 > id) g.need[b0] = 1; }
+		if (b1 != BT_NONE && b1 < g.nid) { g.touch[b1] = 1; if (b1 > id) g.need[b1] = 1; }
 	};
 	wave_walk_marks(g, e, d ^ 1u, reach + 1, lane, push);
 	wave_walk_marks(g, e, d, newlen + 2 * g.k + reach + 1, lane, push);
@@ -478,7 +480,7 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 	g.ndead[nd] = 1;
 	g.nclr[nd] = atomicExch(&t.tc_head, nd);
 	if (t.mode) wave_stamp_id_write(g, stampv, t.tid, t.id, b);
-	if (b > t.id && b < g.nid) g.need[b] = 1;
+	if (b < g.nid) { g.touch[b] = 1; if (b > t.id) g.need[b] = 1; }
 }
 
 __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv)
@@ -638,7 +640,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
 	PH_T0();
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
-	if (lane == 0) { g.need[id] = 0; flag = 1; }
+	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
 	if (solo) {
 		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
@@ -788,7 +790,7 @@ __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_
 struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
-	DevBuf ctr, need, big, own, lock, rmax, wmax, win;
+	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp;
@@ -819,7 +821,7 @@ struct DeviceBackend {
 			g.head[s] = st->head[s].as<uint32_t>(); g.lsize[s] = st->lsize[s].as<uint32_t>();
 		}
 		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nidst = st->nidst.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
-		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>();
+		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>(); g.touch = st->touch.as<uint8_t>();
 		g.own = st->own.as<uint32_t>(); g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 		g.cap_e = cap_e; g.cap_n = cap_n; g.nid = nid_;
 		g.nblk = (cap_e >> BT_BLOCK_SHIFT) + 1;
@@ -847,6 +849,7 @@ struct DeviceBackend {
 			copy(st->ck_bif[s], c->d_bif[s], (size_t)ck_ne * 4); copy(st->ck_nodeof[s], st->nodeof[s], (size_t)ck_ne * 4);
 			copy(st->ck_head[s], st->head[s], ((size_t)nid_ + 1) * 4); copy(st->ck_lsize[s], st->lsize[s], ((size_t)nid_ + 1) * 4);
 		}
+		copy(st->ck_touch, st->touch, (size_t)nid_ + 1);
 		copy(st->ck_nslot, st->nslot, (size_t)ck_nn * 4); copy(st->ck_nnext, st->nnext, (size_t)ck_nn * 4); copy(st->ck_ndead, st->ndead, ck_nn);
 	}
 	void restore()
@@ -857,16 +860,17 @@ struct DeviceBackend {
 			back(c->d_bif[s], st->ck_bif[s], (size_t)ck_ne * 4); back(st->nodeof[s], st->ck_nodeof[s], (size_t)ck_ne * 4);
 			back(st->head[s], st->ck_head[s], ((size_t)nid_ + 1) * 4); back(st->lsize[s], st->ck_lsize[s], ((size_t)nid_ + 1) * 4);
 		}
+		back(st->touch, st->ck_touch, (size_t)nid_ + 1);
 		back(st->nslot, st->ck_nslot, (size_t)ck_nn * 4); back(st->nnext, st->ck_nnext, (size_t)ck_nn * 4); back(st->ndead, st->ck_ndead, ck_nn);
 		unsigned v[2] = { ck_ne, ck_nn };
 		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, 8, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	void snapshot_all()
+	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[6], c->stream));
-		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes);
+		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0);
 		HIP_TRY(hipEventRecord(ev[7], c->stream));
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -972,7 +976,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	SimplifyState *st = c->simp;
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
-	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
+	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
@@ -1061,9 +1065,10 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, sizeof v, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 	}
-	st->need.ensure(nidp); st->big.ensure(nidp); st->own.ensure(nidp * 4);
+	st->need.ensure(nidp); st->big.ensure(nidp); st->touch.ensure(nidp); st->own.ensure(nidp * 4);
 	HIP_TRY(hipMemsetAsync(st->need.p, 0, nidp, s));
 	HIP_TRY(hipMemsetAsync(st->big.p, 0, nidp, s));
+	HIP_TRY(hipMemsetAsync(st->touch.p, 0, nidp, s));
 	// scratch arena per window entry: window caches of ~16 instances (17 B per step, D + k + 2 steps) + FillVisit / Overlap
 	// buffers + the AnyBulges map; ids that need more run alone in the big arena
 	{

@@ -25,7 +25,7 @@ struct SimplifyReport {
 // Backend concept:
 //   uint32_t nid();                                  number of bifurcation ids
 //   void checkpoint(); void restore();               iteration-level copy of every mutable array
-//   void snapshot_all();                             need[id] = AnyBulges verdict, for every id
+//   void snapshot_all(bool incremental);             need[id] = AnyBulges verdict, for every id (incremental: touched ids only)
 //   void reset_round_state(bool stamps_too);         own/lock = 0xFFFFFFFF (and rmax/wmax = 0)
 //   void clear_counters();                           ctr[ERR, BULGES, VIOL, BIG, COMMITTED] reset (VIOL = NONE)
 //   void select(lo, limit, W, &nwin, &newlo, &solo); lowest pending ids in [lo, limit]
@@ -62,7 +62,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 			uint64_t iter_bulges = 0;
 			for (;;) {                                                    // replay loop
 				bool replay = false;
-				be.snapshot_all();
+				be.snapshot_all(rep.iterations > 1);
 				be.reset_round_state(true);
 				be.clear_counters();
 				std::sort(fences.begin(), fences.end());

@@ -21,8 +21,12 @@
 #define SS_ROUND_MAX 4095u
 
 // ---- one-thread forms (tests/hostsim); simplify.hip runs the same steps with 64 lanes scanning the windows
-__host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uint8_t *arena, uint32_t arena_bytes)
+// `incremental`: an id nobody touched since its verdict was last taken (previous snapshot, a probe, or its own
+// RemoveBulges) still has verdict false -- only touched ids are examined again.
+__host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uint8_t *arena, uint32_t arena_bytes, bool incremental)
 {
+	if (incremental && !g.touch[id]) { g.need[id] = 0; return; }
+	g.touch[id] = 0;
 	Txn t;
 	BulgeWork w;
 	t.init(g, id, 0, 0, arena, arena_bytes);
@@ -65,6 +69,7 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 {
 	uint32_t id = g.win[widx];
 	g.need[id] = 0;                            // cleared BEFORE running: a later push must survive
+	g.touch[id] = 1;                           // whatever it leaves behind is examined again by the next snapshot
 	Txn t;
 	BulgeWork w;
 	t.init(g, id, widx, 1, arena, arena_bytes);

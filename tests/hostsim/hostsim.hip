@@ -18,7 +18,7 @@ namespace {
 
 struct HostBackend {
 	GraphView g{};
-	std::vector<uint8_t> ch, ndead, need, big;
+	std::vector<uint8_t> ch, ndead, need, big, touch;
 	std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, nidst, nclr, head[2], lsize[2], ctr, own, lock, rmax, wmax, win;
 	uint32_t nid_ = 0;
 	int order_mode = 0;
@@ -26,14 +26,14 @@ struct HostBackend {
 	std::vector<uint8_t> arena, big_arena;
 	uint64_t rng = 88172645463325252ull;
 	// checkpoint
-	struct Ck { std::vector<uint8_t> ch, ndead; std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, head[2], lsize[2]; uint32_t ne, nn; } ck;
+	struct Ck { std::vector<uint8_t> ch, ndead, touch; std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, head[2], lsize[2]; uint32_t ne, nn; } ck;
 
 	void bind()
 	{
 		g.ch = ch.data(); g.op = op.data(); g.nx = nx.data(); g.pv = pv.data();
 		for (int s = 0; s < 2; s++) { g.bif[s] = bif[s].data(); g.nodeof[s] = nodeof[s].data(); g.head[s] = head[s].data(); g.lsize[s] = lsize[s].data(); }
 		g.nslot = nslot.data(); g.nnext = nnext.data(); g.nidst = nidst.data(); g.nclr = nclr.data(); g.ndead = ndead.data();
-		g.ctr = ctr.data(); g.need = need.data(); g.big = big.data();
+		g.ctr = ctr.data(); g.need = need.data(); g.big = big.data(); g.touch = touch.data();
 		g.own = own.data(); g.lock = lock.data(); g.rmax = rmax.data(); g.wmax = wmax.data();
 		g.cap_e = (uint32_t)ch.size(); g.cap_n = (uint32_t)nslot.size();
 		g.nblk = (g.cap_e >> BT_BLOCK_SHIFT) + 1;
@@ -43,19 +43,19 @@ struct HostBackend {
 	void checkpoint()
 	{
 		ck.ne = ctr[CTR_NE]; ck.nn = ctr[CTR_NN];
-		ck.ch = ch; ck.ndead = ndead; ck.op = op; ck.nx = nx; ck.pv = pv; ck.nslot = nslot; ck.nnext = nnext;
+		ck.ch = ch; ck.ndead = ndead; ck.touch = touch; ck.op = op; ck.nx = nx; ck.pv = pv; ck.nslot = nslot; ck.nnext = nnext;
 		for (int s = 0; s < 2; s++) { ck.bif[s] = bif[s]; ck.nodeof[s] = nodeof[s]; ck.head[s] = head[s]; ck.lsize[s] = lsize[s]; }
 	}
 	void restore()
 	{
 		auto cp = [](auto &dst, const auto &src) { std::copy(src.begin(), src.end(), dst.begin()); };
-		cp(ch, ck.ch); cp(ndead, ck.ndead); cp(op, ck.op); cp(nx, ck.nx); cp(pv, ck.pv); cp(nslot, ck.nslot); cp(nnext, ck.nnext);
+		cp(ch, ck.ch); cp(ndead, ck.ndead); cp(touch, ck.touch); cp(op, ck.op); cp(nx, ck.nx); cp(pv, ck.pv); cp(nslot, ck.nslot); cp(nnext, ck.nnext);
 		for (int s = 0; s < 2; s++) { cp(bif[s], ck.bif[s]); cp(nodeof[s], ck.nodeof[s]); cp(head[s], ck.head[s]); cp(lsize[s], ck.lsize[s]); }
 		ctr[CTR_NE] = ck.ne; ctr[CTR_NN] = ck.nn;
 	}
-	void snapshot_all()
+	void snapshot_all(bool incremental)
 	{
-		for (uint32_t id = 0; id < nid_; id++) ss_snapshot(g, id, arena.data(), 1u << 14);
+		for (uint32_t id = 0; id < nid_; id++) ss_snapshot(g, id, arena.data(), 1u << 14, incremental);
 	}
 	void reset_round_state(bool stamps_too)
 	{
@@ -200,7 +200,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 		}
 		size_t ncap = n0 + n1 + 1024;
 		be.nslot.assign(ncap, 0); be.nidst.assign(ncap, 0); be.nnext.assign(ncap, BT_NONE); be.nclr.assign(ncap, BT_NONE); be.ndead.assign(ncap, 0);
-		be.ctr.assign(CTR_COUNT, 0); be.need.assign((size_t)bif_count + 1, 0); be.big.assign((size_t)bif_count + 1, 0);
+		be.ctr.assign(CTR_COUNT, 0); be.need.assign((size_t)bif_count + 1, 0); be.big.assign((size_t)bif_count + 1, 0); be.touch.assign((size_t)bif_count + 1, 0);
 		be.own.assign((size_t)bif_count + 1, 0xFFFFFFFFu);
 		be.lock.assign((cap >> BT_BLOCK_SHIFT) + 1 + bif_count + 1, 0xFFFFFFFFu);
 		be.rmax.assign(be.lock.size(), 0); be.wmax.assign(be.lock.size(), 0);
