@@ -231,6 +231,36 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	}
 }
 
+// Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
+// without reservation (ss_probe); the others are flagged live and go through reserve / commit.
+__global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ VerdictTable vt;
+	__shared__ int ok;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
+	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	if (wi >= nwin) return;
+	const unsigned id = g.win[wi], tid = id + 1;
+	if (g.need[id] == 2) { if (lane == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
+	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
+	__syncthreads();
+	if (ok) {
+		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+		__syncthreads();
+	}
+	int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
+	if (lane == 0) {
+		bool has = verdict > 0;
+		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
+		if (!has) { g.need[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }
+		else if (!t.err) g.need[id] = 2;
+		live[wi] = has ? 1 : 0;
+	}
+}
+
 // one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
 // (and runs alone if it is the lowest).  Eight ids per thread and step (8-byte loads of the need / big flags).
 // out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
@@ -402,9 +432,12 @@ __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsi
 	wave_walk_marks(g, e, d, newlen + 2 * g.k + reach + 1, lane, push);
 }
 
-// one wave per live window entry: claim every id of the neighbourhood and remember the list for the commit check
-__device__ __forceinline__ void wave_reserve(const GraphView &g, unsigned w, unsigned lane, unsigned *claims, unsigned *seen)
+// one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
+__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
+	unsigned w = blockIdx.x, lane = threadIdx.x;
+	if (w >= nwin || !live[w]) return;
+	__shared__ unsigned seen[SEEN_SLOTS];
 	for (unsigned i = lane; i < SEEN_SLOTS; i += 64) seen[i] = BT_NONE;
 	__syncthreads();
 	unsigned id = g.win[w], st = g.round_bits | w;
@@ -420,52 +453,6 @@ __device__ __forceinline__ void wave_reserve(const GraphView &g, unsigned w, uns
 		}
 	if (lane == 0) cl.buf[0] = cl.n;
 }
-__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
-{
-	__shared__ unsigned seen[SEEN_SLOTS];
-	unsigned w = blockIdx.x, lane = threadIdx.x;
-	if (w >= nwin || !live[w]) return;
-	wave_reserve(g, w, lane, claims, seen);
-}
-
-// Probe + reserve of the window entries between rounds, fused (both only read the graph): entries whose AnyBulges verdict
-// is false NOW are retired without reservation (ss_probe); the others are flagged live and claim their neighbourhood.
-__global__ void __launch_bounds__(64) k_probe_reserve(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned *claims)
-{
-	__shared__ Txn t;
-	__shared__ BulgeWork w;
-	__shared__ VerdictTable vt;
-	__shared__ int ok, s_live;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
-	__shared__ unsigned seen[SEEN_SLOTS];
-	const unsigned wi = blockIdx.x, lane = threadIdx.x;
-	if (wi >= nwin) return;
-	const unsigned id = g.win[wi], tid = id + 1;
-	if (g.need[id] == 2) {                                            // found live by an earlier probe and not touched since (a push resets it to 1)
-		if (lane == 0) live[wi] = 1;
-		wave_reserve(g, wi, lane, claims, seen);
-		return;
-	}
-	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
-	__syncthreads();
-	if (ok) {
-		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
-		__syncthreads();
-	}
-	int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
-	if (lane == 0) {
-		bool has = verdict > 0;
-		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
-		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
-		if (!has) { g.need[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }
-		else if (!t.err) g.need[id] = 2;
-		live[wi] = has ? 1 : 0;
-		s_live = has ? 1 : 0;
-	}
-	__syncthreads();
-	if (s_live) wave_reserve(g, wi, lane, claims, seen);
-}
-
 // ---- wave-wide CollapseBulgeGreedily ------------------------------------------------------------------------
 // Same effect as bt_collapse (bulge_txn.h) = EraseBifurcations + DNASequence::Replace + UpdateBifurcations
 // (reference src/bulgeremoval.cpp:55-95, 238-327, src/dnasequence.cpp:189-252), but every element the reference reaches
@@ -823,7 +810,6 @@ struct DeviceBackend {
 	hipEvent_t ev[8] = {};
 	bool timed_reserve = false, timed_commit = false, timed_probe = false;
 	int prof = 0;
-	bool fused_reserve = false;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
 	uint32_t nid() { return nid_; }
@@ -919,16 +905,15 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		HIP_TRY(hipEventRecord(ev[4], c->stream));
-		k_probe_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), st->claims.as<unsigned>());
+		k_probe<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[5], c->stream));
-		timed_probe = true; fused_reserve = true;
+		timed_probe = true;
 		HIP_TRY(hipGetLastError());
 	}
 	void mark_live(uint32_t nwin) { HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		if (fused_reserve) { fused_reserve = false; return; }         // the probe kernel already claimed for the live entries
 		HIP_TRY(hipEventRecord(ev[0], c->stream));
 		k_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[1], c->stream));
