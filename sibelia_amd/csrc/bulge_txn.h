@@ -337,6 +337,7 @@ struct BulgeWork {
 	uint64_t *wmk; uint32_t *wmn; // compact list of the marked steps >= 1 of each window: (step << 32) | id, and their number
 	uint32_t *wst; char *wck;     // mark at step 0 and (oriented) character at step k of each window
 	uint32_t *wbk, *wnb;          // steps at which the walk leaves consecutive slots (BT_MAX_BREAKS per window) and their number
+	uint32_t *wdel;              // elements this transaction has deleted inside each window (reach beyond the reserved range, simplify.hip)
 	bool lite;                   // verdict-only use: wel / wbf / wch are not materialised
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
@@ -382,7 +383,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc2(n);
 	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
 	w.lite = lite;
-	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
 	if (!lite) {
 		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
@@ -390,6 +391,8 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.wch = (uint8_t *)t.alloc(n * w.ws);
 		w.wbk = (uint32_t *)t.alloc(n * BT_MAX_BREAKS * 4);
 		w.wnb = (uint32_t *)t.alloc(n * 4);
+		w.wdel = (uint32_t *)t.alloc2(n * 4);
+		if (w.wdel) for (uint32_t i = 0; i < n; i++) w.wdel[i] = 0;
 		w.visit = (uint64_t *)t.alloc2(w.visit_cap * 8);
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
 		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);

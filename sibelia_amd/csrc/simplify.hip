@@ -70,13 +70,12 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 // writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
 __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r)
 {
+	// Exclusivity inside a round needs no per-element lock here: an owner holds every id marked in the range it reserved
+	// (2(D+k+2)+k elements ahead of each instance), its scans reach D+k+2 elements, and k_commit checks after every
+	// collapse that the elements it has deleted inside a window cannot carry a later scan / push beyond the reserved range.
 	bool bad = false;
 	unsigned other = BT_NONE;
-	if (mode != 3) {                                              // 3 = probe: no writer is running, no exclusivity to establish
-		unsigned old = atomicMin(&g.lock[r], stampv);
-		bad = old != stampv && (old >> 20) == (stampv >> 20);
-		other = bad ? g.win[old & 0xFFFFFu] : BT_NONE;
-	}
+	(void)stampv;
 	if (mode == 2) atomicMax(&g.rmax[r], tid);
 	unsigned wm = g.wmax[r];
 	if (wm > tid) bad = true;
@@ -696,6 +695,17 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			wave_collapse(g, t, w, lane, stampv);
 			PH_ADD(5);
 			if (t.err) break;
+			if (lane == 0 && w.c_dT > w.c_dS) {
+				// deletions shift what a window of fixed step count reaches: stay inside the reserved range or run alone
+				const unsigned F = 2 * (g.D + g.k + 2) + g.k, del = w.c_dT - w.c_dS;
+				bool escape = !selective;
+				for (unsigned i = 0; i < w.n && selective; i++)
+					if ((dirty[i >> 6] >> (i & 63)) & 1ull) {
+						w.wdel[i] += del;
+						if (g.D + g.k + 2 + w.wdel[i] > F || (g.D - 1) + 3 * g.k + g.D + 2 + w.wdel[i] > F + g.D - 1 - w.c_dS) escape = true;
+					}
+				if (escape && !solo) { g.big[id] = 1; atomicMin(&g.ctr[CTR_VIOL], id); }     // replay with this id running alone
+			}
 			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
 			PH_ADD(6);
 			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
