@@ -23,6 +23,7 @@
 #define BT_DEAD_CHAR 0            // ch[] of an element that was erased from the list
 #define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
 #define BT_MAX_BREAKS 16u
+#define BT_LDS_MARKS 48u
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
@@ -335,6 +336,8 @@ struct BulgeWork {
 	uint8_t *wch;                // raw character per step
 	uint32_t *wlen;              // number of leading steps before the first separator (<= ws)
 	uint64_t *wmk; uint32_t *wmn; // compact list of the marked steps >= 1 of each window: (step << 32) | id, and their number
+	uint32_t mks;                // stride of wmk per window: ws in the arena, BT_LDS_MARKS when the lists live in the fast scratch
+	bool mk_overflow;            // a window had more marks than mks: bt_marks_to_arena + full rescan required
 	uint32_t *wst; char *wck;     // mark at step 0 and (oriented) character at step k of each window
 	uint32_t *wbk, *wnb;          // steps at which the walk leaves consecutive slots (BT_MAX_BREAKS per window) and their number
 	uint32_t *wdel;              // elements this transaction has deleted inside each window (reach beyond the reserved range, simplify.hip)
@@ -381,7 +384,11 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wmn = (uint32_t *)t.alloc2(n * 4);
 	w.wst = (uint32_t *)t.alloc2(n * 4);
 	w.wck = (char *)t.alloc2(n);
-	w.wmk = (uint64_t *)t.alloc(n * w.ws * 8);
+	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
+	w.mk_overflow = false;
+	w.wmk = lite ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);
+	w.mks = BT_LDS_MARKS;
+	if (!w.wmk) { w.wmk = (uint64_t *)t.alloc(n * w.ws * 8); w.mks = w.ws; }
 	w.lite = lite;
 	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
@@ -424,13 +431,24 @@ __host__ __device__ inline void bt_scan_instance(Txn &t, BulgeWork &w, uint32_t 
 		if (s == 0) w.wst[i] = b;
 		if (s == k) w.wck[i] = a.d ? bt_comp((char)c) : (char)c;
 		if (c == BT_SEP) break;
-		if (s && b != BT_NONE) w.wmk[base + nm++] = ((uint64_t)s << 32) | b;
+		if (s && b != BT_NONE) { if (nm < w.mks) w.wmk[(size_t)i * w.mks + nm] = ((uint64_t)s << 32) | b; else w.mk_overflow = true; nm++; }
 		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
 	}
 	w.wlen[i] = s; w.wmn[i] = nm;
 	if (!w.lite) w.wnb[i] = nb;
 }
-__host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w) { for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
+// a window had more marks than the fast scratch holds: move the lists to the arena (the caller rescans every window)
+__host__ __device__ inline void bt_marks_to_arena(Txn &t, BulgeWork &w)
+{
+	w.wmk = (uint64_t *)t.alloc(w.n * w.ws * 8);
+	w.mks = w.ws;
+	w.mk_overflow = false;
+}
+__host__ __device__ inline void bt_scan_all(Txn &t, BulgeWork &w)
+{
+	for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i);
+	if (w.mk_overflow) { bt_marks_to_arena(t, w); if (!t.err) for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
+}
 
 // endChar (bulgeremoval.cpp:340-347, ProperKMer(k + 1) dnasequence.h:154-165)
 __host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
@@ -443,7 +461,7 @@ __host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
 __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 {
 	uint32_t D = t.g.D, n = 0;
-	const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
 	uint32_t start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
 	for (uint32_t j = 0; j < nm; j++) {
 		uint32_t step = (uint32_t)(mk[j] >> 32), b = (uint32_t)mk[j];
@@ -525,7 +543,7 @@ __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uin
 __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i, uint32_t distance)
 {
 	uint32_t r = 0, nm = w.wmn[i];
-	const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
 	for (uint32_t j = 0; j < nm; j++) {
 		if ((uint32_t)(mk[j] >> 32) >= distance) break;
 		uint32_t c = t.count_bif((uint32_t)mk[j]);
@@ -690,7 +708,7 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	bool any = false;
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
-		const uint64_t *mk = w.wmk + (size_t)i * w.ws;
+		const uint64_t *mk = w.wmk + (size_t)i * w.mks;
 		uint32_t start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
 		for (uint32_t j = 0; j < nm; j++) {
 			uint32_t b = (uint32_t)mk[j];
@@ -758,7 +776,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 			while (w.idJ < ge) {
 				const uint32_t kmerJ = w.ab.grp_mem[w.idJ++];
 				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
-				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.ws;
+				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.mks;
 				const uint32_t limJ = w.wlen[kmerJ] < D ? w.wlen[kmerJ] : D, nmJ = w.wmn[kmerJ];
 				for (uint32_t j = 0; j < nmJ; j++) {
 					uint32_t step = (uint32_t)(mkJ[j] >> 32), nowBif = (uint32_t)mkJ[j];

@@ -134,7 +134,8 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			{	// compact list of the marked steps (>= 1, before the separator), in step order
 				bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
 				unsigned long long mm = __ballot(marked);
-				if (marked) w.wmk[base + nm + __popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)(done + lane) << 32) | bv;
+				unsigned mo = nm + __popcll(mm & ((1ull << lane) - 1ull));
+				if (marked && mo < w.mks) w.wmk[(size_t)i * w.mks + mo] = ((unsigned long long)(done + lane) << 32) | bv;
 				nm += __popcll(mm);
 			}
 			if (mode) {
@@ -148,7 +149,7 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			if (pre < 64 || cur != (dir ? lastc - 1 : lastc + 1)) break;      // link break: re-anchor with a fresh burst
 		}
 	}
-	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; }
+	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; if (nm > w.mks) *const_cast<bool *>(&w.mk_overflow) = true; }
 }
 
 // AnyBulges VERDICT with 64 lanes.  "Some bulge group gets a second member" is an order-free predicate: there is an
@@ -171,7 +172,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 		const char ec = w.wck[i];
 		const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
 		const unsigned lim = len < D ? len : D, nm = w.wmn[i], start = w.wst[i];
-		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.ws;
+		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
 		for (unsigned j0 = 0; j0 < nm; j0 += 64) {
 			unsigned j = j0 + lane;
 			unsigned long long v = j < nm ? mk[j] : ~0ull;
@@ -618,7 +619,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int flag;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // FillVisit list + AnyBulges map of typical ids
+	__shared__ __attribute__((aligned(16))) uint8_t fast[24576];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
@@ -665,6 +666,13 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 		__syncthreads();
+		if (w.mk_overflow) {                                          // more marks in a window than the LDS lists hold: use the arena
+			__syncthreads();
+			if (lane == 0) bt_marks_to_arena(t, w);
+			__syncthreads();
+			if (!t.err) for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+			__syncthreads();
+		}
 		PH_ADD(1);
 		if (lane == 0) flag = bt_rb_begin(t, w) && !t.err ? 1 : 0;
 		__syncthreads();
@@ -713,6 +721,14 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			for (unsigned i = 0; i < w.n; i++)
 				if (!selective || ((dirty[i >> 6] >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			__syncthreads();
+			if (w.mk_overflow) {
+				__syncthreads();
+				if (lane == 0) bt_marks_to_arena(t, w);
+				__syncthreads();
+				if (t.err) break;
+				for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+				__syncthreads();
+			}
 			PH_ADD(8);
 		}
 	}

@@ -65,7 +65,8 @@ __host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint
 }
 
 // the transaction proper, for a window entry that owns its whole neighbourhood
-__host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
+__host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes,
+                                              uint8_t *fast = nullptr, uint32_t fast_bytes = 0)
 {
 	uint32_t id = g.win[widx];
 	g.need[id] = 0;                            // cleared BEFORE running: a later push must survive
@@ -80,6 +81,7 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	bt_atomic_add(&g.ctr[CTR_TXN], 1u);
 	if (!has) return;
 	t.init(g, id, widx, 2, arena, arena_bytes);                   // writer pass: publish reads and writes
+	t.fscr = fast; t.fscr_cap = fast_bytes;                       // (the kernels put summaries, mark lists and the AnyBulges map in LDS)
 	w.ret = 0;
 	bt_setup(t, w);
 	bt_scan_all(t, w);

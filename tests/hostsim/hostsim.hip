@@ -91,6 +91,7 @@ struct HostBackend {
 	// like k_reserve / k_commit: the ids claimed at RESERVATION time are remembered and checked at commit time
 	std::vector<std::vector<uint32_t>> claims;
 	std::vector<uint32_t> dbg_bif0, dbg_bif1; uint32_t dbg_nn = 0;
+	alignas(16) uint8_t fastbuf[24576];      // stands in for the kernels' LDS scratch
 	std::vector<uint8_t> live;
 	void probe(uint32_t nwin, uint32_t round)
 	{
@@ -113,14 +114,14 @@ struct HostBackend {
 	void commit(uint32_t nwin, uint32_t round, bool solo)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		if (solo) { ss_commit_run(g, 0, big_arena.data(), big_arena_bytes); return; }
+		if (solo) { ss_commit_run(g, 0, big_arena.data(), big_arena_bytes, fastbuf, sizeof fastbuf); return; }
 		for (uint32_t w : order(nwin)) {
 			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
 			bool owner = true;
 			for (uint32_t b : claims[w]) if (own[b] != st) { owner = false; break; }
 			uint32_t before = ctr[CTR_VIOL];
-			if (owner) ss_commit_run(g, w, arena.data(), arena_bytes);
+			if (owner) ss_commit_run(g, w, arena.data(), arena_bytes, fastbuf, sizeof fastbuf);
 			if (getenv("HOSTSIM_DEBUG") && ctr[CTR_VIOL] != before) {
 				uint32_t a = win[w];
 				fprintf(stderr, "[dbg] violation while committing id %u (widx %u)\n", a, w);
