@@ -27,7 +27,7 @@
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
-       CTR_BIG = 8, CTR_PUSHED = 9, CTR_TXN = 10, /* 11..15: violation detail */ CTR_NOWN = 16, CTR_COUNT = 32 };
+       CTR_BIG = 8, CTR_PUSHED = 9, CTR_TXN = 10, CTR_COUNT = 16 };
 enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
 
 struct GraphView {

@@ -325,7 +325,6 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 		g.ctr[CTR_NWIN] = s_base;
 		g.ctr[CTR_LO] = s_first == SBL_NONE ? lo : s_first;
 		g.ctr[CTR_PUSHED] = s_solo;
-		g.ctr[CTR_NOWN] = 0;
 	}
 }
 
@@ -612,35 +611,32 @@ __device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summe
 #define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
 
-// Owners of the round: window entries that hold every id they claimed.  Compacted into a list so that k_commit only
-// starts (LDS-heavy) waves for them.
-__global__ void __launch_bounds__(64) k_owners(GraphView g, unsigned nwin, const unsigned *claims, const uint8_t *live, unsigned *owners)
-{
-	const unsigned wi = blockIdx.x, lane = threadIdx.x;
-	if (wi >= nwin || !live[wi]) return;
-	const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
-	const unsigned n = cb[0], stampv = g.round_bits | wi;
-	bool owner = true;
-	if (n <= CLAIM_CAP) {
-		for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != stampv) owner = false;
-		owner = !__any(!owner);
-	} else {
-		if (lane == 0) owner = ss_owns_footprint(g, wi);          // list overflowed: serial re-walk
-		owner = __shfl((int)owner, 0) != 0;
-	}
-	if (owner && lane == 0) owners[atomicAdd(&g.ctr[CTR_NOWN], 1u)] = wi;
-}
-
-// RemoveBulges for one owner: lane 0 takes the decisions on the cached windows, all lanes scan / collapse / rescan.
-__device__ void commit_one(const GraphView &g, const unsigned wi, uint8_t *arena, unsigned arena_bytes, int solo, int prof)
+// One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
+// the decisions on the cached windows and all lanes rescanning them after every collapse.
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
+	__shared__ VerdictTable vt;
 	__shared__ int flag;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
-	const unsigned lane = threadIdx.x;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[24576];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
+	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	if (wi >= nwin) return;
+	if (!solo && !live[wi]) return;                                   // retired by the probe
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
-	__syncthreads();                                                  // the shared state of the previous owner of this wave is dead
+	if (!solo) {
+		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
+		unsigned n = cb[0];
+		bool owner = true;
+		if (n <= CLAIM_CAP) {
+			for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != stampv) owner = false;
+			owner = !__any(!owner);
+		} else {
+			if (lane == 0) owner = ss_owns_footprint(g, wi);      // list overflowed: serial re-walk
+			owner = __shfl((int)owner, 0) != 0;
+		}
+		if (!owner) return;                                       // stays pending
+	}
 	uint8_t *mine = arena + (size_t)wi * arena_bytes;
 	PH_T0();
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
@@ -652,7 +648,7 @@ __device__ void commit_one(const GraphView &g, const unsigned wi, uint8_t *arena
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
 			__syncthreads();
 		}
-		int verdict = flag ? wave_verdict(g, w, *reinterpret_cast<VerdictTable *>(fast), lane) : 0;   // the fast scratch is idle in this pass
+		int verdict = flag ? wave_verdict(g, w, vt, lane) : 0;
 		if (lane == 0) {
 			bool has = verdict > 0;
 			if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
@@ -745,13 +741,6 @@ __device__ void commit_one(const GraphView &g, const unsigned wi, uint8_t *arena
 	}
 }
 
-__global__ void __launch_bounds__(64) k_commit(GraphView g, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *owners, int prof)
-{
-	if (solo) { if (blockIdx.x == 0) commit_one(g, 0, arena, arena_bytes, 1, prof); return; }
-	const unsigned nown = g.ctr[CTR_NOWN];
-	for (unsigned o = blockIdx.x; o < nown; o += gridDim.x) commit_one(g, owners[o], arena, arena_bytes, 0, prof);
-}
-
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
 // The list is a chain of "segments" = maximal runs of consecutive slots linked consecutively.  Heads are
 // found with a flag pass, segments are ranked by pointer jumping, elements scatter to rank + offset.
@@ -828,7 +817,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, owners;
+	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
@@ -963,12 +952,9 @@ struct DeviceBackend {
 		HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
-			k_commit<<<1, 64, 0, c->stream>>>(g, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, prof);
+			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr, prof);
 		} else
-		{
-			k_owners<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>(), st->owners.as<unsigned>());
-			k_commit<<<std::min<unsigned>(nwin, 2048u), 64, 0, c->stream>>>(g, st->arena.as<uint8_t>(), arena_bytes, 0, st->owners.as<unsigned>(), prof);
-		}
+			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
 		HIP_TRY(hipEventRecord(ev[3], c->stream));
 		timed_commit = true;
 		HIP_TRY(hipGetLastError());
@@ -1017,7 +1003,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->owners, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -1137,7 +1123,6 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	st->arena.ensure((size_t)window * be.arena_bytes);
 	st->claims.ensure((size_t)window * (CLAIM_CAP + 1) * 4);
 	st->live.ensure((size_t)window + 64);
-	st->owners.ensure((size_t)window * 4 + 64);
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z)); }
