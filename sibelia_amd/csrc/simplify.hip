@@ -617,9 +617,8 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
-	__shared__ VerdictTable vt;
 	__shared__ int flag;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[24576];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
+	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
@@ -648,7 +647,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
 			__syncthreads();
 		}
-		int verdict = flag ? wave_verdict(g, w, vt, lane) : 0;
+		int verdict = flag ? wave_verdict(g, w, *reinterpret_cast<VerdictTable *>(fast), lane) : 0;   // the fast scratch is idle in this pass
 		if (lane == 0) {
 			bool has = verdict > 0;
 			if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
