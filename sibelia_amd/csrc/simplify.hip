@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
 	__shared__ int flag;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[16384];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
+	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
