@@ -24,7 +24,6 @@
 #define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
 #define BT_MAX_BREAKS 16u
 #define BT_LDS_MARKS 48u
-#define BT_SUMMARY_MARKS 24u      // marks kept per instance summary; windows with more are rescanned every time
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
@@ -42,9 +41,6 @@ struct GraphView {
 	uint8_t *need;                      // need[id] != 0: RemoveBulges(id) must run at its turn
 	uint8_t *big;                       // big[id] != 0: needs the large scratch arena (runs alone)
 	uint8_t *touch;                     // touch[id] != 0: windows or lists of the id changed since its verdict was last taken
-	// per-instance window summaries kept across probes / snapshots (simplify.hip): valid until a collapse rewrites
-	// something the window can see (the neighbourhood push invalidates them); null = not used (host test driver)
-	uint8_t *svalid, *sck; uint32_t *slen, *snm; uint64_t *smk;
 	// reservation (ordered-commit rounds) and order validation, see simplify.hip
 	uint32_t *own;                      // per id: round-stamped owner (atomicMin)
 	uint32_t *lock, *rmax, *wmax;       // per resource: blocks [0,nblk) then ids [nblk, nblk+nid]
@@ -198,7 +194,6 @@ struct Txn {
 		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
 		g.lsize[a.d][b]++;
 		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
-		if (g.svalid) g.svalid[nd] = 0;
 		push_dirty(b);
 		return true;
 	}

@@ -152,34 +152,6 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; if (nm > w.mks) *const_cast<bool *>(&w.mk_overflow) = true; }
 }
 
-// Lite (verdict-only) windows of an id: instances whose summary is still valid are read back (one coalesced load of
-// <= 200 B) instead of scanned (three dependent 64-slot steps over four arrays); fresh scans refresh the summary.
-// Marks of instance i then live at wave_marks_of(...).
-__device__ __forceinline__ void wave_lite_windows(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned tid, unsigned mode, unsigned id)
-{
-	for (unsigned i = 0; i < w.n; i++) {
-		const unsigned nd = w.start[i] >> 1;
-		if (g.svalid[nd]) {
-			if (lane == 0) { w.wlen[i] = g.slen[nd]; w.wmn[i] = g.snm[nd]; w.wst[i] = id; w.wck[i] = (char)g.sck[nd]; }
-			continue;
-		}
-		wave_scan_instance(g, w, i, lane, 0, tid, mode, id);
-		__syncthreads();
-		const unsigned nm = w.wmn[i];
-		if (nm <= BT_SUMMARY_MARKS && w.wst[i] == id) {
-			if (lane < nm) g.smk[(size_t)nd * BT_SUMMARY_MARKS + lane] = w.wmk[(size_t)i * w.mks + lane];
-			if (lane == 0) { g.slen[nd] = w.wlen[i]; g.snm[nd] = nm; g.sck[nd] = (uint8_t)w.wck[i]; g.svalid[nd] = 1; }
-		}
-	}
-	__syncthreads();
-}
-__device__ __forceinline__ const unsigned long long *wave_marks_of(const GraphView &g, const BulgeWork &w, unsigned i)
-{
-	return w.lite && w.wmn[i] <= BT_SUMMARY_MARKS && w.wst[i] == (g.nidst[w.start[i] >> 1] >> 1)
-		? reinterpret_cast<const unsigned long long *>(g.smk) + (size_t)(w.start[i] >> 1) * BT_SUMMARY_MARKS
-		: reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
-}
-
 // AnyBulges VERDICT with 64 lanes.  "Some bulge group gets a second member" is an order-free predicate: there is an
 // id b that two instances with different endChars both reach (steps 1 .. min(D, window) - 1, before their own id
 // recurs) -- whichever iteration order boost::unordered_map has.  Marks are hashed into a small LDS table that
@@ -200,7 +172,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 		const char ec = w.wck[i];
 		const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
 		const unsigned lim = len < D ? len : D, nm = w.wmn[i], start = w.wst[i];
-		const unsigned long long *mk = wave_marks_of(g, w, i);
+		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
 		for (unsigned j0 = 0; j0 < nm; j0 += 64) {
 			unsigned j = j0 + lane;
 			unsigned long long v = j < nm ? mk[j] : ~0ull;
@@ -245,7 +217,10 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 		__syncthreads();
 		if (lane == 0) { g.touch[id] = 0; t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 		__syncthreads();
-		if (ok) wave_lite_windows(g, w, lane, 0, 0, id);
+		if (ok) {
+			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
+			__syncthreads();
+		}
 		int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
 		if (lane == 0) {
 			bool v = verdict > 0;
@@ -271,7 +246,10 @@ __global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_
 	if (g.need[id] == 2) { if (lane == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
 	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 	__syncthreads();
-	if (ok) wave_lite_windows(g, w, lane, tid, 3, id);
+	if (ok) {
+		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+		__syncthreads();
+	}
 	int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
 	if (lane == 0) {
 		bool has = verdict > 0;
@@ -378,7 +356,7 @@ __device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned fir
 		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
 		bool proc = lane < pre && lane < stop;
-		f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE, c);
+		f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
 		if (stop < pre) break;
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
@@ -409,7 +387,7 @@ __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, un
 __device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
                                                 ClaimList &cl, unsigned st)
 {
-	wave_walk_marks(g, first, dir, maxcount, lane, [&](unsigned b0, unsigned b1, unsigned) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
+	wave_walk_marks(g, first, dir, maxcount, lane, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
 }
 
 // After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
@@ -446,10 +424,9 @@ __device__ __forceinline__ void wave_stamp_writes(const GraphView &g, unsigned i
 __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
 {
 	unsigned reach = g.D + g.k + 2;
-	// ... and the cached window summary of every instance that can see the region is dropped
-	auto push = [&](unsigned b0, unsigned b1, unsigned c) {
-		if (b0 != BT_NONE && b0 < g.nid) { g.touch[b0] = 1; if (b0 > id) g.need[b0] = 1; g.svalid[g.nodeof[0][c]] = 0; }
-		if (b1 != BT_NONE && b1 < g.nid) { g.touch[b1] = 1; if (b1 > id) g.need[b1] = 1; g.svalid[g.nodeof[1][c]] = 0; }
+	auto push = [&](unsigned b0, unsigned b1) {
+		if (b0 != BT_NONE && b0 < g.nid) { g.touch[b0] = 1; if (b0 > id) g.need[b0] = 1; }
+		if (b1 != BT_NONE && b1 < g.nid) { g.touch[b1] = 1; if (b1 > id) g.need[b1] = 1; }
 	};
 	wave_walk_marks(g, e, d ^ 1u, reach + 1, lane, push);
 	wave_walk_marks(g, e, d, newlen + 2 * g.k + reach + 1, lane, push);
@@ -838,7 +815,6 @@ __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_
 struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
-	DevBuf svalid, sck, slen, snm, smk;
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
@@ -870,7 +846,6 @@ struct DeviceBackend {
 			g.head[s] = st->head[s].as<uint32_t>(); g.lsize[s] = st->lsize[s].as<uint32_t>();
 		}
 		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nidst = st->nidst.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
-		g.svalid = st->svalid.as<uint8_t>(); g.sck = st->sck.as<uint8_t>(); g.slen = st->slen.as<uint32_t>(); g.snm = st->snm.as<uint32_t>(); g.smk = st->smk.as<uint64_t>();
 		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>(); g.touch = st->touch.as<uint8_t>();
 		g.own = st->own.as<uint32_t>(); g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 		g.cap_e = cap_e; g.cap_n = cap_n; g.nid = nid_;
@@ -912,7 +887,6 @@ struct DeviceBackend {
 		}
 		back(st->touch, st->ck_touch, (size_t)nid_ + 1);
 		back(st->nslot, st->ck_nslot, (size_t)ck_nn * 4); back(st->nnext, st->ck_nnext, (size_t)ck_nn * 4); back(st->ndead, st->ck_ndead, ck_nn);
-		HIP_TRY(hipMemsetAsync(st->svalid.p, 0, cap_n, c->stream));      // summaries taken after the checkpoint are void
 		unsigned v[2] = { ck_ne, ck_nn };
 		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, 8, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1014,8 +988,6 @@ struct DeviceBackend {
 			size_t n = (size_t)cap_n * 2;
 			SBL_CHECK(n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
 			st->nslot.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nnext.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nclr.grow_keep(n * 4, (size_t)cap_n * 4, s); st->nidst.grow_keep(n * 4, (size_t)cap_n * 4, s);
-			st->svalid.ensure(n); st->sck.ensure(n); st->slen.ensure(n * 4); st->snm.ensure(n * 4); st->smk.ensure(n * BT_SUMMARY_MARKS * 8);
-			HIP_TRY(hipMemsetAsync(st->svalid.p, 0, n, s));
 			st->ndead.grow_keep(n, cap_n, s);
 			cap_n = (uint32_t)n;
 		}
@@ -1028,7 +1000,7 @@ void sbl_simplify_free(sbl_ctx *c)
 {
 	SimplifyState *st = c->simp;
 	if (!st) return;
-	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead, &st->svalid, &st->sck, &st->slen, &st->snm, &st->smk,
+	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
@@ -1090,8 +1062,6 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	SBL_CHECK(cap_n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
 	be.cap_n = (uint32_t)cap_n;
 	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nidst.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);
-	st->svalid.ensure(cap_n); st->sck.ensure(cap_n); st->slen.ensure(cap_n * 4); st->snm.ensure(cap_n * 4); st->smk.ensure(cap_n * BT_SUMMARY_MARKS * 8);
-	HIP_TRY(hipMemsetAsync(st->svalid.p, 0, cap_n, s));
 	size_t nidp = (size_t)be.nid_ + 1;
 	for (int t = 0; t < 2; t++) {
 		st->head[t].ensure(nidp * 4); st->lsize[t].ensure(nidp * 4);

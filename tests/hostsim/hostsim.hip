@@ -34,7 +34,6 @@ struct HostBackend {
 		for (int s = 0; s < 2; s++) { g.bif[s] = bif[s].data(); g.nodeof[s] = nodeof[s].data(); g.head[s] = head[s].data(); g.lsize[s] = lsize[s].data(); }
 		g.nslot = nslot.data(); g.nnext = nnext.data(); g.nidst = nidst.data(); g.nclr = nclr.data(); g.ndead = ndead.data();
 		g.ctr = ctr.data(); g.need = need.data(); g.big = big.data(); g.touch = touch.data();
-		g.svalid = nullptr; g.sck = nullptr; g.slen = nullptr; g.snm = nullptr; g.smk = nullptr;      // window summaries: kernels only
 		g.own = own.data(); g.lock = lock.data(); g.rmax = rmax.data(); g.wmax = wmax.data();
 		g.cap_e = (uint32_t)ch.size(); g.cap_n = (uint32_t)nslot.size();
 		g.nblk = (g.cap_e >> BT_BLOCK_SHIFT) + 1;
