@@ -605,24 +605,32 @@ __host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t d
 // every id whose forward window can see the rewritten region must be re-examined at its turn
 __host__ __device__ inline void bt_push_neighbourhood(Txn &t, SIt tstart, uint32_t newlen)
 {
-	uint32_t reach = t.g.D + t.g.k + 2, k = t.g.k;   // windows are scanned (and stamped) over D + k + 2 steps
-	// backwards from the target instance (opposite to its direction), then forwards across the region and beyond
-	SIt a = tstart;
-	a.d ^= 1;
-	for (uint32_t i = 0; i <= reach; i++) {
-		if (t.g.ch[a.e] == BT_SEP) break;
-		uint32_t b0 = t.g.bif[0][a.e], b1 = t.g.bif[1][a.e];
-		if (b0 != BT_NONE) t.push_dirty(b0);
-		if (b1 != BT_NONE) t.push_dirty(b1);
-		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
+	// Only instances walking TOWARDS the rewritten region can see it: upstream of the target that is the target's own
+	// strand, beyond the end of the region the opposite strand; inside the region both.
+	uint32_t reach = t.g.D + t.g.k + 2, k = t.g.k, d = tstart.d;   // windows are scanned (and stamped) over D + k + 2 steps
+	uint32_t e = d ? t.g.nx[tstart.e] : t.g.pv[tstart.e];
+	for (uint32_t i = 0; i < reach && e != BT_NONE; i++) {
+		if (t.g.ch[e] == BT_SEP) break;
+		uint32_t b = t.g.bif[d][e];
+		if (b != BT_NONE) t.push_dirty(b);
+		e = d ? t.g.nx[e] : t.g.pv[e];
 	}
-	a = tstart;
-	for (uint32_t i = 0; i <= newlen + 2 * k + reach; i++) {
-		if (t.g.ch[a.e] == BT_SEP) break;
-		uint32_t b0 = t.g.bif[0][a.e], b1 = t.g.bif[1][a.e];
+	e = tstart.e;
+	bool open = true;
+	for (uint32_t i = 0; i <= newlen + 2 * k; i++) {
+		if (t.g.ch[e] == BT_SEP) { open = false; break; }
+		uint32_t b0 = t.g.bif[0][e], b1 = t.g.bif[1][e];
 		if (b0 != BT_NONE) t.push_dirty(b0);
 		if (b1 != BT_NONE) t.push_dirty(b1);
-		a.e = a.d ? t.g.pv[a.e] : t.g.nx[a.e];
+		e = d ? t.g.pv[e] : t.g.nx[e];
+		if (e == BT_NONE) { open = false; break; }
+	}
+	for (uint32_t i = 0; open && i < reach; i++) {
+		if (t.g.ch[e] == BT_SEP) break;
+		uint32_t b = t.g.bif[d ^ 1][e];
+		if (b != BT_NONE) t.push_dirty(b);
+		e = d ? t.g.pv[e] : t.g.nx[e];
+		if (e == BT_NONE) break;
 	}
 }
 
@@ -821,7 +829,9 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 template <class F>
 __host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F f)
 {
-	uint32_t back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k;     // + 2: the scanned window length is D + k + 2
+	// core (what the transaction itself reads or writes): both strands; upstream: same strand only; further downstream:
+	// opposite strand only -- instances walking away from the core cannot see or touch it (k_reserve does the same)
+	uint32_t back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
 	f(id);
 	for (uint32_t s = 0; s < 2; s++)
 		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
@@ -830,6 +840,7 @@ __host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F 
 			for (uint32_t i = 0; i <= fwd; i++) {
 				if (i && g.ch[e] == BT_SEP) break;
 				uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
+				if (i >= core) { if (s) b1 = BT_NONE; else b0 = BT_NONE; }      // keep the opposite strand only
 				if (b0 != BT_NONE) f(b0);
 				if (b1 != BT_NONE) f(b1);
 				e = s ? g.pv[e] : g.nx[e];
@@ -838,9 +849,8 @@ __host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F 
 			e = s ? g.nx[e0] : g.pv[e0];
 			for (uint32_t i = 1; i <= back && e != BT_NONE; i++) {
 				if (g.ch[e] == BT_SEP) break;
-				uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
-				if (b0 != BT_NONE) f(b0);
-				if (b1 != BT_NONE) f(b1);
+				uint32_t b = g.bif[s][e];
+				if (b != BT_NONE) f(b);
 				e = s ? g.nx[e] : g.pv[e];
 			}
 		}

@@ -340,7 +340,8 @@ struct ClaimList { unsigned *buf; unsigned n; unsigned *seen; };
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
 template <class F>
-__device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane, F f)
+__device__ __forceinline__ unsigned wave_walk_marks(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
+                                                   unsigned strands /* bit s: report marks of strand s */, F f)
 {
 	unsigned cur = first, done = 0;
 	while (done < maxcount && cur != BT_NONE) {
@@ -349,7 +350,7 @@ __device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned fir
 		// all loads of the step are issued together (speculatively for lanes past a link break): one memory round trip per 64 elements
 		unsigned plink = inr && lane ? (dir ? g.pv[c + 1] : g.nx[c - 1]) : c;
 		unsigned chv = inr ? g.ch[c] : 0u;
-		unsigned b0 = inr ? g.bif[0][c] : BT_NONE, b1 = inr ? g.bif[1][c] : BT_NONE;
+		unsigned b0 = inr && (strands & 1u) ? g.bif[0][c] : BT_NONE, b1 = inr && (strands & 2u) ? g.bif[1][c] : BT_NONE;
 		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);      // intact prefix, >= 1
@@ -357,10 +358,11 @@ __device__ __forceinline__ void wave_walk_marks(const GraphView &g, unsigned fir
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
 		bool proc = lane < pre && lane < stop;
 		f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
-		if (stop < pre) break;
+		if (stop < pre) return BT_NONE;
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
 	}
+	return cur;                                                                  // the element after the last one visited (BT_NONE: end of chromosome)
 }
 
 __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
@@ -384,10 +386,10 @@ __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, un
 	cl.n += __popcll(m);
 }
 
-__device__ __forceinline__ void wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
-                                                ClaimList &cl, unsigned st)
+__device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
+                                                    unsigned strands, ClaimList &cl, unsigned st)
 {
-	wave_walk_marks(g, first, dir, maxcount, lane, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
+	return wave_walk_marks(g, first, dir, maxcount, lane, strands, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
 }
 
 // After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
@@ -428,8 +430,12 @@ __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsi
 		if (b0 != BT_NONE && b0 < g.nid) { g.touch[b0] = 1; if (b0 > id) g.need[b0] = 1; }
 		if (b1 != BT_NONE && b1 < g.nid) { g.touch[b1] = 1; if (b1 > id) g.need[b1] = 1; }
 	};
-	wave_walk_marks(g, e, d ^ 1u, reach + 1, lane, push);
-	wave_walk_marks(g, e, d, newlen + 2 * g.k + reach + 1, lane, push);
+	// Only instances walking TOWARDS the rewritten region can see it: upstream of the target that is the target's own
+	// strand, beyond the end of the region the opposite strand; inside the region both.
+	const unsigned own = 1u << d, opp = 1u << (d ^ 1u);
+	wave_walk_marks(g, d ? g.nx[e] : g.pv[e], d ^ 1u, reach, lane, own, push);
+	unsigned nxt = wave_walk_marks(g, e, d, newlen + 2 * g.k + 1, lane, 3u, push);
+	if (nxt != BT_NONE) wave_walk_marks(g, nxt, d, reach, lane, opp, push);
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
@@ -447,9 +453,13 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 	for (unsigned s = 0; s < 2; s++)
 		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
 			if (g.ndead[nd]) continue;
-			unsigned e0 = g.nslot[nd];
-			wave_walk_claim(g, e0, s, fwd + 1, lane, cl, st);
-			wave_walk_claim(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, cl, st);
+			// Who can interact with this instance: anything marked where the transaction itself reads or writes (core:
+			// D + 2k + 3 elements, both strands), instances upstream on the same strand and instances further downstream on
+			// the opposite strand (both walk towards the core); instances walking away from it cannot see or touch it.
+			unsigned e0 = g.nslot[nd], core = g.D + 2 * g.k + 3;
+			unsigned nxt = wave_walk_claim(g, e0, s, core, lane, 3u, cl, st);
+			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_claim(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), cl, st);
+			wave_walk_claim(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, cl, st);
 		}
 	if (lane == 0) cl.buf[0] = cl.n;
 }
