@@ -8,9 +8,12 @@ Inputs are resident in HBM when the timed region starts (sbl_restore_state is a 
 of the saved stage-boundary state and is inside the timed region).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 (launched through torch.distributed.run, one rank per GPU over RCCL): the bulge-removal order is
-global, so the path does not shard in this round -- every rank runs the whole job on its own strain set
-("replicas only", weak scaling, no data-path collective); value = strand-k-mers of all ranks / max time.
+N > 1 (launched through torch.distributed.run, one rank per GPU over RCCL): bulge removal is globally ordered
+and is >90 % of a stage, so by default every rank runs the whole job on its own strain set ("replicas",
+weak scaling, no data-path collective); value = strand-k-mers of all ranks / max time.
+--shard-enum runs ONE job on all ranks instead: the k-mer table of the enumeration is sharded by hash prefix
+(RCCL all-to-all of 16-B k-mer records + all-gathers of bifurcation codes and marks, csrc/shard.hip), the
+simplification runs replicated and bit-identical; value = strand-k-mers of the one job / max time ("strong").
 
 The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
@@ -42,6 +45,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--cpu-sample-L0", type=int, default=1_200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-enum", action="store_true", help="one job on all ranks: hash-prefix sharded enumeration over RCCL")
     ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
     a = ap.parse_args()
 
@@ -64,9 +68,15 @@ def main():
     from sibelia_amd import BlockFinder, workloads as W, dist as D
 
     # every rank owns its own strain set (same generator, rank-specific seed): independent jobs, no collective
-    seqs = W.gen_strains(**D.rank_workload(rank, a.strains, a.L0))
+    seqs = W.gen_strains(**D.rank_workload(0 if a.shard_enum else rank, a.strains, a.L0))
     N = W.strand_kmers(seqs, a.k)
     bf = BlockFinder(seqs, device=local)
+    if a.shard_enum:
+        if world > 1:
+            D.attach(bf, device=torch.device("cuda", local))
+        else:
+            from sibelia_amd.api import comm_unique_id
+            bf.attach_rccl(0, 1, comm_unique_id())
     if a.window:
         bf.set_window(a.window)
     bf.save_state()
@@ -93,6 +103,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     dt, Ntot = D.aggregate(dt, float(N), device="cuda" if world > 1 else None)
+    if a.shard_enum:
+        Ntot = float(N)                      # one job, however many GPUs enumerate it
 
     if rank == 0:
         st = bf.stats()
@@ -131,11 +143,14 @@ def main():
             "metric": "k-mers/sec in BlockFinder graph-build+simplify, 8xE.coli k=25",
             "value": Ntot / (dt / a.steps), "unit": "strand-k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "strong" if a.shard_enum else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1, 1%% SNP, indels, inversions), "
                                    "k=%d D=%d maxIterations=%d, one full stage" % (a.strains, a.L0 / 1e6, a.k, a.D, a.iters),
-                       "strand_kmers_per_gpu": N, "parallelism": "replicas only (x%d)" % world if world > 1 else "1 GPU",
+                       "strand_kmers_per_gpu": N,
+                       "parallelism": ("1 job: enumeration sharded by k-mer hash prefix over %d GPU(s) (RCCL all-to-all), simplification replicated" % world)
+                       if a.shard_enum else ("replicas (x%d), one job per GPU" % world if world > 1 else "1 GPU"),
+                       "exchange_ms": st["exchange_ms"], "exchange_bytes_rank0": st["exchange_bytes"],
                        "bulges": bulges, "bif_ids": st["bif_count"], "instances": st["instances"],
                        "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"]},
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},

@@ -69,6 +69,8 @@ typedef struct {
 	double probe_ms;
 	uint64_t executed;               /* pending ids examined in ordered rounds (retired by the probe or committed) */
 	uint64_t transactions;           /* ... of which RemoveBulges transactions that owned their neighbourhood and ran */
+	double exchange_ms;              /* sharded enumeration: host time inside the collectives (all-to-all + gathers) */
+	uint64_t exchange_bytes;         /* ... and the bytes this GPU sent to its peers */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).
@@ -110,6 +112,26 @@ sbl_status sbl_restore_state(sbl_ctx *ctx);
 sbl_status sbl_last_stats(const sbl_ctx *ctx, sbl_stage_stats *out);
 const char *sbl_last_error(const sbl_ctx *ctx);
 const char *sbl_strerror(sbl_status s);
+
+/* ---- Multi-GPU (one context per GPU).  The reference is a single-threaded CPU program with no
+ * counterpart; these entry points attach a communicator to a context, after which the enumeration inside
+ * sbl_enumerate / sbl_simplify_stage / sbl_list_edges (k <= 32) shards the k-mer table by hash prefix:
+ * every GPU scans a contiguous slice of base positions into a local pre-aggregating table, sends each distinct
+ * canonical k-mer (16-B record) to its owner GPU in ONE all-to-all, owners classify, the bifurcation codes and
+ * the resolved marks are all-gathered.  Simplification is globally ordered and runs replicated (bit-identical) on
+ * every attached GPU.  The calls are collective: every attached context must make them with the same arguments.
+ *   RCCL transport (one process or thread per GPU, xGMI): rank 0 calls sbl_comm_unique_id, the host distributes the
+ *   128 bytes (MPI, torch.distributed, a file), every rank calls sbl_comm_attach_rccl.
+ *   Local transport: contexts of ONE process driven by one host thread each (device-to-device copies);
+ *   used by the tests to run several virtual ranks on a single GPU. */
+#define SBL_COMM_ID_BYTES 128
+typedef struct sbl_group sbl_group;
+sbl_status sbl_comm_unique_id(void *id /* SBL_COMM_ID_BYTES */);
+sbl_status sbl_comm_attach_rccl(sbl_ctx *ctx, uint32_t rank, uint32_t nranks, const void *id);
+sbl_group *sbl_group_create_local(uint32_t nranks);
+void sbl_group_destroy(sbl_group *group);
+sbl_status sbl_comm_attach_local(sbl_ctx *ctx, sbl_group *group, uint32_t rank);
+sbl_status sbl_comm_detach(sbl_ctx *ctx);
 
 /* Tuning knob (0 = default): number of bifurcation ids speculatively committed per ordered round. */
 sbl_status sbl_set_window(sbl_ctx *ctx, uint32_t window);

@@ -32,7 +32,8 @@ class StageStats(C.Structure):
                 ("enumerate_ms", C.c_double), ("simplify_ms", C.c_double), ("copyback_ms", C.c_double), ("total_ms", C.c_double),
                 ("kmer_table_ms", C.c_double), ("kmer_table_bytes", C.c_uint64),
                 ("snapshot_ms", C.c_double), ("reserve_ms", C.c_double), ("commit_ms", C.c_double), ("probe_ms", C.c_double),
-                ("executed", C.c_uint64), ("transactions", C.c_uint64)]
+                ("executed", C.c_uint64), ("transactions", C.c_uint64),
+                ("exchange_ms", C.c_double), ("exchange_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -72,6 +73,14 @@ def load_library():
         L.sbl_set_window.argtypes = [C.c_void_p, C.c_uint32]
         L.sbl_save_state.argtypes = [C.c_void_p]
         L.sbl_restore_state.argtypes = [C.c_void_p]
+        L.sbl_comm_unique_id.argtypes = [C.c_void_p]
+        L.sbl_comm_attach_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.sbl_group_create_local.argtypes = [C.c_uint32]
+        L.sbl_group_create_local.restype = C.c_void_p
+        L.sbl_group_destroy.argtypes = [C.c_void_p]
+        L.sbl_group_destroy.restype = None
+        L.sbl_comm_attach_local.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.sbl_comm_detach.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -165,3 +174,68 @@ class BlockFinder:
 
     def set_window(self, w: int) -> None:
         self.L.sbl_set_window(self.h, w)
+
+    # ---- multi-GPU: hash-prefix sharded enumeration (include/sibelia_amd.h, csrc/shard.hip) ----
+    def attach_rccl(self, rank: int, nranks: int, unique_id: bytes) -> None:
+        """Collective over all ranks; unique_id = comm_unique_id() of rank 0, distributed by the host."""
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._check(self.L.sbl_comm_attach_rccl(self.h, rank, nranks, buf), "sbl_comm_attach_rccl")
+
+    def attach_local(self, group: "LocalGroup", rank: int) -> None:
+        self._group = group                         # keep the group alive as long as the context uses it
+        self._check(self.L.sbl_comm_attach_local(self.h, group.h, rank), "sbl_comm_attach_local")
+
+    def detach(self) -> None:
+        self._check(self.L.sbl_comm_detach(self.h), "sbl_comm_detach")
+        self._group = None
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    L = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = L.sbl_comm_unique_id(buf)
+    if rc:
+        raise SibeliaError("sbl_comm_unique_id: " + L.sbl_strerror(rc).decode())
+    return buf.raw
+
+
+class LocalGroup:
+    """Contexts of one process, one host thread per virtual rank (tests: several ranks on one GPU)."""
+
+    def __init__(self, nranks: int):
+        self.L = load_library()
+        self.n = nranks
+        self.h = C.c_void_p(self.L.sbl_group_create_local(nranks))
+        if not self.h:
+            raise SibeliaError("sbl_group_create_local failed")
+
+    def run(self, fns):
+        """Run one callable per rank concurrently (the calls are collective) and return their results."""
+        import threading
+        out, err = [None] * self.n, [None] * self.n
+
+        def body(i):
+            try:
+                out[i] = fns[i]()
+            except BaseException as e:          # noqa: BLE001 - reported to the caller below
+                err[i] = e
+        th = [threading.Thread(target=body, args=(i,)) for i in range(self.n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.sbl_group_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -168,10 +168,11 @@ __device__ __forceinline__ void tile_walk(const KmerTile &t, size_t tile, unsign
 static __global__ void __launch_bounds__(KM_THREADS) k_kmer_table_build(const unsigned long long *__restrict__ pk,
                                                                  const unsigned *__restrict__ sp, size_t nwords, size_t nelem,
                                                                  unsigned k, KmerSlot *__restrict__ table, unsigned long long capmask,
-                                                                 size_t ntiles, unsigned *__restrict__ used_count, unsigned *__restrict__ used_slots)
+                                                                 size_t tile_begin, size_t tile_end /* this GPU's slice of tiles */,
+                                                                 unsigned *__restrict__ used_count, unsigned *__restrict__ used_slots)
 {
 	__shared__ KmerTile t;
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	for (size_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
 		__syncthreads();
 		tile_load(t, pk, sp, tile, nwords);
 		__syncthreads();
@@ -270,6 +271,135 @@ static __global__ void __launch_bounds__(KM_THREADS) k_resolve_marks(const unsig
 			}
 		});
 	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hash-prefix sharded enumeration (shard.hip): every GPU scans a contiguous slice of tiles into a
+// local pre-aggregating table, ships each distinct canonical k-mer (code + masks) to the GPU that owns its hash
+// prefix, owners merge and classify, the bifurcation codes are gathered everywhere and ranked, and every GPU
+// resolves its own slice against the (small) bifurcation-only table.
+struct alignas(16) KmerRecord { unsigned long long key; unsigned int mask, pad; };
+
+__device__ __forceinline__ unsigned kmer_owner(unsigned long long canon, unsigned nranks)
+{
+	return (unsigned)(((kmer_hash(canon) >> 32) * (unsigned long long)nranks) >> 32);   // hash PREFIX: independent of the slot index (low bits)
+}
+
+// one pass per wave over distinct owners: leader reserves, lanes take consecutive places
+template <class F>
+__device__ __forceinline__ void wave_group_by(bool act, unsigned key, F f)
+{
+	unsigned long long todo = __ballot(act);
+	unsigned lane = threadIdx.x & 63;
+	while (todo) {
+		unsigned src = (unsigned)__builtin_ctzll(todo);
+		unsigned kk = __shfl(key, src);
+		unsigned long long m = __ballot(act && key == kk);
+		f(kk, m, act && key == kk, (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1)), lane == src);
+		todo &= ~m;
+	}
+}
+
+static __global__ void __launch_bounds__(256) k_shard_count(const KmerSlot *__restrict__ table, const unsigned *__restrict__ used_slots, unsigned nused,
+                                                     unsigned nranks, unsigned *__restrict__ counts)
+{
+	for (size_t u0 = (size_t)blockIdx.x * blockDim.x; u0 < nused; u0 += (size_t)gridDim.x * blockDim.x) {
+		size_t u = u0 + threadIdx.x;
+		bool act = u < nused;
+		unsigned o = act ? kmer_owner(table[used_slots[u]].key, nranks) : 0u;
+		wave_group_by(act, o, [&](unsigned kk, unsigned long long m, bool, unsigned, bool lead) {
+			if (lead) atomicAdd(&counts[kk], (unsigned)__builtin_popcountll(m));
+		});
+	}
+}
+
+static __global__ void __launch_bounds__(256) k_shard_scatter(const KmerSlot *__restrict__ table, const unsigned *__restrict__ used_slots, unsigned nused,
+                                                       unsigned nranks, const unsigned *__restrict__ offs, unsigned *__restrict__ cursor,
+                                                       KmerRecord *__restrict__ send)
+{
+	for (size_t u0 = (size_t)blockIdx.x * blockDim.x; u0 < nused; u0 += (size_t)gridDim.x * blockDim.x) {
+		size_t u = u0 + threadIdx.x;
+		bool act = u < nused;
+		KmerSlot sl; sl.key = 0; sl.mask = 0;
+		if (act) sl = table[used_slots[u]];
+		unsigned o = act ? kmer_owner(sl.key, nranks) : 0u;
+		wave_group_by(act, o, [&](unsigned kk, unsigned long long m, bool mine, unsigned place, bool lead) {
+			unsigned base = 0;
+			if (lead) base = atomicAdd(&cursor[kk], (unsigned)__builtin_popcountll(m));
+			base = __shfl(base, (unsigned)__builtin_ctzll(m));
+			if (mine) { KmerRecord r; r.key = sl.key; r.mask = sl.mask; r.pad = 0; send[(size_t)offs[kk] + base + place] = r; }
+		});
+	}
+}
+
+// owner side: OR the received masks into the owner's table
+static __global__ void __launch_bounds__(256) k_shard_merge(const KmerRecord *__restrict__ recv, size_t nrecv, KmerSlot *__restrict__ table,
+                                                     unsigned long long capmask, unsigned *__restrict__ used_count, unsigned *__restrict__ used_slots)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrecv; i += (size_t)gridDim.x * blockDim.x) {
+		KmerRecord r = recv[i];
+		unsigned long long h = kmer_hash(r.key) & capmask;
+		for (;;) {
+			unsigned long long old = atomicCAS(&table[h].key, SBL_EMPTY_KEY, r.key);
+			if (old == SBL_EMPTY_KEY) used_slots[atomicAdd(used_count, 1u)] = (unsigned)h;
+			if (old == SBL_EMPTY_KEY || old == r.key) { atomicOr(&table[h].mask, r.mask); break; }
+			h = (h + 1) & capmask;
+		}
+	}
+}
+
+// bifurcation-only table from the globally sorted strand-specific codes: slot.mask = id of the canonical code,
+// slot.aux = id of its reverse complement (the same id for a palindrome)
+static __global__ void __launch_bounds__(256) k_bif_table_build(const unsigned long long *__restrict__ skeys, unsigned nkeys, unsigned k,
+                                                         KmerSlot *__restrict__ table, unsigned long long capmask)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nkeys) return;
+	unsigned long long key = skeys[i], r = rc_code(key, k), canon = key < r ? key : r;
+	unsigned long long h = kmer_hash(canon) & capmask;
+	for (;;) {
+		unsigned long long old = atomicCAS(&table[h].key, SBL_EMPTY_KEY, canon);
+		if (old == SBL_EMPTY_KEY || old == canon) break;
+		h = (h + 1) & capmask;
+	}
+	if (key == canon) table[h].mask = i;
+	if (r == canon) table[h].aux = i;
+}
+
+// K5 against the bifurcation-only table, over this GPU's slice of tiles
+static __global__ void __launch_bounds__(KM_THREADS) k_resolve_marks_bif(const unsigned long long *__restrict__ pk, const unsigned *__restrict__ sp,
+                                                                  size_t nwords, size_t nelem, unsigned k,
+                                                                  const KmerSlot *__restrict__ table, unsigned long long capmask,
+                                                                  unsigned *__restrict__ bif0, unsigned *__restrict__ bif1,
+                                                                  size_t tile_begin, size_t tile_end)
+{
+	__shared__ KmerTile t;
+	for (size_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+		__syncthreads();
+		tile_load(t, pk, sp, tile, nwords);
+		__syncthreads();
+		tile_walk(t, tile, k, nelem, [&](size_t g, unsigned long long fwd, unsigned long long rev, unsigned, unsigned) {
+			unsigned long long canon = fwd < rev ? fwd : rev;
+			unsigned long long h = kmer_hash(canon) & capmask;
+			for (;;) {
+				KmerSlot sl = table[h];
+				if (sl.key == canon) {
+					bool o = fwd <= rev;
+					bif0[g] = o ? sl.mask : sl.aux;
+					bif1[g + k - 1] = o ? sl.aux : sl.mask;
+					break;
+				}
+				if (sl.key == SBL_EMPTY_KEY) break;     // not a bifurcation
+				h = (h + 1) & capmask;
+			}
+		});
+	}
+}
+
+static __global__ void __launch_bounds__(256) k_scatter_marks(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, size_t n, unsigned *__restrict__ bif)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) bif[elem[i]] = id[i];
 }
 
 // ---------------------------------------------------------------------------------------------

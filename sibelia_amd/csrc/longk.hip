@@ -130,28 +130,41 @@ __global__ void __launch_bounds__(256) k_lk_marks(const unsigned *__restrict__ s
 struct LongKScratch {
 	DevBuf rank[2], keys, skeys, idx, sidx, flag, scan, mask, gkeys, gmask, gcount, gbif, gid, tmp, sym;
 };
-static LongKScratch g_lk;       // grow-only scratch shared by all contexts of the process (calls are serialised per device queue)
+static LongKScratch &lk_of(sbl_ctx *c)      // grow-only scratch owned by the context (contexts may live on different devices / host threads)
+{
+	if (!c->lk) c->lk = new LongKScratch;
+	return *c->lk;
+}
+void sbl_longk_free(sbl_ctx *c)
+{
+	if (!c->lk) return;
+	LongKScratch &L = *c->lk;
+	for (DevBuf *b : { &L.rank[0], &L.rank[1], &L.keys, &L.skeys, &L.idx, &L.sidx, &L.flag, &L.scan, &L.mask, &L.gkeys, &L.gmask, &L.gcount, &L.gbif, &L.gid, &L.tmp, &L.sym })
+		b->release();
+	delete c->lk;
+	c->lk = nullptr;
+}
 
 static void lk_sort(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n)
 {
 	size_t tmp = 0;
 	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
-	g_lk.tmp.ensure(tmp);
-	HIP_TRY(rocprim::radix_sort_pairs(g_lk.tmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	lk_of(c).tmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(lk_of(c).tmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
 }
 static void lk_inclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
 {
 	size_t tmp = 0;
 	HIP_TRY(rocprim::inclusive_scan(nullptr, tmp, in, out, n, rocprim::plus<unsigned>(), c->stream));
-	g_lk.tmp.ensure(tmp);
-	HIP_TRY(rocprim::inclusive_scan(g_lk.tmp.p, tmp, in, out, n, rocprim::plus<unsigned>(), c->stream));
+	lk_of(c).tmp.ensure(tmp);
+	HIP_TRY(rocprim::inclusive_scan(lk_of(c).tmp.p, tmp, in, out, n, rocprim::plus<unsigned>(), c->stream));
 }
 static void lk_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
 {
 	size_t tmp = 0;
 	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
-	g_lk.tmp.ensure(tmp);
-	HIP_TRY(rocprim::exclusive_scan(g_lk.tmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
+	lk_of(c).tmp.ensure(tmp);
+	HIP_TRY(rocprim::exclusive_scan(lk_of(c).tmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
 }
 
 struct BitOr { __host__ __device__ unsigned operator()(unsigned a, unsigned b) const { return a | b; } };
@@ -162,7 +175,7 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	const size_t E = c->nelem, n = 2 * E - 1, np = n + k;             // 2L + 2 nchr + 1 = 2E - 1; padded with k '#'
 	SBL_CHECK(np < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "input too large for 32-bit suffix ranks");
 	c->cur_k = k;
-	LongKScratch &L = g_lk;
+	LongKScratch &L = lk_of(c);
 	for (int t = 0; t < 2; t++) L.rank[t].ensure((np + 1) * 4);
 	L.sym.ensure((np + 1) * 4);
 	L.keys.ensure(np * 8); L.skeys.ensure(np * 8); L.idx.ensure(np * 4); L.sidx.ensure(np * 4);

@@ -113,7 +113,8 @@ static void device_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }
+	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }      // long k: every GPU enumerates the whole input
+	if (c->comm) { sbl_run_enumeration_sharded(c, k, elem_capacity); return; }    // k-mer table sharded by hash prefix over the attached GPUs
 	hipStream_t s = c->stream;
 	size_t E = c->nelem, nwords = (E + 31) / 32;
 	size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
@@ -134,7 +135,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 8);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
 	k_kmer_table_build<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, ntiles,
+	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, (size_t)0, ntiles,
 	                                               c->d_counters.as<unsigned>() + 8, c->d_usedslots.as<unsigned>());
 	HIP_TRY(hipEventRecord(c->ev[1], s));
 	HIP_TRY(hipGetLastError());
@@ -208,26 +209,6 @@ void sbl_compact_marks(sbl_ctx *c, int strand)
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
-template <class F>
-static sbl_status guarded(sbl_ctx *c, F f)
-{
-	if (!c) return SBL_ERR_BAD_ARG;
-	try {
-		(void)hipSetDevice(c->device);
-		f();
-		return SBL_OK;
-	} catch (const SblError &e) {
-		c->err = e.msg;
-		return e.st;
-	} catch (const std::bad_alloc &) {
-		c->err = "host allocation failed";
-		return SBL_ERR_OOM;
-	} catch (...) {
-		c->err = "unexpected exception";
-		return SBL_ERR_INTERNAL;
-	}
-}
-
 extern "C" sbl_status sbl_create(sbl_ctx **out, int device)
 {
 	if (!out) return SBL_ERR_BAD_ARG;
@@ -251,7 +232,9 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	sbl_simplify_free(c);
-	DevBuf *bufs[] = { &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
+	sbl_comm_release(c);
+	sbl_longk_free(c);
+	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
 	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
 	for (DevBuf *b : bufs) b->release();

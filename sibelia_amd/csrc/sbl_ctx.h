@@ -53,6 +53,12 @@ struct sbl_ctx {
 	std::vector<sbl_inst> inst[2];
 	std::vector<sbl_edge> edges;
 
+	// ---- multi-GPU enumeration (shard.hip): attached communicator + exchange buffers
+	struct SblComm *comm = nullptr;
+	DevBuf d_send, d_recv, d_otable, d_oused, d_allkeys, d_allkeys2, d_gelem[2], d_gid[2], d_stage;
+
+	struct LongKScratch *lk = nullptr;   // k > 32 workspace (longk.hip)
+
 	// ---- simplification workspace lives in simplify.hip (opaque here)
 	struct SimplifyState *simp = nullptr;
 	uint32_t window = 0;
@@ -61,12 +67,37 @@ struct sbl_ctx {
 	hipEvent_t ev[8] = {};
 };
 
+// every ABI entry point runs under this: no exception crosses the boundary
+template <class F>
+static sbl_status guarded(sbl_ctx *c, F f)
+{
+	if (!c) return SBL_ERR_BAD_ARG;
+	try {
+		(void)hipSetDevice(c->device);
+		f();
+		return SBL_OK;
+	} catch (const SblError &e) {
+		c->err = e.msg;
+		return e.st;
+	} catch (const std::bad_alloc &) {
+		c->err = "host allocation failed";
+		return SBL_ERR_OOM;
+	} catch (...) {
+		c->err = "unexpected exception";
+		return SBL_ERR_INTERNAL;
+	}
+}
+
 // implemented in sbl_api.hip
 void sbl_pack(sbl_ctx *c);
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // fills d_bif[0..1], bif_count
 void sbl_compact_marks(sbl_ctx *c, int strand);
+// implemented in shard.hip
+void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k <= 32, c->comm attached: hash-prefix sharded table
+void sbl_comm_release(sbl_ctx *c);
 // implemented in longk.hip
 void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k > 32: exact rank doubling
+void sbl_longk_free(sbl_ctx *c);
 // implemented in simplify.hip
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
 void sbl_simplify_free(sbl_ctx *c);

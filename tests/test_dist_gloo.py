@@ -15,6 +15,9 @@ def _worker(rank, world, port, q):
     units = float(W.strand_kmers(seqs, 25))
     dist.barrier()
     dt, total = D.aggregate(0.5 + rank, units)
+    # the communicator id of the sharded enumeration travels from rank 0 to everyone (RCCL's id is opaque bytes)
+    uid = D.share_unique_id(lambda: bytes(range(128)))
+    assert uid == bytes(range(128))
     q.put((rank, kw["seed"], W.input_digest(seqs), units, dt, total))
     dist.barrier()
     dist.destroy_process_group()
