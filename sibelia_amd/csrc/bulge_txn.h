@@ -826,32 +826,47 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 // [a - (D+k), a + 2(D+k) + k] of each instance a of the id, directions relative to the instance.
 // Two transactions whose accessed elements or lists can interact always share at least one of
 // these ids (simplify.hip), so owning all of them isolates the transaction inside a round.
+// Reservation footprint of a transaction.  f(id, kind):
+//   kind 0  EXCLUSIVE: the id itself and every id marked in the core of an instance (what the transaction itself reads or
+//           writes, both strands): their instance lists may be rewritten, nobody else may claim them this round;
+//   kind 1  ORDERING: ids marked upstream on the same strand / further downstream on the opposite strand (instances walking
+//           TOWARDS the core; those walking away cannot see or touch it).  The transaction can only make them stale:
+//             x > id  it claims x (atomicMin) without needing to own it -- whoever is above x and can see x must wait;
+//             x < id  it must find x unclaimed by anything at or below x (x itself live, or a lower id that may wake x up),
+//                     see bt_order_blocked; x is not claimed (ids below the runner are never woken up by it).
+// k_reserve (simplify.hip) walks exactly the same elements with 64 lanes.
+__host__ __device__ inline bool bt_order_blocked(const GraphView &g, uint32_t x)
+{
+	uint32_t o = g.own[x];
+	return (o & ~0xFFFFFu) == g.round_bits && g.win[o & 0xFFFFFu] <= x;
+}
+
 template <class F>
 __host__ __device__ inline void bt_footprint(const GraphView &g, uint32_t id, F f)
 {
-	// core (what the transaction itself reads or writes): both strands; upstream: same strand only; further downstream:
-	// opposite strand only -- instances walking away from the core cannot see or touch it (k_reserve does the same)
 	uint32_t back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
-	f(id);
-	for (uint32_t s = 0; s < 2; s++)
-		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
-			if (g.ndead[nd]) continue;
-			uint32_t e0 = g.nslot[nd], e = e0;
-			for (uint32_t i = 0; i <= fwd; i++) {
-				if (i && g.ch[e] == BT_SEP) break;
-				uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
-				if (i >= core) { if (s) b1 = BT_NONE; else b0 = BT_NONE; }      // keep the opposite strand only
-				if (b0 != BT_NONE) f(b0);
-				if (b1 != BT_NONE) f(b1);
-				e = s ? g.pv[e] : g.nx[e];
-				if (e == BT_NONE) break;
+	f(id, 0u);
+	for (uint32_t pass = 0; pass < 2; pass++)                                   // all exclusive claims first (a claim list keeps the first kind it sees)
+		for (uint32_t s = 0; s < 2; s++)
+			for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+				if (g.ndead[nd]) continue;
+				uint32_t e0 = g.nslot[nd], e = e0;
+				for (uint32_t i = 0; i <= fwd; i++) {
+					if (i && g.ch[e] == BT_SEP) break;
+					uint32_t b0 = g.bif[0][e], b1 = g.bif[1][e];
+					if (i < core) { if (pass == 0) { if (b0 != BT_NONE) f(b0, 0u); if (b1 != BT_NONE) f(b1, 0u); } }
+					else if (pass == 1) { uint32_t b = s ? b0 : b1; if (b != BT_NONE) f(b, 1u); }   // opposite strand only
+					else break;
+					e = s ? g.pv[e] : g.nx[e];
+					if (e == BT_NONE) break;
+				}
+				if (pass == 0) continue;
+				e = s ? g.nx[e0] : g.pv[e0];
+				for (uint32_t i = 1; i <= back && e != BT_NONE; i++) {
+					if (g.ch[e] == BT_SEP) break;
+					uint32_t b = g.bif[s][e];
+					if (b != BT_NONE) f(b, 1u);
+					e = s ? g.nx[e] : g.pv[e];
+				}
 			}
-			e = s ? g.nx[e0] : g.pv[e0];
-			for (uint32_t i = 1; i <= back && e != BT_NONE; i++) {
-				if (g.ch[e] == BT_SEP) break;
-				uint32_t b = g.bif[s][e];
-				if (b != BT_NONE) f(b);
-				e = s ? g.nx[e] : g.pv[e];
-			}
-		}
 }

@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 // (an insertion or deletion made by an earlier collapse).  Visits exactly the elements bt_footprint visits.
 #define CLAIM_CAP 4096u                      // ids a window entry can list; beyond that commit re-walks serially
 
+#define RESUME_SLOTS 128u                   // instances whose core walk end is remembered for the ordering pass
 #define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
 struct ClaimList { unsigned *buf; unsigned n; unsigned *seen; };
 
@@ -383,6 +384,29 @@ __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, un
 	unsigned long long m = __ballot(has);
 	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
 	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b;
+	cl.n += __popcll(m);
+}
+
+// ordering claim (bt_footprint kind 1): ids above the runner are stamped without being listed, ids below it are listed
+// (flag bit 31) so that the commit check can see whether anything at or below them is about to run
+__device__ __forceinline__ void wave_claim_order(const GraphView &g, ClaimList &cl, unsigned st, unsigned id, unsigned b, unsigned lane)
+{
+	bool has = b != BT_NONE && b != id;
+	if (has) {
+		unsigned h = (b * 2654435761u) >> 21;
+		has = false;
+		for (int probe = 0; probe < 8; probe++) {
+			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
+			if (old == BT_NONE) { has = true; break; }
+			if (old == b) break;
+			h = (h + 1) & (SEEN_SLOTS - 1);
+			if (probe == 7) has = true;
+		}
+	}
+	if (has && b > id) { atomicMin(&g.own[b], st); has = false; }
+	unsigned long long m = __ballot(has);
+	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
+	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b | 0x80000000u;
 	cl.n += __popcll(m);
 }
 
@@ -449,17 +473,31 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 	unsigned id = g.win[w], st = g.round_bits | w;
 	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0; cl.seen = seen;
 	wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
-	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k;
+	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
+	// Who can interact with an instance: anything marked where the transaction itself reads or writes (core, both
+	// strands) -- claimed exclusively, the instance lists of those ids may be rewritten; instances upstream on the same
+	// strand and further downstream on the opposite strand walk towards the core -- the transaction can only make them
+	// stale, which orders it against them (bt_footprint, bulge_txn.h); instances walking away cannot see or touch it.
+	__shared__ unsigned resume[RESUME_SLOTS];
+	unsigned ninst = 0;
+	for (unsigned s = 0; s < 2; s++)                                  // all exclusive claims first: the seen-set keeps the first kind
+		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+			if (g.ndead[nd]) continue;
+			unsigned nxt = wave_walk_claim(g, g.nslot[nd], s, core, lane, 3u, cl, st);
+			if (lane == 0 && ninst < RESUME_SLOTS) resume[ninst] = nxt;
+			ninst++;
+		}
+	__syncthreads();
+	auto order = [&](unsigned b0, unsigned b1) { wave_claim_order(g, cl, st, id, b0, lane); wave_claim_order(g, cl, st, id, b1, lane); };
+	unsigned done = 0;
 	for (unsigned s = 0; s < 2; s++)
 		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
 			if (g.ndead[nd]) continue;
-			// Who can interact with this instance: anything marked where the transaction itself reads or writes (core:
-			// D + 2k + 3 elements, both strands), instances upstream on the same strand and instances further downstream on
-			// the opposite strand (both walk towards the core); instances walking away from it cannot see or touch it.
-			unsigned e0 = g.nslot[nd], core = g.D + 2 * g.k + 3;
-			unsigned nxt = wave_walk_claim(g, e0, s, core, lane, 3u, cl, st);
-			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_claim(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), cl, st);
-			wave_walk_claim(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, cl, st);
+			unsigned e0 = g.nslot[nd];
+			unsigned nxt = done < RESUME_SLOTS ? resume[done] : wave_walk_marks(g, e0, s, core, lane, 0u, [](unsigned, unsigned) {});
+			done++;
+			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
+			wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
 		}
 	if (lane == 0) cl.buf[0] = cl.n;
 }
@@ -638,7 +676,11 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		unsigned n = cb[0];
 		bool owner = true;
 		if (n <= CLAIM_CAP) {
-			for (unsigned i = lane; i < n; i += 64) if (g.own[cb[1 + i]] != stampv) owner = false;
+			for (unsigned i = lane; i < n; i += 64) {
+				unsigned b = cb[1 + i];
+				if (b & 0x80000000u) { if (bt_order_blocked(g, b & 0x7FFFFFFFu)) owner = false; }     // something at or below a lower id of the surroundings is about to run
+				else if (g.own[b] != stampv) owner = false;
+			}
 			owner = !__any(!owner);
 		} else {
 			if (lane == 0) owner = ss_owns_footprint(g, wi);      // list overflowed: serial re-walk

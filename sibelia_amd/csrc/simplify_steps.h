@@ -6,9 +6,11 @@
 //                 (replaces ~instances x (D-1) x iterations cache-cold window steps of the reference);
 //   2. ordered rounds over the ids that need to run (verdict true, or made stale by an earlier commit):
 //        select   the W lowest pending ids,
-//        reserve  each claims every id marked in its neighbourhood with atomicMin(round | rank),
-//        commit   a transaction that owns its whole neighbourhood runs RemoveBulges for real; ids whose
-//                 windows or lists it changed are marked pending if they are still ahead in the order.
+//        reserve  each claims the ids marked in its neighbourhood with atomicMin(round | rank): exclusively where it
+//                 reads or writes itself, as an ordering hint where it can only make a later id stale (bt_footprint),
+//        commit   a transaction that owns its core and finds nothing below it about to run in its surroundings runs
+//                 RemoveBulges for real; ids whose windows or lists it changed are marked pending if they are still
+//                 ahead in the order.
 //      A committed transaction is isolated inside its round (nobody else owns anything it can reach) and
 //      no lower pending id can reach what it touches, so the result equals the sequential order.
 //   3. validation: commits publish per-32-element-block and per-id read/write stamps; touching something
@@ -39,7 +41,7 @@ __host__ __device__ inline void ss_snapshot(const GraphView &g, uint32_t id, uin
 __host__ __device__ inline void ss_reserve(const GraphView &g, uint32_t widx)
 {
 	uint32_t id = g.win[widx], st = g.round_bits | widx;
-	bt_footprint(g, id, [&](uint32_t b) { bt_atomic_min(&g.own[b], st); });
+	bt_footprint(g, id, [&](uint32_t b, uint32_t kind) { if (kind == 0 || b > id) bt_atomic_min(&g.own[b], st); });
 }
 
 __host__ __device__ inline void ss_mark_big(const GraphView &g, uint32_t id)
@@ -102,7 +104,10 @@ __host__ __device__ inline bool ss_owns_footprint(const GraphView &g, uint32_t w
 {
 	uint32_t id = g.win[widx], st = g.round_bits | widx;
 	bool owner = true;
-	bt_footprint(g, id, [&](uint32_t b) { if (g.own[b] != st) owner = false; });
+	bt_footprint(g, id, [&](uint32_t b, uint32_t kind) {
+		if (kind == 0) { if (g.own[b] != st) owner = false; }
+		else if (b < id && g.own[b] != st && bt_order_blocked(g, b)) owner = false;      // (own == st: also in a core, claimed exclusively)
+	});
 	return owner;
 }
 

@@ -108,7 +108,12 @@ struct HostBackend {
 		for (uint32_t w : order(nwin)) {
 			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
-			bt_footprint(g, win[w], [&](uint32_t b) { bt_atomic_min(&g.own[b], st); claims[w].push_back(b); });
+			uint32_t me = win[w];
+			bt_footprint(g, me, [&](uint32_t b, uint32_t kind) {
+				if (kind == 0) { bt_atomic_min(&g.own[b], st); claims[w].push_back(b); }
+				else if (b > me) bt_atomic_min(&g.own[b], st);
+				else if (b < me) claims[w].push_back(b | 0x80000000u);
+			});
 		}
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
@@ -119,7 +124,10 @@ struct HostBackend {
 			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
 			bool owner = true;
-			for (uint32_t b : claims[w]) if (own[b] != st) { owner = false; break; }
+			for (uint32_t b : claims[w]) {
+				if (b & 0x80000000u) { uint32_t x = b & 0x7FFFFFFFu; if (own[x] != st && bt_order_blocked(g, x)) { owner = false; break; } }
+				else if (own[b] != st) { owner = false; break; }
+			}
 			uint32_t before = ctr[CTR_VIOL];
 			if (owner) ss_commit_run(g, w, arena.data(), arena_bytes, fastbuf, sizeof fastbuf);
 			if (getenv("HOSTSIM_DEBUG") && ctr[CTR_VIOL] != before) {
@@ -127,7 +135,7 @@ struct HostBackend {
 				fprintf(stderr, "[dbg] violation while committing id %u (widx %u)\n", a, w);
 				for (uint32_t x = 0; x < nwin; x++) {
 					if (x == w) continue;
-					bool xo = true; for (uint32_t b : claims[x]) if (own[b] != (g.round_bits | x)) { xo = false; break; }
+					bool xo = true; for (uint32_t b : claims[x]) if (!(b & 0x80000000u) && own[b] != (g.round_bits | x)) { xo = false; break; }
 					if (!xo) continue;
 					uint32_t b = win[x];
 					bool near = false;
