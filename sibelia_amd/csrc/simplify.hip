@@ -164,7 +164,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 	for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 	__syncthreads();
 	const unsigned D = g.D, k = g.k;
-	unsigned total = 0;
+	unsigned distinct = 0;                                             // occupied slots (homologous instances repeat the same ids)
 	bool found = false;
 	for (unsigned i = 0; i < w.n; i++) {
 		const unsigned len = w.wlen[i];
@@ -180,13 +180,14 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 			bool stop = j >= nm || step >= lim || b == start;
 			unsigned long long ms = __ballot(stop);
 			unsigned upto = ms ? (unsigned)__builtin_ctzll(ms) : 64u;    // marks before the first stop condition
-			total += upto;
-			if (total > VT_SLOTS / 2) return -1;
+			if (distinct + upto > (VT_SLOTS * 3) / 4) return -1;         // the table could fill up
+			bool fresh = false;
 			if (lane < upto) {
 				unsigned h = (b * 2654435761u) >> 23;                    // 9 bits
 				for (;;) {
 					unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
 					if (old == BT_NONE || old == b) {
+						fresh = old == BT_NONE;
 						unsigned m = atomicOr(&vt.mask[h], bit) | bit;
 						if (m & (m - 1)) found = true;
 						break;
@@ -194,6 +195,8 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 					h = (h + 1) & (VT_SLOTS - 1);
 				}
 			}
+			distinct += (unsigned)__popcll(__ballot(fresh));
+			if (__any(found)) return 1;                                  // a second member for some group: verdict reached
 			if (upto < 64) break;
 		}
 	}
