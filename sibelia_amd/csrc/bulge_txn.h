@@ -324,6 +324,15 @@ __host__ __device__ inline void bt_sort_u32(uint32_t *a, uint32_t n)
 // AnyBulges result: group g's members are grp_mem[grp_off[g] .. grp_off[g+1]), in unordered_map iteration order.
 struct AnyBulgesOut { uint32_t ngroups; uint32_t *grp_off; uint32_t *grp_mem; };
 
+// AnyBulges under construction: the Boost-ordered map + per-entry member lists (a log of instances chained per entry)
+struct ABuild {
+	BoostMap m;
+	char *echar;
+	uint32_t *mhead, *mtail, *mcnt, *log_inst, *log_next;
+	uint32_t logcap, nlog;
+	bool any;
+};
+
 struct BulgeWork {
 	uint32_t n;                  // instances of the id
 	uint32_t *start;             // (node << 1) | strand, list order: + list then - list (ListPositions, bifurcationstorage.h:59-72)
@@ -346,6 +355,7 @@ struct BulgeWork {
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
 	AnyBulgesOut ab;
+	ABuild abb;
 	// resumable loop state of RemoveBulges (a collapse interrupts the loops for a window rescan)
 	uint32_t gi, idI, idJ, ret;
 	bool inI, need_fill;
@@ -684,15 +694,16 @@ __host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK,
 }
 
 // AnyBulges (bulgeremoval.cpp:158-218) into a BoostMap + per-entry member lists, reading the window cache.
-// verdict_only: stop at the first group that gets a second member.
-__host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict_only)
+// The map-building loop exists twice: bt_any_bulges below (one thread) and wave_any_bulges in simplify.hip (64 lanes skip
+// the look-ups that change nothing); both go through bt_ab_prepare / bt_ab_insert / bt_ab_append / bt_ab_finish, so the
+// sequence of operator[] insertions -- and with it the iteration order -- is the same.
+// cap: upper bound of the number of distinct ids that get an entry (the total number of marks is always one).
+__host__ __device__ inline bool bt_ab_prepare(Txn &t, BulgeWork &w, uint32_t cap)
 {
-	uint32_t D = t.g.D, n = w.n;
-	// capacity: the number of marks in the windows bounds the number of map entries; it goes to the fast scratch
-	// (LDS) when it fits there, otherwise the map takes whatever arena is left
-	uint32_t marks = 0;
-	for (uint32_t i = 0; i < n; i++) marks += w.wmn[i];
-	uint32_t cap = marks < 16 ? 16 : marks;
+	ABuild &a = w.abb;
+	uint32_t n = w.n;
+	if (cap < 16) cap = 16;
+	// the map goes to the fast scratch (LDS) when it fits there, otherwise it takes whatever arena is left
 	bool fast = t.fscr && (t.fscr_cap - ((t.fscr_used + 7u) & ~7u)) / 48 >= cap + n / 2 + 2;
 	if (!fast) {
 		uint32_t left = t.scr_cap - ((t.scr_used + 7u) & ~7u);
@@ -703,17 +714,69 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	uint32_t bcap = bt_new_bucket_count(cap + 1);
 	if (bcap > 2 * cap) bcap >>= 1;
 	if (bcap < 16) bcap = 16;
-	BoostMap m;
+	BoostMap &m = a.m;
 	auto A = [&](uint32_t bytes) { return fast ? t.alloc2(bytes) : t.alloc(bytes); };
 	m.key = (uint32_t *)A(cap * 4); m.nxt = (int32_t *)A(cap * 4); m.bprev = (int32_t *)A(bcap * 4);
-	char *echar = (char *)A(cap);
-	uint32_t *mhead = (uint32_t *)A(cap * 4), *mtail = (uint32_t *)A(cap * 4), *mcnt = (uint32_t *)A(cap * 4);
-	uint32_t logcap = cap + n;
-	uint32_t *log_inst = (uint32_t *)A(logcap * 4), *log_next = (uint32_t *)A(logcap * 4);
+	a.echar = (char *)A(cap);
+	a.mhead = (uint32_t *)A(cap * 4); a.mtail = (uint32_t *)A(cap * 4); a.mcnt = (uint32_t *)A(cap * 4);
+	a.logcap = cap + n;
+	a.log_inst = (uint32_t *)A(a.logcap * 4); a.log_next = (uint32_t *)A(a.logcap * 4);
 	if (t.err) return false;
 	m.size = 0; m.cap = cap; m.bc = 0; m.bcap = bcap; m.first = -1; m.started = false;
-	uint32_t nlog = 0;
-	bool any = false;
+	a.nlog = 0; a.any = false;
+	return true;
+}
+// id b is reached by instance i and has no entry yet: operator[] creates it.  Returns the entry or -1 (scratch exhausted).
+__host__ __device__ inline int32_t bt_ab_insert(Txn &t, BulgeWork &w, uint32_t i, uint32_t b)
+{
+	ABuild &a = w.abb;
+	int32_t kt = bm_insert(a.m, b);
+	if (kt < 0 || a.nlog >= a.logcap) { t.err |= BT_ERR_SCRATCH; return -1; }
+	a.echar[kt] = w.endc[i];
+	a.log_inst[a.nlog] = i; a.log_next[a.nlog] = BT_NONE;
+	a.mhead[kt] = a.mtail[kt] = a.nlog++; a.mcnt[kt] = 1;
+	return kt;
+}
+// instance i reaches entry kt, whose endChar differs: second (or later) member of the bulge group
+__host__ __device__ inline bool bt_ab_append(Txn &t, BulgeWork &w, uint32_t i, int32_t kt)
+{
+	ABuild &a = w.abb;
+	if (a.nlog >= a.logcap) { t.err |= BT_ERR_SCRATCH; return false; }
+	a.log_inst[a.nlog] = i; a.log_next[a.nlog] = BT_NONE;
+	a.log_next[a.mtail[kt]] = a.nlog; a.mtail[kt] = a.nlog++; a.mcnt[kt]++;
+	a.any = true;
+	return true;
+}
+// groups with more than one member, in unordered_map iteration order
+__host__ __device__ inline bool bt_ab_finish(Txn &t, BulgeWork &w)
+{
+	ABuild &a = w.abb;
+	BoostMap &m = a.m;
+	if (!a.any) return false;
+	uint32_t ng = 0, total = 0;
+	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (a.mcnt[p] > 1) { ng++; total += a.mcnt[p]; }
+	w.ab.grp_off = (uint32_t *)t.alloc2((ng + 1) * 4);
+	w.ab.grp_mem = (uint32_t *)t.alloc2(total * 4);
+	if (t.err) return false;
+	uint32_t gi = 0, o = 0;
+	for (int32_t p = m.first; p != -1; p = m.nxt[p]) {
+		if (a.mcnt[p] <= 1) continue;
+		w.ab.grp_off[gi++] = o;
+		for (uint32_t l = a.mhead[p]; l != BT_NONE; l = a.log_next[l]) w.ab.grp_mem[o++] = a.log_inst[l];
+	}
+	w.ab.grp_off[gi] = o;
+	w.ab.ngroups = ng;
+	return true;
+}
+
+// verdict_only: stop at the first group that gets a second member.
+__host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict_only)
+{
+	uint32_t D = t.g.D, n = w.n;
+	uint32_t marks = 0;
+	for (uint32_t i = 0; i < n; i++) marks += w.wmn[i];
+	if (!bt_ab_prepare(t, w, marks)) return false;
+	ABuild &a = w.abb;
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
 		const uint64_t *mk = w.wmk + (size_t)i * w.mks;
@@ -721,38 +784,17 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 		for (uint32_t j = 0; j < nm; j++) {
 			uint32_t b = (uint32_t)mk[j];
 			if ((uint32_t)(mk[j] >> 32) >= lim || b == start) break;
-			int32_t kt = bm_find(m, b);
-			if (kt < 0) {
-				kt = bm_insert(m, b);
-				if (kt < 0 || nlog >= logcap) { t.err |= BT_ERR_SCRATCH; return false; }
-				echar[kt] = w.endc[i];
-				log_inst[nlog] = i; log_next[nlog] = BT_NONE;
-				mhead[kt] = mtail[kt] = nlog++; mcnt[kt] = 1;
-			} else if (echar[kt] != w.endc[i]) {
-				if (nlog >= logcap) { t.err |= BT_ERR_SCRATCH; return false; }
-				log_inst[nlog] = i; log_next[nlog] = BT_NONE;
-				log_next[mtail[kt]] = nlog; mtail[kt] = nlog++; mcnt[kt]++;
-				any = true;
+			int32_t kt = bm_find(a.m, b);
+			if (kt < 0) { if (bt_ab_insert(t, w, i, b) < 0) return false; }
+			else if (a.echar[kt] != w.endc[i]) {
+				if (!bt_ab_append(t, w, i, kt)) return false;
 				if (verdict_only) return true;
 				break;
 			}
 		}
 	}
-	if (!any || verdict_only) return any;
-	uint32_t ng = 0, total = 0;
-	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (mcnt[p] > 1) { ng++; total += mcnt[p]; }
-	w.ab.grp_off = (uint32_t *)t.alloc2((ng + 1) * 4);
-	w.ab.grp_mem = (uint32_t *)t.alloc2(total * 4);
-	if (t.err) return false;
-	uint32_t gi = 0, o = 0;
-	for (int32_t p = m.first; p != -1; p = m.nxt[p]) {
-		if (mcnt[p] <= 1) continue;
-		w.ab.grp_off[gi++] = o;
-		for (uint32_t l = mhead[p]; l != BT_NONE; l = log_next[l]) w.ab.grp_mem[o++] = log_inst[l];
-	}
-	w.ab.grp_off[gi] = o;
-	w.ab.ngroups = ng;
-	return true;
+	if (!a.any || verdict_only) return a.any;
+	return bt_ab_finish(t, w);
 }
 
 // RemoveBulges, bulgeremoval.cpp:330-430, as a resumable routine over the window cache.
@@ -760,10 +802,10 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 //   bt_rb_run:   runs the group / I / J loops until a collapse has been decided (returns true: the caller performs
 //                CollapseBulgeGreedily(c_src -> c_tgt), rescans the windows and calls again) or everything is done
 //                (returns false, Cleanup performed).
-__host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w)
+__host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w, int any_bulges = -1 /* >= 0: AnyBulges already evaluated by the caller */)
 {
-	bt_end_chars(t, w);
-	if (!bt_any_bulges(t, w, false)) return false;
+	if (any_bulges < 0) { bt_end_chars(t, w); any_bulges = bt_any_bulges(t, w, false) ? 1 : 0; }
+	if (!any_bulges) return false;
 	t.iw(t.id);
 	w.gi = 0; w.idI = w.ab.grp_off[0]; w.idJ = 0; w.ret = 0; w.inI = false; w.need_fill = false;
 	return true;
@@ -822,10 +864,6 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 }
 
 // ------------------------------------------------------------------------------------------- reservation footprint
-// Calls f(b) for the transaction's own id and for every id marked (either strand) within
-// [a - (D+k), a + 2(D+k) + k] of each instance a of the id, directions relative to the instance.
-// Two transactions whose accessed elements or lists can interact always share at least one of
-// these ids (simplify.hip), so owning all of them isolates the transaction inside a round.
 // Reservation footprint of a transaction.  f(id, kind):
 //   kind 0  EXCLUSIVE: the id itself and every id marked in the core of an instance (what the transaction itself reads or
 //           writes, both strands): their instance lists may be rewritten, nobody else may claim them this round;

@@ -658,6 +658,130 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 	__syncthreads();
 }
 
+// ---- AnyBulges with 64 lanes (writer pass) --------------------------------------------------------------------
+// bt_any_bulges looks every mark of every window up in the Boost-ordered map; for homologous instances nearly all of
+// those look-ups change nothing (the id has an entry with the same endChar).  Here the lanes classify 64 marks at a time
+// against a small shadow table (id -> entry, endChar) and only the marks that DO something -- a new entry, or the first
+// entry with a different endChar, which also ends the instance -- reach lane 0, in the same order as in the serial loop.
+// A first pass counts the distinct ids so that the map is sized by them (it then usually fits the LDS scratch) instead of
+// by the total number of marks.  Falls back to bt_any_bulges when the tables do not fit.
+struct ABShared { unsigned *skey, *sval; unsigned bits, distinct; int mode; };   // mode 0: serial fallback, 1: wave path
+
+#define AB_COUNT_SLOTS 512u
+__device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane)
+{
+	const unsigned D = g.D, n = w.n;
+	unsigned mark = 0;
+	if (lane == 0) {
+		bt_end_chars(t, w);
+		mark = t.fscr_used;
+		sh.skey = (unsigned *)t.falloc(AB_COUNT_SLOTS * 4);
+		sh.mode = sh.skey ? 1 : 0;
+	}
+	__syncthreads();
+	if (sh.mode) {
+		// ---- pass 1: number of distinct ids that can get an entry
+		for (unsigned i = lane; i < AB_COUNT_SLOTS; i += 64) sh.skey[i] = BT_NONE;
+		__syncthreads();
+		unsigned distinct = 0;
+		bool full = false;
+		for (unsigned i = 0; i < n && !full; i++) {
+			if (w.endc[i] == ' ') continue;
+			const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
+			const unsigned start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+			for (unsigned j0 = 0; j0 < nm; j0 += 64) {
+				unsigned j = j0 + lane;
+				unsigned long long v = j < nm ? mk[j] : ~0ull;
+				unsigned b = (unsigned)v;
+				bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
+				unsigned long long ms = __ballot(stop);
+				unsigned upto = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+				if (distinct + upto > (AB_COUNT_SLOTS * 3) / 4) { full = true; break; }
+				bool fresh = false;
+				if (lane < upto) {
+					unsigned h = (b * 2654435761u) >> 23;
+					for (;;) {
+						unsigned old = atomicCAS(&sh.skey[h], BT_NONE, b);
+						if (old == BT_NONE || old == b) { fresh = old == BT_NONE; break; }
+						h = (h + 1) & (AB_COUNT_SLOTS - 1);
+					}
+				}
+				distinct += (unsigned)__popcll(__ballot(fresh));
+				if (upto < 64) break;
+			}
+		}
+		__syncthreads();
+		if (lane == 0) {
+			t.fscr_used = mark;                                        // the counting set is done
+			if (full) sh.mode = 0;
+			else {
+				unsigned bits = 6;
+				while ((1u << bits) < 2 * distinct + 2) bits++;
+				sh.bits = bits; sh.distinct = distinct;
+				sh.skey = (unsigned *)t.alloc2((2u << bits) * 4);
+				sh.sval = sh.skey ? sh.skey + (1u << bits) : nullptr;
+				if (!sh.skey || !bt_ab_prepare(t, w, distinct)) sh.mode = -1;
+			}
+		}
+		__syncthreads();
+	}
+	if (sh.mode < 0) return 0;                                             // t.err is set
+	if (sh.mode == 0) {                                                    // tables do not fit: one thread, map sized by the total number of marks
+		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
+		__syncthreads();
+		return sh.mode == 3;
+	}
+	// ---- pass 2: build the map; lanes skip what changes nothing
+	const unsigned slots = 1u << sh.bits, shift = 32 - sh.bits;
+	for (unsigned i = lane; i < slots; i += 64) { sh.skey[i] = BT_NONE; sh.sval[i] = BT_NONE; }
+	__syncthreads();
+	bool bad = false;
+	for (unsigned i = 0; i < n && !bad; i++) {
+		const char ec = w.endc[i];
+		if (ec == ' ') continue;
+		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
+		const unsigned start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+		unsigned pos = 0;
+		while (pos < nm) {
+			unsigned j = pos + lane;
+			unsigned long long v = j < nm ? mk[j] : ~0ull;
+			unsigned b = (unsigned)v;
+			bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
+			unsigned long long ms = __ballot(stop);
+			unsigned upto = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			unsigned ev = 0, val = BT_NONE, h = 0;
+			if (lane < upto) {
+				h = (b * 2654435761u) >> shift;
+				for (;;) {
+					unsigned kk = sh.skey[h];
+					if (kk == b) { val = sh.sval[h]; ev = (char)(val & 0xFFu) != ec ? 2u : 0u; break; }
+					if (kk == BT_NONE) { ev = 1u; break; }                 // no entry yet (h = where the shadow entry goes)
+					h = (h + 1) & (slots - 1);
+				}
+			}
+			unsigned long long em = __ballot(ev != 0);
+			if (!em) { if (upto < 64) break; pos += 64; continue; }
+			unsigned f = (unsigned)__builtin_ctzll(em);
+			unsigned eev = __shfl(ev, f), eb = __shfl(b, f), eh = __shfl(h, f), evl = __shfl(val, f);
+			if (lane == 0) {
+				if (eev == 1u) {
+					int kt = bt_ab_insert(t, w, i, eb);
+					if (kt < 0) sh.mode = -1;
+					else { sh.skey[eh] = eb; sh.sval[eh] = ((unsigned)kt << 8) | (unsigned char)ec; }
+				} else if (!bt_ab_append(t, w, i, (int)(evl >> 8))) sh.mode = -1;
+			}
+			__syncthreads();
+			if (sh.mode < 0) { bad = true; break; }
+			if (eev == 2u) break;                                          // the instance joined a group: next instance
+			pos += f + 1;
+		}
+	}
+	if (bad) return 0;
+	if (lane == 0) sh.mode = bt_ab_finish(t, w) ? 3 : 2;
+	__syncthreads();
+	return sh.mode == 3;
+}
+
 __device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
 #define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
@@ -669,6 +793,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
 	__shared__ int flag;
+	__shared__ ABShared absh;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
@@ -728,7 +853,8 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			__syncthreads();
 		}
 		PH_ADD(1);
-		if (lane == 0) flag = bt_rb_begin(t, w) && !t.err ? 1 : 0;
+		int any = wave_any_bulges(g, t, w, absh, lane);
+		if (lane == 0) flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0;
 		__syncthreads();
 		PH_ADD(2);
 		while (flag) {
