@@ -560,48 +560,66 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		if (i < k + dT) { unsigned e = T[i]; if (i > 0) wave_erase(g, t, d, e, stampv); wave_erase(g, t, opp, e, stampv); }
 	}
 	__syncthreads();
-	// ---- DNASequence::Replace in + coordinates: P(j) = j-th element of the old span, C(j) = j-th new character
+	// ---- DNASequence::Replace in + coordinates: P(j) = j-th element of the old span, C(j) = j-th new character.
+	// All lanes: character writes, the new elements of an insertion and the position interpolation (the sequence
+	// acc += ssize of dnasequence.cpp:221-227 is replayed in registers, every lane keeps the value of its own step).
 	__shared__ unsigned s_newbase;
 	const unsigned common = dS < dT ? dS : dT;
+	auto P = [&](unsigned jx) { return d == 0 ? T[k + jx] : T[k + dT - 1 - jx]; };
+	auto OC = [&](unsigned x) { char c = (char)w.wch[(size_t)src * ws + x]; return ds ? bt_comp(c) : c; };
+	auto C = [&](unsigned jx) { return d == 0 ? OC(k + jx) : bt_comp(OC(k + dS - 1 - jx)); };
+	const unsigned Eafter = d == 0 ? T[k + dT] : T[k - 1];
+	const unsigned firstPos = g.op[P(0)] & BT_POS_MASK, lastPos = g.op[Eafter] & BT_POS_MASK;
 	if (lane == 0) {
 		t.wrote = true;
-		auto P = [&](unsigned j) { return d == 0 ? T[k + j] : T[k + dT - 1 - j]; };
-		auto OC = [&](unsigned x) { char c = (char)w.wch[(size_t)src * ws + x]; return ds ? bt_comp(c) : c; };
-		auto C = [&](unsigned j) { return d == 0 ? OC(k + j) : bt_comp(OC(k + dS - 1 - j)); };
-		const unsigned Eafter = d == 0 ? T[k + dT] : T[k - 1];
-		const unsigned firstPos = g.op[P(0)] & BT_POS_MASK, lastPos = g.op[Eafter] & BT_POS_MASK;
 		unsigned newbase = BT_NONE;
-		for (unsigned j = 0; j < common; j++) g.ch[P(j)] = (uint8_t)C(j);
-		if (dS < dT) {
-			for (unsigned j = dS; j < dT; j++) g.ch[P(j)] = BT_DEAD_CHAR;
-			unsigned before = P(dS - 1);
-			g.nx[before] = Eafter; g.pv[Eafter] = before;
-		} else if (dS > dT) {
-			unsigned m = dS - dT, span = (m + 31u) & ~31u;
+		if (dS > dT) {
+			unsigned span = (dS - dT + 31u) & ~31u;
 			unsigned base = atomicAdd(&g.ctr[CTR_NE], span);
-			if (base + span > g.cap_e) t.err |= BT_ERR_ELEM_CAP;
-			else {
-				unsigned before = P(dT - 1);
-				for (unsigned i = 0; i < span; i++) {
-					unsigned ne = base + i;
-					g.bif[0][ne] = g.bif[1][ne] = BT_NONE;
-					if (i < m) { g.ch[ne] = (uint8_t)C(dT + i); g.op[ne] = 0; g.nx[before] = ne; g.pv[ne] = before; before = ne; }
-					else g.ch[ne] = BT_DEAD_CHAR;
-				}
-				g.nx[before] = Eafter; g.pv[Eafter] = before;
-				newbase = base;
-			}
-		}
-		if (!t.err) {
-			double acc = (double)firstPos, ssize = (double)dT / (double)dS;     // dnasequence.cpp:221-227, same operation order
-			for (unsigned j = 0; j < dS; j++, acc += ssize) {
-				unsigned long long p = (unsigned long long)acc;
-				if (p > lastPos) p = lastPos;
-				unsigned e = j < common ? P(j) : newbase + (j - dT);
-				g.op[e] = (unsigned)p & BT_POS_MASK;
-			}
+			if (base + span > g.cap_e) t.err |= BT_ERR_ELEM_CAP; else newbase = base;
 		}
 		s_newbase = newbase;
+	}
+	__syncthreads();
+	if (t.err) return;
+	{
+		const unsigned nb = s_newbase;
+		for (unsigned j0 = 0; j0 < (dS < dT ? dT : common); j0 += 64) {
+			unsigned jx = j0 + lane;
+			if (jx < common) g.ch[P(jx)] = (uint8_t)C(jx);
+			else if (jx < dT) g.ch[P(jx)] = BT_DEAD_CHAR;                 // deletion: the tail of the old span dies
+		}
+		if (dS < dT) {
+			if (lane == 0) { unsigned before = P(dS - 1); g.nx[before] = Eafter; g.pv[Eafter] = before; }
+		} else if (dS > dT) {
+			const unsigned m = dS - dT, span = (m + 31u) & ~31u, before0 = P(dT - 1);
+			for (unsigned i0 = 0; i0 < span; i0 += 64) {
+				unsigned i = i0 + lane;
+				if (i >= span) break;
+				unsigned ne = nb + i;
+				g.bif[0][ne] = BT_NONE; g.bif[1][ne] = BT_NONE;
+				if (i < m) {
+					g.ch[ne] = (uint8_t)C(dT + i); g.op[ne] = 0;
+					g.pv[ne] = i ? ne - 1 : before0;
+					g.nx[ne] = i + 1 < m ? ne + 1 : Eafter;
+				} else g.ch[ne] = BT_DEAD_CHAR;
+			}
+			if (lane == 0) { g.nx[before0] = nb; g.pv[Eafter] = nb + m - 1; }
+		}
+		double acc = (double)firstPos;
+		const double ssize = (double)dT / (double)dS;
+		for (unsigned j0 = 0; j0 < dS; j0 += 64) {
+			const unsigned cnt = dS - j0 < 64u ? dS - j0 : 64u;
+			double mine = 0.0;
+			for (unsigned jj = 0; jj < cnt; jj++) { if (jj == lane) mine = acc; acc += ssize; }
+			unsigned jx = j0 + lane;
+			if (jx < dS) {
+				unsigned long long pp = (unsigned long long)mine;
+				if (pp > lastPos) pp = lastPos;
+				unsigned e = jx < common ? P(jx) : nb + (jx - dT);
+				g.op[e] = (unsigned)pp & BT_POS_MASK;
+			}
+		}
 	}
 	__syncthreads();
 	if (t.err) return;
@@ -642,19 +660,65 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		}
 	__syncthreads();
 	if (t.err) return;
-	if (lane == 0) {
-		unsigned nd = s_nodebase;
-		// first loop: restore the flanks (merge of the two index-sorted lists, look-back before look-forward at equal index)
-		unsigned a = 0, b = 0;
-		while (a < nlb || b < nlf) {
-			bool takeA = b >= nlf || (a < nlb && w.lb[2 * a] <= w.lf[2 * b]);
-			SIt p;
-			if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point_prepared(p, w.lb[2 * a + 1], nd++); a++; }
-			else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point_prepared(p, w.lf[2 * b + 1], nd++); b++; }
+	if (total > 64) {
+		if (lane == 0) {
+			unsigned nd = s_nodebase;
+			// first loop: restore the flanks (merge of the two index-sorted lists, look-back before look-forward at equal index)
+			unsigned a = 0, b = 0;
+			while (a < nlb || b < nlf) {
+				bool takeA = b >= nlf || (a < nlb && w.lb[2 * a] <= w.lf[2 * b]);
+				SIt p;
+				if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point_prepared(p, w.lb[2 * a + 1], nd++); a++; }
+				else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point_prepared(p, w.lf[2 * b + 1], nd++); b++; }
+			}
+			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
 		}
-		for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
-		t.push_e = T[0]; t.push_d = d; t.push_len = dS;
+	} else {
+		// One AddPoint per lane.  seq = its place in the reference's order (flanks merged by index, look-back first at equal
+		// index, then the copied source marks); an element that already carries a mark ignores later AddPoints, and the
+		// insertions into one list chain up in seq order (front insertion: the last one becomes the head).
+		unsigned seq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
+		if (lane < nlb) {
+			unsigned idx = w.lb[2 * lane], c = 0;
+			for (unsigned y = 0; y < nlf; y++) c += w.lf[2 * y] < idx;
+			seq = lane + c; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * lane + 1];
+		} else if (lane < nlb + nlf) {
+			unsigned bi = lane - nlb, idx = w.lf[2 * bi], c = 0;
+			for (unsigned y = 0; y < nlb; y++) c += w.lb[2 * y] <= idx;
+			seq = bi + c; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
+		} else if (lane < total) {
+			unsigned x = lane - nlb - nlf;
+			seq = lane; ad = w.act[3 * x]; ae = w.act[3 * x + 1]; ab = w.act[3 * x + 2];
+		}
+		bool valid = seq != BT_NONE && ab != BT_NONE && g.bif[ad][ae] == BT_NONE;
+		const unsigned ekey = (ae << 1) | ad;
+		for (unsigned y = 0; y < total; y++) {                        // an earlier AddPoint on the same (strand, element) wins
+			unsigned ky = __shfl(ekey, y), sy = __shfl(seq, y);
+			if (valid && y != lane && ky == ekey && sy < seq) valid = false;
+		}
+		const unsigned lkey = (ab << 1) | ad;
+		unsigned pred = BT_NONE, cnt = 0;
+		bool last = true;
+		for (unsigned y = 0; y < total; y++) {
+			unsigned ky = __shfl(lkey, y), sy = __shfl(seq, y);
+			bool vy = __shfl((int)valid, y) != 0;
+			if (vy && ky == lkey) {
+				cnt++;
+				if (sy < seq && (pred == BT_NONE || sy > pred)) pred = sy;
+				if (sy > seq) last = false;
+			}
+		}
+		if (valid) {
+			const unsigned nd = s_nodebase + seq;
+			const unsigned h = g.head[ad][ab], ls = g.lsize[ad][ab];
+			g.nslot[nd] = ae; g.ndead[nd] = 0; g.nidst[nd] = (ab << 1) | ad;
+			g.nnext[nd] = pred != BT_NONE ? s_nodebase + pred : h;
+			if (last) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls + cnt; }
+			g.bif[ad][ae] = ab; g.nodeof[ad][ae] = nd;
+			if (ab < g.nid) { g.touch[ab] = 1; if (ab > t.id) g.need[ab] = 1; }
+		}
 	}
+	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
 	__syncthreads();
 }
 
