@@ -820,12 +820,14 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 			const uint32_t kmerI = w.ab.grp_mem[w.idI];
 			if (!w.inI) {
 				if (!bt_pvalid(t, w.start[kmerI])) { w.idI++; continue; }
-				bt_fill_visit(t, w, kmerI);
-				w.inI = true; w.idJ = w.idI + 1;
-			} else if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; }
+				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true;
+			}
 			while (w.idJ < ge) {
 				const uint32_t kmerJ = w.ab.grp_mem[w.idJ++];
 				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
+				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
+				// after a collapse that rewrote I's own window
+				if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; if (t.err) return false; }
 				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.mks;
 				const uint32_t limJ = w.wlen[kmerJ] < D ? w.wlen[kmerJ] : D, nmJ = w.wmn[kmerJ];
 				for (uint32_t j = 0; j < nmJ; j++) {

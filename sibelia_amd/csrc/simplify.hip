@@ -729,7 +729,7 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 // entry with a different endChar, which also ends the instance -- reach lane 0, in the same order as in the serial loop.
 // A first pass counts the distinct ids so that the map is sized by them (it then usually fits the LDS scratch) instead of
 // by the total number of marks.  Falls back to bt_any_bulges when the tables do not fit.
-struct ABShared { unsigned *skey, *sval; unsigned bits, distinct; int mode; };   // mode 0: serial fallback, 1: wave path
+struct ABShared { unsigned *skey, *sval; unsigned bits, distinct; int mode; unsigned batch[64]; };   // mode 0: serial fallback, 1: wave path
 
 #define AB_COUNT_SLOTS 512u
 __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane)
@@ -826,18 +826,28 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			unsigned long long em = __ballot(ev != 0);
 			if (!em) { if (upto < 64) break; pos += 64; continue; }
 			unsigned f = (unsigned)__builtin_ctzll(em);
-			unsigned eev = __shfl(ev, f), eb = __shfl(b, f), eh = __shfl(h, f), evl = __shfl(val, f);
+			unsigned eev = __shfl(ev, f), evl = __shfl(val, f);
+			// a run of consecutive new ids (the first instance of every endChar brings ~all its marks) is handed to lane 0 at once
+			unsigned long long ins = __ballot(ev == 1u) >> f;
+			unsigned run = eev == 1u ? (ins == ~0ull ? 64u - f : (unsigned)__builtin_ctzll(~ins)) : 0u;
+			if (lane >= f && lane < f + run) sh.batch[lane - f] = b;
+			__syncthreads();
 			if (lane == 0) {
 				if (eev == 1u) {
-					int kt = bt_ab_insert(t, w, i, eb);
-					if (kt < 0) sh.mode = -1;
-					else { sh.skey[eh] = eb; sh.sval[eh] = ((unsigned)kt << 8) | (unsigned char)ec; }
+					for (unsigned x = 0; x < run && sh.mode > 0; x++) {
+						unsigned bb = sh.batch[x], hh = (bb * 2654435761u) >> shift;
+						while (sh.skey[hh] != BT_NONE && sh.skey[hh] != bb) hh = (hh + 1) & (slots - 1);
+						if (sh.skey[hh] == bb) continue;                       // the id occurs twice in this window: second look-up finds the entry just made
+						int kt = bt_ab_insert(t, w, i, bb);
+						if (kt < 0) sh.mode = -1;
+						else { sh.skey[hh] = bb; sh.sval[hh] = ((unsigned)kt << 8) | (unsigned char)ec; }
+					}
 				} else if (!bt_ab_append(t, w, i, (int)(evl >> 8))) sh.mode = -1;
 			}
 			__syncthreads();
 			if (sh.mode < 0) { bad = true; break; }
 			if (eev == 2u) break;                                          // the instance joined a group: next instance
-			pos += f + 1;
+			pos += f + run;
 		}
 	}
 	if (bad) return 0;
@@ -847,7 +857,9 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 }
 
 __device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
-#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull
+__device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
+__device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
+#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
 
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
@@ -977,6 +989,13 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		}
 	}
 	if (lane == 0) {
+		if (prof) {
+			unsigned long long dur = __builtin_readcyclecounter() - ph_start;
+			unsigned bin = 0;
+			while (bin < 15 && (dur >> (13 + bin))) bin++;
+			atomicAdd(&g_txn_hist[w.ret < 3 ? w.ret : 3][bin], 1ull);
+			if (atomicMax(&g_txn_max[0], dur) < dur) g_txn_max[1] = ((unsigned long long)w.n << 32) | w.ret;
+		}
 		if (t.err) {
 			if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
 			atomicOr(&g.ctr[CTR_ERR], t.err);
@@ -1369,7 +1388,12 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	st->live.ensure((size_t)window + 64);
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
-	if (be.prof) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z)); }
+	if (be.prof) {
+		unsigned long long z[64] = {0};
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 16 * 8));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_hist), z, 64 * 8));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_max), z, 16));
+	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
 	HIP_TRY(hipEventRecord(c->ev[3], s));
@@ -1432,6 +1456,15 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
 		const char *nm[9] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "stamp_writes", "push", "rescan"};
 		for (int i = 0; i < 9; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
+		unsigned long long hh[4][16], mx[2];
+		HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
+		HIP_TRY(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_txn_max), sizeof mx));
+		for (int r = 0; r < 4; r++) {
+			fprintf(stderr, "[sbl] transactions with %d%s collapses by duration (bins of 2^k x 8192 cycles):", r, r == 3 ? "+" : "");
+			for (int b = 0; b < 16; b++) fprintf(stderr, " %llu", hh[r][b]);
+			fprintf(stderr, "\n");
+		}
+		fprintf(stderr, "[sbl] longest transaction: %llu cycles, %llu instances, %llu collapses\n", mx[0], mx[1] >> 32, mx[1] & 0xFFFFFFFFull);
 	}
 	*bulges = rep.bulges;
 }
