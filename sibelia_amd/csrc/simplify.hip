@@ -159,10 +159,12 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 #define VT_SLOTS 512u
 struct VerdictTable { unsigned key[VT_SLOTS]; unsigned mask[VT_SLOTS]; };
 
-__device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane)
+__device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane, bool table_ready = false)
 {
-	for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-	__syncthreads();
+	if (!table_ready) {                                                // (multi-wave callers clear the table before their own barrier)
+		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+		__syncthreads();
+	}
 	const unsigned D = g.D, k = g.k;
 	unsigned distinct = 0;                                             // occupied slots (homologous instances repeat the same ids)
 	bool found = false;
@@ -236,24 +238,26 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 
 // Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
 // without reservation (ss_probe); the others are flagged live and go through reserve / commit.
-__global__ void __launch_bounds__(64) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
+#define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
+__global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
-	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	const unsigned wi = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
-	if (g.need[id] == 2) { if (lane == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
-	if (lane == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
+	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
+	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
 	__syncthreads();
-	if (ok) {
-		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
-		__syncthreads();
-	}
-	int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
+	if (ok)
+		for (unsigned i = wv; i < w.n; i += PROBE_WAVES) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+	__syncthreads();
+	if (wv) return;
+	int verdict = ok ? wave_verdict(g, w, vt, lane, true) : 0;
 	if (lane == 0) {
 		bool has = verdict > 0;
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 
 #define RESUME_SLOTS 128u                   // instances whose core walk end is remembered for the ordering pass
 #define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
-struct ClaimList { unsigned *buf; unsigned n; unsigned *seen; };
+struct ClaimList { unsigned *buf; unsigned *n; unsigned *seen; };      // n: LDS counter shared by the waves of the workgroup
 
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
@@ -385,9 +389,11 @@ __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, un
 	}
 	if (has) atomicMin(&g.own[b], st);
 	unsigned long long m = __ballot(has);
-	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
+	if (!m) return;
+	unsigned base = 0;
+	if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(cl.n, (unsigned)__popcll(m));
+	unsigned off = __shfl(base, (unsigned)__builtin_ctzll(m)) + __popcll(m & ((1ull << lane) - 1ull));
 	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b;
-	cl.n += __popcll(m);
 }
 
 // ordering claim (bt_footprint kind 1): ids above the runner are stamped without being listed, ids below it are listed
@@ -408,9 +414,11 @@ __device__ __forceinline__ void wave_claim_order(const GraphView &g, ClaimList &
 	}
 	if (has && b > id) { atomicMin(&g.own[b], st); has = false; }
 	unsigned long long m = __ballot(has);
-	unsigned off = cl.n + __popcll(m & ((1ull << lane) - 1ull));
+	if (!m) return;
+	unsigned base = 0;
+	if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(cl.n, (unsigned)__popcll(m));
+	unsigned off = __shfl(base, (unsigned)__builtin_ctzll(m)) + __popcll(m & ((1ull << lane) - 1ull));
 	if (has && off < CLAIM_CAP) cl.buf[1 + off] = b | 0x80000000u;
-	cl.n += __popcll(m);
 }
 
 __device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
@@ -466,28 +474,33 @@ __device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsi
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
-__global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
+#define RSV_WAVES 4u                         // waves of a reservation workgroup: the instances of the id are dealt out to them
+__global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
-	unsigned w = blockIdx.x, lane = threadIdx.x;
+	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	if (w >= nwin || !live[w]) return;
 	__shared__ unsigned seen[SEEN_SLOTS];
-	for (unsigned i = lane; i < SEEN_SLOTS; i += 64) seen[i] = BT_NONE;
+	__shared__ unsigned resume[RESUME_SLOTS];
+	__shared__ unsigned nclaims;
+	for (unsigned i = threadIdx.x; i < SEEN_SLOTS; i += 64 * RSV_WAVES) seen[i] = BT_NONE;
+	if (threadIdx.x == 0) nclaims = 0;
 	__syncthreads();
 	unsigned id = g.win[w], st = g.round_bits | w;
-	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = 0; cl.seen = seen;
-	wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
+	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = &nclaims; cl.seen = seen;
+	if (wv == 0) wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
 	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
 	// Who can interact with an instance: anything marked where the transaction itself reads or writes (core, both
 	// strands) -- claimed exclusively, the instance lists of those ids may be rewritten; instances upstream on the same
 	// strand and further downstream on the opposite strand walk towards the core -- the transaction can only make them
 	// stale, which orders it against them (bt_footprint, bulge_txn.h); instances walking away cannot see or touch it.
-	__shared__ unsigned resume[RESUME_SLOTS];
 	unsigned ninst = 0;
 	for (unsigned s = 0; s < 2; s++)                                  // all exclusive claims first: the seen-set keeps the first kind
 		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
 			if (g.ndead[nd]) continue;
-			unsigned nxt = wave_walk_claim(g, g.nslot[nd], s, core, lane, 3u, cl, st);
-			if (lane == 0 && ninst < RESUME_SLOTS) resume[ninst] = nxt;
+			if (ninst % RSV_WAVES == wv) {
+				unsigned nxt = wave_walk_claim(g, g.nslot[nd], s, core, lane, 3u, cl, st);
+				if (lane == 0 && ninst < RESUME_SLOTS) resume[ninst] = nxt;
+			}
 			ninst++;
 		}
 	__syncthreads();
@@ -496,13 +509,16 @@ __global__ void __launch_bounds__(64) k_reserve(GraphView g, unsigned nwin, unsi
 	for (unsigned s = 0; s < 2; s++)
 		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
 			if (g.ndead[nd]) continue;
-			unsigned e0 = g.nslot[nd];
-			unsigned nxt = done < RESUME_SLOTS ? resume[done] : wave_walk_marks(g, e0, s, core, lane, 0u, [](unsigned, unsigned) {});
+			if (done % RSV_WAVES == wv) {
+				unsigned e0 = g.nslot[nd];
+				unsigned nxt = done < RESUME_SLOTS ? resume[done] : wave_walk_marks(g, e0, s, core, lane, 0u, [](unsigned, unsigned) {});
+				if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
+				wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
+			}
 			done++;
-			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
-			wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
 		}
-	if (lane == 0) cl.buf[0] = cl.n;
+	__syncthreads();
+	if (threadIdx.x == 0) cl.buf[0] = nclaims;
 }
 // ---- wave-wide CollapseBulgeGreedily ------------------------------------------------------------------------
 // Same effect as bt_collapse (bulge_txn.h) = EraseBifurcations + DNASequence::Replace + UpdateBifurcations
@@ -1194,7 +1210,7 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		HIP_TRY(hipEventRecord(ev[4], c->stream));
-		k_probe<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
+		k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[5], c->stream));
 		timed_probe = true;
 		HIP_TRY(hipGetLastError());
@@ -1204,7 +1220,7 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		HIP_TRY(hipEventRecord(ev[0], c->stream));
-		k_reserve<<<nwin, 64, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
+		k_reserve<<<nwin, 64 * RSV_WAVES, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
 		HIP_TRY(hipEventRecord(ev[1], c->stream));
 		timed_reserve = true;
 		HIP_TRY(hipGetLastError());
