@@ -56,6 +56,18 @@ __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *_
 }
 
 // largest number of instances of any id (sizes the per-transaction scratch arena)
+// Snapshot order: ids sorted by where (one of) their instances lies, so that the workgroups resident at the same time scan
+// overlapping windows (an element is covered by ~17 windows at 8 strains) and meet in L2 instead of re-reading HBM.
+__global__ void __launch_bounds__(256) k_id_position_keys(const unsigned *__restrict__ head0, const unsigned *__restrict__ head1, const unsigned *__restrict__ nslot,
+                                                          unsigned nid, unsigned long long *__restrict__ keys, unsigned *__restrict__ ids)
+{
+	unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= nid) return;
+	unsigned nd = head0[id] != BT_NONE ? head0[id] : head1[id];
+	keys[id] = nd != BT_NONE ? nslot[nd] : 0xFFFFFFFFull;
+	ids[id] = id;
+}
+
 __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restrict__ l0, const unsigned *__restrict__ l1, unsigned nid, unsigned *__restrict__ out)
 {
 	unsigned m = 0;
@@ -207,7 +219,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
 // lane 0 evaluates the Boost-ordered map on the cached marks).
-__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental)
+__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental, const unsigned *__restrict__ perm)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -216,7 +228,12 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];       // per-instance window summaries of typical ids
 	const unsigned lane = threadIdx.x;
 	uint8_t *mine = arena + (size_t)blockIdx.x * arena_bytes;
-	for (unsigned id = blockIdx.x; id < g.nid; id += gridDim.x) {
+	// Workgroups are dealt to the 8 XCDs round robin (blockIdx & 7): every XCD takes a contiguous eighth of each chunk of
+	// gridDim.x positions of the positional order, so the overlapping windows of neighbouring ids share that XCD's L2.
+	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
+		if (base + slot >= g.nid) continue;
+		const unsigned id = perm[base + slot];
 		// incremental: an id nobody touched since its verdict was last taken is still clean
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }
 		__syncthreads();
@@ -1098,7 +1115,7 @@ struct SimplifyState {
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
-	DevBuf keys, skeys, selem, sorttmp, scantmp;
+	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
 	unsigned *h_ctr = nullptr;            // pinned
 };
@@ -1175,7 +1192,7 @@ struct DeviceBackend {
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[6], c->stream));
-		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0);
+		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>());
 		HIP_TRY(hipEventRecord(ev[7], c->stream));
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1284,7 +1301,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
-	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
@@ -1361,6 +1378,15 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>());
 	}
 	HIP_TRY(hipGetLastError());
+	// positional order of the ids for the snapshot kernel
+	st->perm.ensure(nidp * 4 + 16); st->permin.ensure(nidp * 4 + 16);
+	st->keys.ensure(nidp * 8 + 16); st->skeys.ensure(nidp * 8 + 16);
+	if (be.nid_) {
+		k_id_position_keys<<<nblocks(be.nid_, 256), 256, 0, s>>>(st->head[0].as<unsigned>(), st->head[1].as<unsigned>(), st->nslot.as<unsigned>(), be.nid_,
+		                                                       st->keys.as<unsigned long long>(), st->permin.as<unsigned>());
+		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->permin.as<unsigned>(), st->perm.as<unsigned>(), be.nid_);
+	}
+	HIP_TRY(hipGetLastError());
 
 	// ---- control state
 	st->ctr.ensure(CTR_COUNT * 4);
@@ -1390,7 +1416,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		size_t need = slots * 17 * ws + 12 * (size_t)D + 8 * (size_t)k + (64u << 10) + slots * 64;
 		be.arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(need, 128u << 10), 1u << 30);
 		be.snap_arena_bytes = be.arena_bytes;
-		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes));
+		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes)) & ~7u;   // a multiple of the 8 XCDs
 		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
 	}
 	uint32_t window = c->window ? c->window : std::min<uint32_t>(16384, std::max<uint32_t>(2048, be.nid_ / 64));
