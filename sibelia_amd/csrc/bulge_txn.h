@@ -336,6 +336,7 @@ struct ABuild {
 struct BulgeWork {
 	uint32_t n;                  // instances of the id
 	uint32_t *start;             // (node << 1) | strand, list order: + list then - list (ListPositions, bifurcationstorage.h:59-72)
+	uint32_t *sel;               // element of each instance (a live node never changes its element)
 	char *endc;                  // endChar
 	// Window cache: what instance i sees walking its own strand, steps 0 .. ws-1 (step 0 = the instance).
 	// Filled by bt_scan_instance (one thread) or by the wave-cooperative scan of simplify.hip (64 lanes);
@@ -379,7 +380,7 @@ __host__ __device__ inline uint32_t bt_count_instances(const GraphView &g, uint3
 }
 
 // ListPositions (bulgeremoval.cpp:335) + all scratch of the transaction.  False when fewer than two instances.
-__host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false)
+__host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false, bool fill_list = true)
 {
 	GraphView &g = t.g;
 	uint32_t k = g.k, D = g.D;
@@ -389,6 +390,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	if (n < 2) return false;
 	w.ws = D + k + 2;
 	w.start = (uint32_t *)t.alloc2(n * 4);          // small per-instance arrays: fast scratch (LDS) when there is one
+	w.sel = (uint32_t *)t.alloc2(n * 4);
 	w.endc = (char *)t.alloc2(n);
 	w.wlen = (uint32_t *)t.alloc2(n * 4);
 	w.wmn = (uint32_t *)t.alloc2(n * 4);
@@ -416,10 +418,11 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
 	}
 	if (t.err) return false;
+	if (!fill_list) return true;                    // the caller lists the positions itself (64 lanes, simplify.hip: wave_list_positions)
 	uint32_t m = 0;
 	for (uint32_t s = 0; s < 2; s++)
 		for (uint32_t nd = g.head[s][t.id]; nd != BT_NONE; nd = g.nnext[nd])
-			if (!g.ndead[nd] && m < n) w.start[m++] = (nd << 1) | s;
+			if (!g.ndead[nd] && m < n) { w.start[m] = (nd << 1) | s; w.sel[m] = g.nslot[nd]; m++; }
 	if (m != n) { t.err |= BT_ERR_SCRATCH; return false; }     // cannot happen on a consistent graph
 	return true;
 }

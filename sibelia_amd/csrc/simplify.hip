@@ -97,12 +97,50 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 	}
 }
 
+// ListPositions (bifurcationstorage.h:59-72) with 64 lanes: + list then - list, chain order, dead nodes skipped.  Lists
+// start out as runs of consecutive node indices (k_build_lists), so 64 nodes are read per step, speculatively, and the
+// lanes whose predecessors all link consecutively are on the chain; front insertions and the end of a run re-anchor.
+__device__ __forceinline__ unsigned wave_list_positions(const GraphView &g, unsigned id, const BulgeWork &w, unsigned lane)
+{
+	unsigned m = 0;
+	for (unsigned s = 0; s < 2; s++) {
+		unsigned cur = g.head[s][id];
+		while (cur != BT_NONE) {
+			const bool inr = (unsigned long long)cur + lane < g.cap_n;
+			const unsigned nd = cur + lane;
+			const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
+			const unsigned dead = inr ? g.ndead[nd] : 1u;
+			const unsigned el = inr ? g.nslot[nd] : 0u;
+			const unsigned long long cont = __ballot(inr && nxt == nd + 1);
+			const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;   // lanes 0 .. pre-1 are on the chain
+			const bool on = lane < pre && inr;
+			const unsigned long long lv = __ballot(on && !dead);
+			const unsigned off = m + __popcll(lv & ((1ull << lane) - 1ull));
+			if (on && !dead && off < w.n) { w.start[off] = (nd << 1) | s; w.sel[off] = el; }
+			m += (unsigned)__popcll(lv);
+			cur = __shfl(nxt, pre - 1);
+		}
+	}
+	return m;
+}
+// bt_setup with the positions listed by all lanes; `ok` lives in LDS
+__device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork &w, bool lite, unsigned lane, int &ok)
+{
+	if (lane == 0) ok = bt_setup(t, w, lite, false) && !t.err ? 1 : 0;
+	__syncthreads();
+	if (!ok) return false;
+	unsigned m = wave_list_positions(g, t.id, w, lane);
+	if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; ok = 0; }          // cannot happen on a consistent graph
+	__syncthreads();
+	return ok != 0;
+}
+
 __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
                                                    unsigned stampv, unsigned tid, unsigned mode, unsigned id)
 {
 	const size_t base = (size_t)i * w.ws;
 	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
-	unsigned cur = g.nslot[packed >> 1], done = 0, wl = ws, nm = 0, nb = 0, lastc = 0;
+	unsigned cur = w.sel[i], done = 0, wl = ws, nm = 0, nb = 0, lastc = 0;
 	bool finished = false;
 	while (done < ws && cur != BT_NONE && !finished) {
 		if (!w.lite && done && cur != (dir ? lastc - 1 : lastc + 1)) {      // the walk leaves consecutive slots here
@@ -237,8 +275,9 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 		// incremental: an id nobody touched since its verdict was last taken is still clean
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }
 		__syncthreads();
-		if (lane == 0) { g.touch[id] = 0; t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
+		if (lane == 0) { g.touch[id] = 0; t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; }
 		__syncthreads();
+		wave_setup(g, t, w, true, lane, ok);
 		if (ok) {
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
 			__syncthreads();
@@ -267,8 +306,9 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
-	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; ok = bt_setup(t, w, true) ? 1 : 0; }
+	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }
 	__syncthreads();
+	wave_setup(g, t, w, true, lane, ok);
 	if (ok)
 		for (unsigned i = wv; i < w.n; i += PROBE_WAVES) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
@@ -930,8 +970,9 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
 	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
 	if (solo) {
-		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; flag = bt_setup(t, w, true) ? 1 : 0; }
+		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; }
 		__syncthreads();
+		wave_setup(g, t, w, true, lane, flag);
 		if (flag) {
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
 			__syncthreads();
@@ -948,8 +989,9 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
-	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; flag = bt_setup(t, w) && !t.err ? 1 : 0; }
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; }
 	__syncthreads();
+	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
 	if (flag) {
 		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
