@@ -140,22 +140,21 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	HIP_TRY(hipEventRecord(c->ev[1], s));
 	HIP_TRY(hipGetLastError());
 
-	// classify the claimed slots: first count, then emit keys into exactly sized buffers
+	// classify the claimed slots in ONE pass: every claimed slot yields at most one pair / two keys, so the key buffers are
+	// sized by that bound (16 + 8 B per distinct k-mer, transient) instead of by a counting pre-pass over the random slots
 	unsigned nused = 0;
 	HIP_TRY(hipMemcpyAsync(&nused, c->d_counters.as<unsigned>() + 8, 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	unsigned cgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)nused + 255) / 256, 256 * 16));
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(), nullptr, nullptr, 0);
+	c->d_keys.ensure((size_t)nused * 16 + 16); c->d_payload.ensure((size_t)nused * 8 + 16);
+	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(),
+	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), nused);
 	unsigned cnt[4];
 	HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	unsigned npairs = cnt[0], nkeys = cnt[1];
-	c->d_keys.ensure((size_t)nkeys * 8 + 16); c->d_payload.ensure((size_t)nkeys * 4 + 16);
 	c->d_skeys.ensure((size_t)nkeys * 8 + 16); c->d_spayload.ensure((size_t)nkeys * 4 + 16);
 	c->d_pairids.ensure((size_t)npairs * 8 + 16);
-	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 8 * 4, s));
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(),
-	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), npairs);
 	if (nkeys) {
 		device_sort_pairs(c, c->d_keys.as<unsigned long long>(), c->d_skeys.as<unsigned long long>(),
 		                  c->d_payload.as<unsigned>(), c->d_spayload.as<unsigned>(), nkeys, 2 * k);

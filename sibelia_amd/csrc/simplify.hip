@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 // one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
 // (and runs alone if it is the lowest).  Eight ids per thread and step (8-byte loads of the need / big flags).
 // out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
+#define SEL_WORDS 4                          // 8-id words per thread and step: 1024 threads x 32 ids = 32768 ids per step
 __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, unsigned lo, unsigned limit, unsigned W)
 {
 	__shared__ unsigned s_wave[16];
@@ -335,29 +336,40 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	if (threadIdx.x == 0) { s_base = 0; s_first = SBL_NONE; s_stop = 0; s_solo = 0; }
 	__syncthreads();
-	for (unsigned long long start = lo & ~7ull; start <= limit; start += 8192) {
-		const unsigned long long id0 = start + 8ull * threadIdx.x;
-		unsigned long long nb = 0, bb = 0;                       // byte j = id0 + j: 1 = pending / pending and big
-		if (id0 <= limit) {
-			nb = *reinterpret_cast<const unsigned long long *>(g.need + id0);
-			bb = *reinterpret_cast<const unsigned long long *>(g.big + id0);
+	for (unsigned long long start = lo & ~7ull; start <= limit; start += 8192ull * SEL_WORDS) {
+		const unsigned long long id0 = start + 8ull * SEL_WORDS * threadIdx.x;
+		unsigned long long nb[SEL_WORDS], bb[SEL_WORDS];         // byte j of word q = id0 + 8q + j: 1 = pending / pending and big
+		unsigned firstp = SBL_NONE, firstb = SBL_NONE;
 #pragma unroll
-			for (int j = 0; j < 8; j++) if (id0 + j < lo || id0 + j > limit) nb &= ~(0xFFull << (8 * j));
-			nb = (nb | (nb >> 1) | (nb >> 2) | (nb >> 3) | (nb >> 4) | (nb >> 5) | (nb >> 6) | (nb >> 7)) & 0x0101010101010101ull;
-			bb = (bb | (bb >> 1) | (bb >> 2) | (bb >> 3) | (bb >> 4) | (bb >> 5) | (bb >> 6) | (bb >> 7)) & nb;
+		for (int q = 0; q < SEL_WORDS; q++) {
+			const unsigned long long idq = id0 + 8ull * q;
+			nb[q] = 0; bb[q] = 0;
+			if (idq <= limit) {
+				nb[q] = *reinterpret_cast<const unsigned long long *>(g.need + idq);
+				bb[q] = *reinterpret_cast<const unsigned long long *>(g.big + idq);
+#pragma unroll
+				for (int j = 0; j < 8; j++) if (idq + j < lo || idq + j > limit) nb[q] &= ~(0xFFull << (8 * j));
+				nb[q] = (nb[q] | (nb[q] >> 1) | (nb[q] >> 2) | (nb[q] >> 3) | (nb[q] >> 4) | (nb[q] >> 5) | (nb[q] >> 6) | (nb[q] >> 7)) & 0x0101010101010101ull;
+				bb[q] = (bb[q] | (bb[q] >> 1) | (bb[q] >> 2) | (bb[q] >> 3) | (bb[q] >> 4) | (bb[q] >> 5) | (bb[q] >> 6) | (bb[q] >> 7)) & nb[q];
+				if (bb[q] && firstb == SBL_NONE) firstb = (unsigned)(idq + (__builtin_ctzll(bb[q]) >> 3));
+				if (nb[q] && firstp == SBL_NONE) firstp = (unsigned)(idq + (__builtin_ctzll(nb[q]) >> 3));
+			}
 		}
 		if (threadIdx.x == 0) s_bigid = SBL_NONE;
 		__syncthreads();
-		if (bb) atomicMin(&s_bigid, (unsigned)(id0 + (__builtin_ctzll(bb) >> 3)));
-		if (nb) atomicMin(&s_first, (unsigned)(id0 + (__builtin_ctzll(nb) >> 3)));
+		if (firstb != SBL_NONE) atomicMin(&s_bigid, firstb);
+		if (firstp != SBL_NONE) atomicMin(&s_first, firstp);
 		__syncthreads();
 		const unsigned bigid = s_bigid;
-		unsigned long long tk = nb;
-		if (bigid != SBL_NONE) {
+		unsigned cnt = 0;
 #pragma unroll
-			for (int j = 0; j < 8; j++) if (id0 + j >= bigid) tk &= ~(0xFFull << (8 * j));
+		for (int q = 0; q < SEL_WORDS; q++) {
+			if (bigid != SBL_NONE) {
+#pragma unroll
+				for (int j = 0; j < 8; j++) if (id0 + 8ull * q + j >= bigid) nb[q] &= ~(0xFFull << (8 * j));
+			}
+			cnt += __popcll(nb[q]);
 		}
-		const unsigned cnt = __popcll(tk);
 		unsigned incl = cnt;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
@@ -366,11 +378,15 @@ __global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, uns
 		unsigned woff = 0, total = 0;
 		for (unsigned w = 0; w < 16; w++) { unsigned v = s_wave[w]; if (w < wv) woff += v; total += v; }
 		unsigned pos = s_base + woff + incl - cnt;
-		while (tk) {
-			unsigned j = __builtin_ctzll(tk) >> 3;
-			if (pos < W) win[pos] = (unsigned)(id0 + j);
-			pos++;
-			tk &= tk - 1;
+#pragma unroll
+		for (int q = 0; q < SEL_WORDS; q++) {
+			unsigned long long tk = nb[q];
+			while (tk) {
+				unsigned j = __builtin_ctzll(tk) >> 3;
+				if (pos < W) win[pos] = (unsigned)(id0 + 8ull * q + j);
+				pos++;
+				tk &= tk - 1;
+			}
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
