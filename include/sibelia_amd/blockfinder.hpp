@@ -2,8 +2,8 @@
 //
 // Mirrors SyntenyFinder::BlockFinder's public section (reference src/blockfinder.h:28-45) for the hot path:
 // same constructors (a FASTARecord only needs GetSequence()), same method names, argument order and meaning.
-// Header-only; link with -lsibelia_amd.  Errors that the reference cannot produce (no device, OOM, k > 32
-// in this build) are thrown as std::runtime_error, the only exception type the reference itself throws
+// Header-only; link with -lsibelia_amd.  Errors that the reference cannot produce (no device, OOM, input
+// beyond the 29-bit limits) are thrown as std::runtime_error, the only exception type the reference itself throws
 // (src/platform.cpp:40,79,118,126).
 #ifndef SIBELIA_AMD_BLOCKFINDER_HPP
 #define SIBELIA_AMD_BLOCKFINDER_HPP
@@ -72,6 +72,18 @@ namespace SyntenyFinderAMD
 			return std::vector<uint32_t>(p, p + n);
 		}
 		sbl_ctx *Context() const { return ctx_; }
+
+		// Several GPUs (no counterpart in the reference): one BlockFinder per GPU on the same input; with a communicator
+		// attached the enumeration of every stage is sharded by k-mer hash prefix and the calls become collective.
+		static std::string CommUniqueId()                                 // rank 0; distribute the bytes to every rank
+		{
+			std::string id(SBL_COMM_ID_BYTES, '\0');
+			if (sbl_comm_unique_id(&id[0]) != SBL_OK) throw std::runtime_error("sibelia_amd: RCCL is not available");
+			return id;
+		}
+		void AttachRccl(unsigned rank, unsigned nranks, const std::string &id) { Check(sbl_comm_attach_rccl(ctx_, rank, nranks, id.data()), "AttachRccl"); }
+		void AttachLocal(sbl_group *group, unsigned rank) { Check(sbl_comm_attach_local(ctx_, group, rank), "AttachLocal"); }
+		void Detach() { Check(sbl_comm_detach(ctx_), "Detach"); }
 
 	private:
 		template <class FASTARecordVector>

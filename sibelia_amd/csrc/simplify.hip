@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 			bool v = verdict > 0;
 			if (verdict < 0) { bt_end_chars(t, w); v = bt_any_bulges(t, w, true); }      // too many marks for the LDS table
 			if (t.err & BT_ERR_SCRATCH) v = true;
-			g.need[id] = v ? 1 : 0;
+			g.need[id] = v ? (verdict > 0 ? 2 : 1) : 0;                 // 2: known live, the first probe of the entry is skipped (a push resets it to 1)
 		}
 	}
 }

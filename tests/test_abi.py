@@ -39,3 +39,26 @@ def test_product_never_references_the_oracle():
                 if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "sibelia_oracle" not in txt and "oracle.oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_cpp_class_surface_compiles_and_fails_loudly_without_a_gpu(tmp_path):
+    # include/sibelia_amd/blockfinder.hpp (the reference's BlockFinder surface over the C ABI) with plain g++
+    import subprocess
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from sibelia_amd.build import LIBDIR
+    src = tmp_path / "main.cpp"
+    src.write_text('#include "sibelia_amd/blockfinder.hpp"\n'
+                   'struct Rec { std::string s; const std::string &GetSequence() const { return s; } };\n'
+                   'int main() { std::vector<Rec> v(1); v[0].s = "ACGTACGTTGCA";\n'
+                   '  try { SyntenyFinderAMD::BlockFinder bf(v); std::printf("bulges %zu\\n", bf.PerformGraphSimplifications(3, 6, 2)); }\n'
+                   '  catch (const std::exception &e) { std::printf("error: %s\\n", e.what()); return 3; } return 0; }\n')
+    exe = tmp_path / "main"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", LIBDIR, "-lsibelia_amd",
+                    "-Wl,-rpath," + LIBDIR, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and r.stdout.startswith("bulges ")
+    else:
+        assert r.returncode == 3 and "no usable HIP device" in r.stdout

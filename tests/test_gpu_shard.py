@@ -20,7 +20,7 @@ def _max_k(v):
 
 
 PICK = [v for v in VECS if (v["name"].startswith("hand/") or (v["name"].startswith("small/") and _bulges(v) < 60)) and _max_k(v) <= 32][:40]
-GENOMES = [v for v in VECS if v["name"] in ("real/hpylori_k25", "synth/strains4_100k")]
+GENOMES = [v for v in VECS if v["name"] in ("real/hpylori_k25", "real/hpylori_fine", "synth/strains4_100k", "synth/strains4_100k_fine")]
 
 
 def _sharded(nranks):
