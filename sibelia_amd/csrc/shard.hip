@@ -40,6 +40,8 @@ struct SblComm {
 	// device buffers; byte counts / offsets per peer
 	virtual void alltoallv(sbl_ctx *c, const char *send, const size_t *sbytes, const size_t *soff,
 	                       char *recv, const size_t *rbytes, const size_t *roff) = 0;
+	// this rank is leaving a collective call with an error: release peers that would wait for it (local transport)
+	virtual void abort_peers() {}
 };
 
 struct RcclApi {
@@ -108,32 +110,55 @@ struct RcclComm : SblComm {
 };
 
 struct sbl_group {
-	uint32_t n = 0, attached = 0;
-	pthread_barrier_t bar;
+	uint32_t n = 0;
 	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	uint32_t waiting = 0, generation = 0;
+	bool failed = false;                      // a rank gave up inside a collective call: everybody else must not wait for it
 	std::vector<const char *> send;
 	std::vector<const size_t *> soff;
 	std::vector<std::vector<uint8_t>> host;
+	// barrier that can be broken: a rank that fails (out of memory, ...) wakes the others up instead of leaving them blocked
+	void wait()
+	{
+		pthread_mutex_lock(&mu);
+		if (!failed) {
+			uint32_t gen = generation;
+			if (++waiting == n) { waiting = 0; generation++; pthread_cond_broadcast(&cv); }
+			else while (gen == generation && !failed) pthread_cond_wait(&cv, &mu);
+		}
+		bool f = failed;
+		pthread_mutex_unlock(&mu);
+		if (f) throw SblError{SBL_ERR_INTERNAL, "a peer rank of the local group failed inside a collective call"};
+	}
+	void fail()
+	{
+		pthread_mutex_lock(&mu);
+		failed = true;
+		pthread_cond_broadcast(&cv);
+		pthread_mutex_unlock(&mu);
+	}
 };
 struct LocalComm : SblComm {
 	sbl_group *g = nullptr;
 	void allgather_host(sbl_ctx *, const void *in, size_t bytes, void *out) override
 	{
 		g->host[rank].assign((const uint8_t *)in, (const uint8_t *)in + bytes);
-		pthread_barrier_wait(&g->bar);
+		g->wait();
 		for (uint32_t p = 0; p < n; p++) memcpy((char *)out + (size_t)p * bytes, g->host[p].data(), bytes);
-		pthread_barrier_wait(&g->bar);
+		g->wait();
 	}
 	void alltoallv(sbl_ctx *c, const char *send, const size_t *, const size_t *soff, char *recv, const size_t *rbytes, const size_t *roff) override
 	{
 		HIP_TRY(hipStreamSynchronize(c->stream));             // my send buffer is complete
 		g->send[rank] = send; g->soff[rank] = soff;
-		pthread_barrier_wait(&g->bar);
+		g->wait();
 		for (uint32_t p = 0; p < n; p++)
 			if (rbytes[p]) HIP_TRY(hipMemcpyAsync(recv + roff[p], g->send[p] + g->soff[p][rank], rbytes[p], hipMemcpyDefault, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		pthread_barrier_wait(&g->bar);                         // peers may reuse their send buffers
+		g->wait();                                             // peers may reuse their send buffers
 	}
+	void abort_peers() override { g->fail(); }
 };
 
 void sbl_comm_release(sbl_ctx *c)
@@ -172,15 +197,15 @@ extern "C" sbl_group *sbl_group_create_local(uint32_t nranks)
 	if (nranks < 1 || nranks > 64) return nullptr;
 	sbl_group *g = new sbl_group;
 	g->n = nranks;
-	pthread_barrier_init(&g->bar, nullptr, nranks);
 	pthread_mutex_init(&g->mu, nullptr);
+	pthread_cond_init(&g->cv, nullptr);
 	g->send.assign(nranks, nullptr); g->soff.assign(nranks, nullptr); g->host.resize(nranks);
 	return g;
 }
 extern "C" void sbl_group_destroy(sbl_group *g)
 {
 	if (!g) return;
-	pthread_barrier_destroy(&g->bar);
+	pthread_cond_destroy(&g->cv);
 	pthread_mutex_destroy(&g->mu);
 	delete g;
 }
@@ -229,7 +254,13 @@ size_t allgatherv(sbl_ctx *c, Clock &clk, const char *send, size_t sbytes, DevBu
 }
 }
 
+static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);
 void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity)
+{
+	try { run_enumeration_sharded(c, k, elem_capacity); }
+	catch (...) { c->comm->abort_peers(); throw; }
+}
+static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SblComm *cm = c->comm;
 	const uint32_t R = cm->n, r = cm->rank;

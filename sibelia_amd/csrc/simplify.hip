@@ -135,8 +135,28 @@ __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork
 	return ok != 0;
 }
 
+// Burst: the loads of up to SCAN_BURST x 64 consecutive slots are issued together, assuming the list is laid out
+// consecutively there (it almost always is); blocks are then consumed in order and the burst is abandoned at the
+// first link break or separator.  One memory round trip per window instead of one per 64 elements.
+enum { SCAN_BURST = 3 };
+struct ScanBurst { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST]; bool inr[SCAN_BURST]; };
+__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b)
+{
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		unsigned off = lane + 64u * u;
+		b.inr[u] = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
+		b.cc[u] = dir ? cur - off : cur + off;
+		b.plink[u] = b.inr[u] && off ? (dir ? g.pv[b.cc[u] + 1] : g.nx[b.cc[u] - 1]) : b.cc[u];
+		b.chv[u] = b.inr[u] ? g.ch[b.cc[u]] : 0u;
+		b.bvl[u] = b.inr[u] ? g.bif[dir][b.cc[u]] : BT_NONE;
+		b.lnk[u] = b.inr[u] ? (dir ? g.pv[b.cc[u]] : g.nx[b.cc[u]]) : BT_NONE;
+	}
+}
+
+// pre: the first burst of this window, already in flight (issued while the previous window was being consumed)
 __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
-                                                   unsigned stampv, unsigned tid, unsigned mode, unsigned id)
+                                                   unsigned stampv, unsigned tid, unsigned mode, unsigned id, const ScanBurst *pre_burst = nullptr)
 {
 	const size_t base = (size_t)i * w.ws;
 	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
@@ -147,22 +167,10 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			if (lane == 0 && nb < BT_MAX_BREAKS) w.wbk[i * BT_MAX_BREAKS + nb] = done;
 			nb++;
 		}
-		// Burst: the loads of up to SCAN_BURST x 64 consecutive slots are issued together, assuming the list is laid out
-		// consecutively there (it almost always is); blocks are then consumed in order and the burst is abandoned at the
-		// first link break or separator.  One memory round trip per window instead of one per 64 elements.
-		enum { SCAN_BURST = 3 };
-		unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST];
-		bool inr[SCAN_BURST];
-#pragma unroll
-		for (int u = 0; u < SCAN_BURST; u++) {
-			unsigned off = lane + 64u * u;
-			inr[u] = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
-			cc[u] = dir ? cur - off : cur + off;
-			plink[u] = inr[u] && off ? (dir ? g.pv[cc[u] + 1] : g.nx[cc[u] - 1]) : cc[u];
-			chv[u] = inr[u] ? g.ch[cc[u]] : 0u;
-			bvl[u] = inr[u] ? g.bif[dir][cc[u]] : BT_NONE;
-			lnk[u] = inr[u] ? (dir ? g.pv[cc[u]] : g.nx[cc[u]]) : BT_NONE;
-		}
+		ScanBurst bst;
+		if (pre_burst && done == 0) bst = *pre_burst; else scan_burst_load(g, cur, dir, done, ws, lane, bst);
+		const unsigned (&cc)[SCAN_BURST] = bst.cc, (&plink)[SCAN_BURST] = bst.plink, (&chv)[SCAN_BURST] = bst.chv, (&bvl)[SCAN_BURST] = bst.bvl, (&lnk)[SCAN_BURST] = bst.lnk;
+		const bool (&inr)[SCAN_BURST] = bst.inr;
 		const unsigned burst_done = done;
 #pragma unroll
 		for (int u = 0; u < SCAN_BURST; u++) {
@@ -200,6 +208,19 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 		}
 	}
 	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; if (nm > w.mks) *const_cast<bool *>(&w.mk_overflow) = true; }
+}
+
+// windows first, first + stride, ... of the cache, each one's first burst issued while the previous window is consumed
+__device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
+                                              unsigned first = 0, unsigned stride = 1)
+{
+	ScanBurst nb;
+	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, nb);
+	for (unsigned i = first; i < w.n; i += stride) {
+		ScanBurst b = nb;
+		if (i + stride < w.n) scan_burst_load(g, w.sel[i + stride], w.start[i + stride] & 1u, 0, w.ws, lane, nb);
+		wave_scan_instance(g, w, i, lane, stampv, tid, mode, id, &b);
+	}
 }
 
 // AnyBulges VERDICT with 64 lanes.  "Some bulge group gets a second member" is an order-free predicate: there is an
@@ -279,7 +300,7 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 		__syncthreads();
 		wave_setup(g, t, w, true, lane, ok);
 		if (ok) {
-			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, 0, 0, id);
+			wave_scan_all(g, w, lane, 0, 0, 0, id);
 			__syncthreads();
 		}
 		int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
@@ -310,7 +331,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	__syncthreads();
 	wave_setup(g, t, w, true, lane, ok);
 	if (ok)
-		for (unsigned i = wv; i < w.n; i += PROBE_WAVES) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+		wave_scan_all(g, w, lane, 0, tid, 3, id, wv, PROBE_WAVES);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 	__syncthreads();
 	if (wv) return;
@@ -990,7 +1011,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 		__syncthreads();
 		wave_setup(g, t, w, true, lane, flag);
 		if (flag) {
-			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 1, id);
+			wave_scan_all(g, w, lane, stampv, tid, 1, id);
 			__syncthreads();
 		}
 		int verdict = flag ? wave_verdict(g, w, *reinterpret_cast<VerdictTable *>(fast), lane) : 0;   // the fast scratch is idle in this pass
@@ -1010,7 +1031,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
 	if (flag) {
-		for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+		wave_scan_all(g, w, lane, stampv, tid, 2, id);
 		__syncthreads();
 		if (w.mk_overflow) {                                          // more marks in a window than the LDS lists hold: use the arena
 			__syncthreads();
