@@ -522,49 +522,75 @@ __device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned
 }
 
 // After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
-// look-forward flank had marks, characters, positions or links rewritten) and check that no higher id read them.
-__device__ __forceinline__ void wave_stamp_writes(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
+// look-forward flank had marks, characters, positions or links rewritten), check that no higher id read or wrote them, and
+// make every id whose window can see the region and that is still ahead in the order pending (bt_push_neighbourhood with
+// 64 lanes).  Only instances walking TOWARDS the region can see it: upstream that is the target's own strand, beyond the
+// end of the region the opposite strand, inside it both.  The region is walked once (write stamps on its first
+// newlen + 2k elements, pushes on newlen + 2k + 1), then the upstream and the downstream walk advance together.
+__device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
 {
-	unsigned cur = e, done = 0, maxcount = newlen + 2 * g.k, tid = id + 1;
-	while (done < maxcount && cur != BT_NONE) {
-		bool inr = done + lane < maxcount && (d ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
+	const unsigned reach = g.D + g.k + 2, tid = id + 1, nstamp = newlen + 2 * g.k, nreg = nstamp + 1;
+	auto push1 = [&](unsigned b) { if (b != BT_NONE && b < g.nid) { g.touch[b] = 1; if (b > id) g.need[b] = 1; } };
+	// ---- the region
+	unsigned cur = e, done = 0;
+	bool open = true;
+	while (done < nreg && cur != BT_NONE) {
+		bool inr = done + lane < nreg && (d ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = d ? cur - lane : cur + lane;
-		bool link = inr && (lane == 0 || (d ? g.pv[c + 1] == c : g.nx[c - 1] == c));
-		unsigned long long ml = __ballot(link);
+		unsigned plink = inr && lane ? (d ? g.pv[c + 1] : g.nx[c - 1]) : c;
+		unsigned chv = inr ? g.ch[c] : 0u;
+		unsigned b0 = inr ? g.bif[0][c] : BT_NONE, b1 = inr ? g.bif[1][c] : BT_NONE;
+		unsigned lnk = inr ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
+		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-		bool mine = lane < pre;
-		unsigned chv = mine ? g.ch[c] : 0u;
-		unsigned long long ms = __ballot(mine && chv == BT_SEP);
+		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
-		if (mine && lane < stop) {
-			unsigned a = atomicMax(&g.wmax[c], tid);
-			unsigned rm = g.rmax[c];
-			if (a > tid || rm > tid) {
-				atomicMin(&g.ctr[CTR_VIOL], id);
-				if (atomicCAS(&g.ctr[11], 0u, 4u) == 0u) { g.ctr[12] = c; g.ctr[13] = (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
+		if (lane < pre && lane < stop) {
+			push1(b0); push1(b1);
+			if (done + lane < nstamp) {
+				unsigned a = atomicMax(&g.wmax[c], tid);
+				unsigned rm = g.rmax[c];
+				if (a > tid || rm > tid) {
+					atomicMin(&g.ctr[CTR_VIOL], id);
+					if (atomicCAS(&g.ctr[11], 0u, 4u) == 0u) { g.ctr[12] = c; g.ctr[13] = (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
+				}
 			}
 		}
-		if (stop < pre) break;
-		unsigned lnk = mine ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
+		if (stop < pre) { open = false; break; }
 		cur = __shfl(lnk, pre - 1);
 		done += pre;
 	}
-}
-
-// bt_push_neighbourhood with 64 lanes: every id marked around a rewritten region and still ahead in the order becomes pending
-__device__ __forceinline__ void wave_push_neighbourhood(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
-{
-	unsigned reach = g.D + g.k + 2;
-	auto push = [&](unsigned b0, unsigned b1) {
-		if (b0 != BT_NONE && b0 < g.nid) { g.touch[b0] = 1; if (b0 > id) g.need[b0] = 1; }
-		if (b1 != BT_NONE && b1 < g.nid) { g.touch[b1] = 1; if (b1 > id) g.need[b1] = 1; }
-	};
-	// Only instances walking TOWARDS the rewritten region can see it: upstream of the target that is the target's own
-	// strand, beyond the end of the region the opposite strand; inside the region both.
-	const unsigned own = 1u << d, opp = 1u << (d ^ 1u);
-	wave_walk_marks(g, d ? g.nx[e] : g.pv[e], d ^ 1u, reach, lane, own, push);
-	unsigned nxt = wave_walk_marks(g, e, d, newlen + 2 * g.k + 1, lane, 3u, push);
-	if (nxt != BT_NONE) wave_walk_marks(g, nxt, d, reach, lane, opp, push);
+	// ---- upstream (direction d ^ 1, marks of strand d) and downstream (direction d, marks of strand d ^ 1) together
+	unsigned cu = d ? g.nx[e] : g.pv[e], du = 0;
+	unsigned cd = open ? cur : BT_NONE, dd = 0;
+	while ((du < reach && cu != BT_NONE) || (dd < reach && cd != BT_NONE)) {
+		const bool au = du < reach && cu != BT_NONE, ad = dd < reach && cd != BT_NONE;
+		const unsigned diru = d ^ 1u, dird = d;
+		bool inu = au && du + lane < reach && (diru ? lane <= cu : (unsigned long long)cu + lane < g.cap_e);
+		bool ind = ad && dd + lane < reach && (dird ? lane <= cd : (unsigned long long)cd + lane < g.cap_e);
+		unsigned xu = diru ? cu - lane : cu + lane, xd = dird ? cd - lane : cd + lane;
+		unsigned plu = inu && lane ? (diru ? g.pv[xu + 1] : g.nx[xu - 1]) : xu;
+		unsigned pld = ind && lane ? (dird ? g.pv[xd + 1] : g.nx[xd - 1]) : xd;
+		unsigned chu = inu ? g.ch[xu] : 0u, chd = ind ? g.ch[xd] : 0u;
+		unsigned bu = inu ? g.bif[d][xu] : BT_NONE, bd = ind ? g.bif[d ^ 1u][xd] : BT_NONE;
+		unsigned lku = inu ? (diru ? g.pv[xu] : g.nx[xu]) : BT_NONE, lkd = ind ? (dird ? g.pv[xd] : g.nx[xd]) : BT_NONE;
+		if (au) {
+			unsigned long long ml = __ballot(inu && plu == xu);
+			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+			unsigned long long ms = __ballot(lane < pre && chu == BT_SEP);
+			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			if (lane < pre && lane < stop) push1(bu);
+			if (stop < pre || pre == 0) cu = BT_NONE; else { cu = __shfl(lku, pre - 1); du += pre; }
+		}
+		if (ad) {
+			unsigned long long ml = __ballot(ind && pld == xd);
+			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+			unsigned long long ms = __ballot(lane < pre && chd == BT_SEP);
+			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			if (lane < pre && lane < stop) push1(bd);
+			if (stop < pre || pre == 0) cd = BT_NONE; else { cd = __shfl(lkd, pre - 1); dd += pre; }
+		}
+	}
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
@@ -1082,9 +1108,8 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 					}
 				if (escape && !solo) { g.big[id] = 1; atomicMin(&g.ctr[CTR_VIOL], id); }     // replay with this id running alone
 			}
-			wave_stamp_writes(g, id, t.push_e, t.push_d, t.push_len, lane);
+			wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane);
 			PH_ADD(6);
-			wave_push_neighbourhood(g, id, t.push_e, t.push_d, t.push_len, lane);
 			PH_ADD(7);
 			for (unsigned i = 0; i < w.n; i++)
 				if (!selective || ((dirty[i >> 6] >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
@@ -1575,7 +1600,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	if (be.prof) {
 		unsigned long long z[16];
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
-		const char *nm[9] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "stamp_writes", "push", "rescan"};
+		const char *nm[9] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan"};
 		for (int i = 0; i < 9; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 		unsigned long long hh[4][16], mx[2];
 		HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
