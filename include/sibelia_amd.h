@@ -71,6 +71,7 @@ typedef struct {
 	uint64_t transactions;           /* ... of which RemoveBulges transactions that owned their neighbourhood and ran */
 	double exchange_ms;              /* sharded enumeration: host time inside the collectives (all-to-all + gathers) */
 	uint64_t exchange_bytes;         /* ... and the bytes this GPU sent to its peers */
+	uint64_t chain_transactions;     /* transactions run by the serial chain (dense conflict neighbourhoods: small k, low complexity) */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

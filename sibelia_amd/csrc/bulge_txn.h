@@ -85,12 +85,13 @@ struct Txn {
 	bool wrote;                         // the graph has been modified by this transaction
 	bool defer_push;                    // the caller performs bt_push_neighbourhood's work itself (64 lanes, simplify.hip)
 	bool ext_stamps;                    // element stamps are done by the caller's wave-wide scans (reads) and post-collapse pass (writes)
+	bool chain;                         // serial chain (simplify.hip: k_chain): nothing else is in flight and no reservation exists to be checked
 	uint32_t push_e, push_d, push_len;  // ... for this target instance / new branch length
 
 	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
 	{
 		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
-		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; push_e = BT_NONE; push_d = 0; push_len = 0;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0;
 	}
 	// ---- scratch
 	__host__ __device__ void *alloc(uint32_t bytes)
@@ -152,7 +153,7 @@ struct Txn {
 	{
 		uint32_t r = g.nblk + b;
 		uint32_t ow = g.own[b], wm = g.wmax[r], rm = write ? g.rmax[r] : 0u;
-		if (mode != 3 && ow != stamp) violation(BT_NONE);                      // escaped its reservation
+		if (mode != 3 && !chain && ow != stamp) violation(BT_NONE);            // escaped its reservation
 		if (wm > tid || rm > tid) violation(BT_NONE);
 		if (mode == 2) { if (write) bt_atomic_max(&g.wmax[r], tid); else bt_atomic_max(&g.rmax[r], tid); }
 	}

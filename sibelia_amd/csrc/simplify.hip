@@ -650,7 +650,7 @@ __device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned
 {
 	unsigned r = g.nblk + b;
 	unsigned ow = g.own[b], wm = g.wmax[r], rm = g.rmax[r];
-	bool bad = ow != stampv || wm > tid || rm > tid;          // not in its claims (escaped the reservation), or a higher id was here first
+	bool bad = (stampv != BT_NONE && ow != stampv) || wm > tid || rm > tid;   // not in its claims (escaped the reservation; none in the serial chain), or a higher id was here first
 	atomicMax(&g.wmax[r], tid);
 	if (bad) {
 		atomicMin(&g.ctr[CTR_VIOL], id);
@@ -1000,40 +1000,18 @@ __device__ unsigned long long g_txn_max[2];        // longest transaction: cycle
 
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
-__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
+// The transaction proper (RemoveBulges for one id) on one wave; t, w, flag, absh and fast live in LDS.
+// solo: 0 = ordered round (the probe found bulges, the entry owns its claims), 1 = the id runs with nothing else in flight
+// (big-arena solo round, or the serial chain: stampv == BT_NONE, no reservation exists and none is checked).
+__device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWork &w, int &flag, ABShared &absh, uint8_t *fast, unsigned fast_bytes,
+                                            unsigned wi, unsigned id, unsigned stampv, int solo, bool prepass, uint8_t *mine, unsigned arena_bytes, int prof)
 {
-	__shared__ Txn t;
-	__shared__ BulgeWork w;
-	__shared__ int flag;
-	__shared__ ABShared absh;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
-	const unsigned wi = blockIdx.x, lane = threadIdx.x;
-	if (wi >= nwin) return;
-	if (!solo && !live[wi]) return;                                   // retired by the probe
-	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
-	if (!solo) {
-		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
-		unsigned n = cb[0];
-		bool owner = true;
-		if (n <= CLAIM_CAP) {
-			for (unsigned i = lane; i < n; i += 64) {
-				unsigned b = cb[1 + i];
-				if (b & 0x80000000u) { if (bt_order_blocked(g, b & 0x7FFFFFFFu)) owner = false; }     // something at or below a lower id of the surroundings is about to run
-				else if (g.own[b] != stampv) owner = false;
-			}
-			owner = !__any(!owner);
-		} else {
-			if (lane == 0) owner = ss_owns_footprint(g, wi);      // list overflowed: serial re-walk
-			owner = __shfl((int)owner, 0) != 0;
-		}
-		if (!owner) return;                                       // stays pending
-	}
-	uint8_t *mine = arena + (size_t)wi * arena_bytes;
+	const unsigned lane = threadIdx.x, tid = id + 1;
 	PH_T0();
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
 	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
-	if (solo) {
-		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; }
+	if (prepass) {
+		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; t.chain = stampv == BT_NONE; }
 		__syncthreads();
 		wave_setup(g, t, w, true, lane, flag);
 		if (flag) {
@@ -1052,7 +1030,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
-	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; w.ret = 0; }
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0; }
 	__syncthreads();
 	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
@@ -1138,6 +1116,85 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 			atomicOr(&g.ctr[CTR_ERR], t.err);
 		}
 		atomicAdd(&g.ctr[CTR_BULGES], w.ret);
+	}
+}
+
+__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ int flag;
+	__shared__ ABShared absh;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
+	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	if (wi >= nwin) return;
+	if (!solo && !live[wi]) return;                                   // retired by the probe
+	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
+	if (!solo) {
+		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
+		unsigned n = cb[0];
+		bool owner = true;
+		if (n <= CLAIM_CAP) {
+			for (unsigned i = lane; i < n; i += 64) {
+				unsigned b = cb[1 + i];
+				if (b & 0x80000000u) { if (bt_order_blocked(g, b & 0x7FFFFFFFu)) owner = false; }     // something at or below a lower id of the surroundings is about to run
+				else if (g.own[b] != stampv) owner = false;
+			}
+			owner = !__any(!owner);
+		} else {
+			if (lane == 0) owner = ss_owns_footprint(g, wi);      // list overflowed: serial re-walk
+			owner = __shfl((int)owner, 0) != 0;
+		}
+		if (!owner) return;                                       // stays pending
+	}
+	commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)wi * arena_bytes, arena_bytes, prof);
+}
+
+// Serial chain: one wave runs what is pending in the id range of the window strictly in ascending order, one transaction
+// after the other, with nothing else in flight -- the sequential order itself, so no reservation.  The driver switches to
+// it when the ordered rounds stop being parallel (dense conflict neighbourhoods: small k, low-complexity sequence), where a
+// round costs four launches and commits one or two transactions.  The probe has already retired the clean entries (need
+// = 0) and marked the live ones (need = 2: no verdict pass needed); the first id made pending by the chain itself (need = 1)
+// ends the stretch -- the next round's probe takes those verdicts in parallel.  Stops at the first error or order violation.
+__global__ void __launch_bounds__(64) k_chain(GraphView g, uint8_t *arena, unsigned arena_bytes, unsigned nwin, int prof)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ int flag;
+	__shared__ ABShared absh;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];
+	const unsigned lane = threadIdx.x;
+	if (!nwin) return;
+	const unsigned long long limit = g.win[nwin - 1];
+	unsigned long long cur = g.win[0];
+	unsigned done = 0;
+	while (cur <= limit) {
+		// next pending id at or after cur: 64 lanes x 8 flags
+		const unsigned long long base = cur & ~7ull, idq = base + 8ull * lane;
+		unsigned long long nb = 0;
+		if (idq <= limit) {
+			nb = *reinterpret_cast<const unsigned long long *>(g.need + idq);
+#pragma unroll
+			for (int j = 0; j < 8; j++) if (idq + j < cur || idq + j > limit) nb &= ~(0xFFull << (8 * j));
+		}
+		unsigned long long hit = __ballot(nb != 0);
+		if (!hit) { cur = base + 512; continue; }
+		unsigned src = (unsigned)__builtin_ctzll(hit);
+		unsigned long long nbs = __shfl(nb, src);
+		const unsigned byte = (unsigned)__builtin_ctzll(nbs) >> 3;
+		const unsigned id = (unsigned)(base + 8ull * src + byte);
+		const bool known_live = ((nbs >> (8 * byte)) & 0xFFull) == 2ull;
+		// an id made pending by the chain itself ends the stretch: its verdict is taken by the next (parallel) probe
+		if (!known_live && done) break;
+		done++;
+		__syncthreads();
+		if (lane == 0) g.big[id] = 0;                                   // the chain always runs in the big arena
+		commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, 0u, id, BT_NONE, 1, !known_live, arena, arena_bytes, prof);
+		__syncthreads();
+		cur = (unsigned long long)id + 1;
+		__threadfence();
+		unsigned stop = lane == 0 ? (g.ctr[CTR_ERR] != 0 || g.ctr[CTR_VIOL] != BT_NONE || g.big[id] != 0) : 0u;   // big: did not even fit the big arena
+		if (__shfl((int)stop, 0)) break;
 	}
 }
 
@@ -1358,6 +1415,18 @@ struct DeviceBackend {
 		HIP_TRY(hipEventRecord(ev[3], c->stream));
 		timed_commit = true;
 		HIP_TRY(hipGetLastError());
+	}
+	// serial chain over what is pending in the id range of the window (k_chain); timed with the commit phase
+	bool chain(uint32_t nwin, uint32_t round)
+	{
+		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		st->big_arena.ensure(big_arena_bytes);
+		HIP_TRY(hipEventRecord(ev[2], c->stream));
+		k_chain<<<1, 64, 0, c->stream>>>(g, st->big_arena.as<uint8_t>(), big_arena_bytes, nwin, prof);
+		HIP_TRY(hipEventRecord(ev[3], c->stream));
+		timed_commit = true;
+		HIP_TRY(hipGetLastError());
+		return true;
 	}
 	SimplifyCounters counters()
 	{
@@ -1595,7 +1664,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
-	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions;
+	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
 	for (auto &e : be.ev) (void)hipEventDestroy(e);
 	if (be.prof) {
 		unsigned long long z[16];

@@ -20,6 +20,7 @@ struct SimplifyReport {
 	uint64_t bulges = 0;
 	uint32_t iterations = 0, rounds = 0, replays = 0, solo = 0, grow_replays = 0;
 	uint64_t executed = 0, transactions = 0;
+	uint64_t chain_transactions = 0;     // ... of which run by the serial chain (dense conflict neighbourhoods)
 };
 
 // Backend concept:
@@ -32,6 +33,8 @@ struct SimplifyReport {
 //   void probe(nwin, round);                         retire window entries whose verdict is false now, flag the others
 //   void mark_live(nwin);                            flag every window entry live (solo rounds skip the probe)
 //   void reserve(nwin, round); void commit(nwin, round, solo);   (flagged entries only)
+//   bool chain(nwin, round);                         run what is pending in the id range of the window one after the other, in order
+//                                                    (instead of reserve + commit; false: not supported)
 //   SimplifyCounters counters();                     device -> host
 //   bool grow(uint32_t err);                         enlarge element / node capacity after BT_ERR_*_CAP
 template <class Backend>
@@ -39,6 +42,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 {
 	SimplifyReport rep;
 	const bool trace = getenv("SBL_TRACE") != nullptr;
+	const bool use_chain = getenv("SBL_NO_CHAIN") == nullptr;          // debugging / measurement switch
 	const uint32_t nid = be.nid();
 	const uint64_t per_iter = (uint64_t)nid + 1;                      // ids 0 .. GetMaxId() inclusive
 	const uint64_t threshold = ((uint64_t)nid * max_iter) / 50;       // PROGRESS_STRIDE, blockfinder.cpp:28
@@ -68,6 +72,8 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 				std::sort(fences.begin(), fences.end());
 				uint32_t lo = 0, round = 0;
 				size_t fi = 0;
+				uint32_t prev_txn = 0, prev_done = 0, starved = 0;
+				bool chain_mode = false;
 				for (;;) {
 					while (fi < fences.size() && fences[fi] < lo) fi++;
 					uint32_t limit = fi < fences.size() ? fences[fi] : nid - 1;
@@ -83,8 +89,11 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					rep.rounds++;
 					if (solo) { rep.solo++; be.mark_live(nwin); }       // a big id runs alone but still claims its neighbourhood
 					else be.probe(nwin, round);
-					be.reserve(nwin, round);
-					be.commit(nwin, round, solo != 0);
+					const bool chained = !solo && chain_mode && be.chain(nwin, round);
+					if (!chained) {
+						be.reserve(nwin, round);
+						be.commit(nwin, round, solo != 0);
+					}
 					SimplifyCounters c = be.counters();
 					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",
 					                   rep.iterations, round, lo, limit, nwin, solo, c.v[CTR_COMMITTED], c.v[CTR_BULGES], c.v[CTR_BIG], (int)c.v[CTR_VIOL], c.v[CTR_ERR]);
@@ -98,6 +107,16 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					}
 					if (replay) break;
 					report_progress((uint64_t)(rep.iterations - 1) * per_iter + lo);
+					// Dense conflict neighbourhoods (small k, low-complexity sequence): nearly every live entry shares a claim
+					// with a lower one, a round commits one or two transactions and costs four launches.  Once most of the
+					// window stays blocked twice in a row, the rest of the iteration runs in chain mode: the probe still retires
+					// the clean entries in parallel, the live ones are then run one after the other, in order (k_chain).
+					const uint32_t txn = c.v[CTR_TXN] - prev_txn, retired = c.v[CTR_COMMITTED] - prev_done;
+					const uint32_t blocked = nwin > retired ? nwin - retired : 0;
+					prev_txn = c.v[CTR_TXN]; prev_done = c.v[CTR_COMMITTED];
+					if (chained) rep.chain_transactions += txn;
+					else if (!solo && blocked >= 8 && txn <= std::max<uint32_t>(2, blocked / 32)) { if (++starved >= 2 && use_chain && !chain_mode) { chain_mode = true; if (trace) fprintf(stderr, "[sbl] iter %u: chain mode from id %u\n", rep.iterations, lo); } }
+					else starved = 0;
 				}
 				if (!replay) {
 					SimplifyCounters c = be.counters();

@@ -93,6 +93,7 @@ struct HostBackend {
 	std::vector<uint32_t> dbg_bif0, dbg_bif1; uint32_t dbg_nn = 0;
 	alignas(16) uint8_t fastbuf[24576];      // stands in for the kernels' LDS scratch
 	std::vector<uint8_t> live;
+	bool chain(uint32_t, uint32_t) { return false; }      // the host driver always runs ordered rounds
 	void probe(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;

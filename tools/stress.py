@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle stress (not part of the test suite): python tools/stress.py [seconds] [first_seed]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from sibelia_amd import BlockFinder, workloads as W        # noqa: E402
+from oracle.oracle import Oracle                            # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t0 = time.time()
+done = bad = 0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 13))
+    L0 = int(rng.integers(3_000, 80_000))
+    k = int(rng.choice([9, 12, 15, 16, 20, 25, 31, 32, 40]))
+    D = int(rng.integers(k, 12 * k))
+    snp = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
+    seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
+                         inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
+    stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
+    print("case", seed, "n", n, "L0", L0, "stages", stages, "snp", snp, end=" ", flush=True)
+    bf, orc = BlockFinder(seqs, device=0), Oracle(seqs)
+    tg = tc = 0.0
+    if rng.random() < 0.3:
+        bf.set_window(int(rng.choice([1, 3, 64, 1000])))
+    ok = True
+    for kk, dd in stages:
+        t1 = time.time(); a = bf.simplify_stage(kk, dd, 4); t2 = time.time(); b = orc.simplify_stage(kk, dd, 4); t3 = time.time()
+        tg += t2 - t1; tc += t3 - t2
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        ok = ok and a == b and sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    st = bf.stats()
+    done += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, "n", n, "L0", L0, "stages", stages, "snp", snp, flush=True)
+    else:
+        print("ok bulges", a, "rounds", st["rounds"], "replays", st["replays"], "gpu %.2fs cpu %.2fs" % (tg, tc), flush=True)
+    bf.close()
+    seed += 1
+print("done", done, "mismatches", bad)
