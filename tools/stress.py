@@ -17,7 +17,7 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     n = int(rng.integers(2, 13))
     L0 = int(rng.integers(3_000, 80_000))
-    k = int(rng.choice([9, 12, 15, 16, 20, 25, 31, 32, 40]))
+    k = int(rng.choice([15, 16, 20, 25, 31, 32, 40]))
     D = int(rng.integers(k, 12 * k))
     snp = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
     seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
