@@ -600,12 +600,35 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	if (w >= nwin || !live[w]) return;
 	__shared__ unsigned seen[SEEN_SLOTS];
-	__shared__ unsigned resume[RESUME_SLOTS];
-	__shared__ unsigned nclaims;
+	__shared__ unsigned resume[RESUME_SLOTS], inst[RESUME_SLOTS];     // per instance: end of the core walk; (element << 1) | strand
+	__shared__ unsigned nclaims, ninst_s;
 	for (unsigned i = threadIdx.x; i < SEEN_SLOTS; i += 64 * RSV_WAVES) seen[i] = BT_NONE;
 	if (threadIdx.x == 0) nclaims = 0;
-	__syncthreads();
 	unsigned id = g.win[w], st = g.round_bits | w;
+	if (wv == 0) {
+		// ListPositions by 64 lanes (see wave_list_positions): the instances land in LDS, the waves then share them out
+		unsigned m = 0;
+		for (unsigned s = 0; s < 2; s++) {
+			unsigned cur = g.head[s][id];
+			while (cur != BT_NONE) {
+				const bool inr = (unsigned long long)cur + lane < g.cap_n;
+				const unsigned nd = cur + lane;
+				const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
+				const unsigned dead = inr ? g.ndead[nd] : 1u;
+				const unsigned el = inr ? g.nslot[nd] : 0u;
+				const unsigned long long cont = __ballot(inr && nxt == nd + 1);
+				const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;
+				const bool on = lane < pre && inr;
+				const unsigned long long lv = __ballot(on && !dead);
+				const unsigned off = m + __popcll(lv & ((1ull << lane) - 1ull));
+				if (on && !dead && off < RESUME_SLOTS) inst[off] = (el << 1) | s;
+				m += (unsigned)__popcll(lv);
+				cur = __shfl(nxt, pre - 1);
+			}
+		}
+		if (lane == 0) ninst_s = m;
+	}
+	__syncthreads();
 	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = &nclaims; cl.seen = seen;
 	if (wv == 0) wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
 	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
@@ -613,30 +636,41 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 	// strands) -- claimed exclusively, the instance lists of those ids may be rewritten; instances upstream on the same
 	// strand and further downstream on the opposite strand walk towards the core -- the transaction can only make them
 	// stale, which orders it against them (bt_footprint, bulge_txn.h); instances walking away cannot see or touch it.
-	unsigned ninst = 0;
-	for (unsigned s = 0; s < 2; s++)                                  // all exclusive claims first: the seen-set keeps the first kind
-		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
-			if (g.ndead[nd]) continue;
-			if (ninst % RSV_WAVES == wv) {
-				unsigned nxt = wave_walk_claim(g, g.nslot[nd], s, core, lane, 3u, cl, st);
-				if (lane == 0 && ninst < RESUME_SLOTS) resume[ninst] = nxt;
-			}
-			ninst++;
-		}
-	__syncthreads();
 	auto order = [&](unsigned b0, unsigned b1) { wave_claim_order(g, cl, st, id, b0, lane); wave_claim_order(g, cl, st, id, b1, lane); };
-	unsigned done = 0;
-	for (unsigned s = 0; s < 2; s++)
-		for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
-			if (g.ndead[nd]) continue;
-			if (done % RSV_WAVES == wv) {
-				unsigned e0 = g.nslot[nd];
-				unsigned nxt = done < RESUME_SLOTS ? resume[done] : wave_walk_marks(g, e0, s, core, lane, 0u, [](unsigned, unsigned) {});
-				if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
-				wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
-			}
-			done++;
+	const unsigned ninst = ninst_s;
+	if (ninst <= RESUME_SLOTS) {
+		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
+			unsigned nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st);
+			if (lane == 0) resume[i] = nxt;
 		}
+		__syncthreads();
+		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {
+			const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
+			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
+			wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
+		}
+	} else {                                                          // more instances than the LDS list holds: walk the node lists
+		unsigned k1 = 0;
+		for (unsigned s = 0; s < 2; s++)
+			for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+				if (g.ndead[nd]) continue;
+				if (k1 % RSV_WAVES == wv) wave_walk_claim(g, g.nslot[nd], s, core, lane, 3u, cl, st);
+				k1++;
+			}
+		__syncthreads();
+		unsigned k2 = 0;
+		for (unsigned s = 0; s < 2; s++)
+			for (unsigned nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+				if (g.ndead[nd]) continue;
+				if (k2 % RSV_WAVES == wv) {
+					unsigned e0 = g.nslot[nd];
+					unsigned nxt = wave_walk_marks(g, e0, s, core, lane, 0u, [](unsigned, unsigned) {});
+					if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
+					wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
+				}
+				k2++;
+			}
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) cl.buf[0] = nclaims;
 }

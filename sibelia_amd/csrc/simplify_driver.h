@@ -109,13 +109,18 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					report_progress((uint64_t)(rep.iterations - 1) * per_iter + lo);
 					// Dense conflict neighbourhoods (small k, low-complexity sequence): nearly every live entry shares a claim
 					// with a lower one, a round commits one or two transactions and costs four launches.  Once most of the
-					// window stays blocked twice in a row, the rest of the iteration runs in chain mode: the probe still retires
+					// window stays blocked behind one or two transactions twice in a row, the rest of the iteration runs in chain mode: the probe still retires
 					// the clean entries in parallel, the live ones are then run one after the other, in order (k_chain).
 					const uint32_t txn = c.v[CTR_TXN] - prev_txn, retired = c.v[CTR_COMMITTED] - prev_done;
 					const uint32_t blocked = nwin > retired ? nwin - retired : 0;
 					prev_txn = c.v[CTR_TXN]; prev_done = c.v[CTR_COMMITTED];
 					if (chained) rep.chain_transactions += txn;
-					else if (!solo && blocked >= 8 && txn <= std::max<uint32_t>(2, blocked / 32)) { if (++starved >= 2 && use_chain && !chain_mode) { chain_mode = true; if (trace) fprintf(stderr, "[sbl] iter %u: chain mode from id %u\n", rep.iterations, lo); } }
+					else if (!solo && blocked >= 8 && txn <= 2) {       // absolute: a handful of slow transactions per round still beat one wave
+						if (++starved >= 2 && use_chain && !chain_mode) {
+							chain_mode = true;
+							if (trace) fprintf(stderr, "[sbl] iter %u: chain mode from id %u\n", rep.iterations, lo);
+						}
+					}
 					else starved = 0;
 				}
 				if (!replay) {
