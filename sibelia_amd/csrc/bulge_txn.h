@@ -82,6 +82,8 @@ struct Txn {
 	uint8_t *fscr; uint32_t fscr_cap, fscr_used;   // optional small fast scratch (LDS in the kernels); falloc never fails loudly
 	uint32_t err;
 	uint32_t tc_head;                   // lazy erase chain (BifurcationStorage::toClear_), linked through g.nclr
+	uint32_t *tc_list; uint32_t tc_cap, tc_n;   // the same nodes as a flat list when the caller runs Cleanup with 64 lanes (defer_cleanup)
+	bool defer_cleanup;
 	bool wrote;                         // the graph has been modified by this transaction
 	bool defer_push;                    // the caller performs bt_push_neighbourhood's work itself (64 lanes, simplify.hip)
 	bool ext_stamps;                    // element stamps are done by the caller's wave-wide scans (reads) and post-collapse pass (writes)
@@ -91,7 +93,7 @@ struct Txn {
 	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
 	{
 		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
-		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; tc_list = nullptr; tc_cap = 0; tc_n = 0; defer_cleanup = false; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0;
 	}
 	// ---- scratch
 	__host__ __device__ void *alloc(uint32_t bytes)
@@ -865,7 +867,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 		w.gi++;
 		if (w.gi < w.ab.ngroups) w.idI = w.ab.grp_off[w.gi];
 	}
-	t.cleanup();
+	if (!t.defer_cleanup) t.cleanup();           // (simplify.hip: Cleanup by all lanes once the loops are over)
 	return false;
 }
 

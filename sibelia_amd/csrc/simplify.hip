@@ -700,6 +700,7 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 	g.bif[strand][e] = BT_NONE;
 	g.ndead[nd] = 1;
 	g.nclr[nd] = atomicExch(&t.tc_head, nd);
+	{ unsigned ix = atomicAdd(&t.tc_n, 1u); if (ix < t.tc_cap) t.tc_list[ix] = nd; }
 	if (t.mode) wave_stamp_id_write(g, stampv, t.tid, t.id, b);
 	if (b < g.nid) { g.touch[b] = 1; if (b > t.id) g.need[b] = 1; }
 }
@@ -1064,7 +1065,8 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
-	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0; }
+	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0;
+	                 t.tc_cap = 1024; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true; }
 	__syncthreads();
 	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
@@ -1136,6 +1138,13 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			}
 			PH_ADD(8);
 		}
+	}
+	// ---- Cleanup (bifurcationstorage.cpp:33-41) once the loops are over: the erased nodes leave their lists' sizes, all lanes
+	__syncthreads();
+	if (!t.err && t.tc_n) {
+		if (t.tc_n <= t.tc_cap) {
+			for (unsigned x = lane; x < t.tc_n; x += 64) { unsigned v = g.nidst[t.tc_list[x]]; atomicSub(&g.lsize[v & 1u][v >> 1], 1u); }
+		} else if (lane == 0) t.cleanup();                              // more erased nodes than the flat list holds: walk the chain
 	}
 	if (lane == 0) {
 		if (prof) {
