@@ -23,7 +23,9 @@
 #define BT_DEAD_CHAR 0            // ch[] of an element that was erased from the list
 #define BT_POS_MASK 0x1FFFFFFFu   // 29-bit original positions (reference src/stranditerator.cpp:19-27)
 #define BT_MAX_BREAKS 16u
+#ifndef BT_LDS_MARKS
 #define BT_LDS_MARKS 48u
+#endif
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,

@@ -1035,6 +1035,9 @@ __device__ unsigned long long g_txn_max[2];        // longest transaction: cycle
 
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
+#ifndef COMMIT_FAST_BYTES
+#define COMMIT_FAST_BYTES 8192               // LDS scratch of a transaction; with Txn / BulgeWork ~9 KB per workgroup = 17 workgroups per CU (12 KB: 12, and 4 % slower)
+#endif
 // The transaction proper (RemoveBulges for one id) on one wave; t, w, flag, absh and fast live in LDS.
 // solo: 0 = ordered round (the probe found bulges, the entry owns its claims), 1 = the id runs with nothing else in flight
 // (big-arena solo round, or the serial chain: stampv == BT_NONE, no reservation exists and none is checked).
@@ -1168,7 +1171,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ BulgeWork w;
 	__shared__ int flag;
 	__shared__ ABShared absh;
-	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
+	__shared__ __attribute__((aligned(16))) uint8_t fast[COMMIT_FAST_BYTES];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
