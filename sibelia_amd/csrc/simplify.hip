@@ -594,7 +594,9 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
+#ifndef RSV_WAVES
 #define RSV_WAVES 4u                         // waves of a reservation workgroup: the instances of the id are dealt out to them
+#endif
 __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
