@@ -419,7 +419,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		if (w.wdel) for (uint32_t i = 0; i < n; i++) w.wdel[i] = 0;
 		w.visit = (uint64_t *)t.alloc2(w.visit_cap * 8);
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
-		w.lb = (uint32_t *)t.alloc(k * 8); w.lf = (uint32_t *)t.alloc(k * 8);
+		w.lb = (uint32_t *)t.alloc2(k * 8); w.lf = (uint32_t *)t.alloc2(k * 8);   // flank lists of a collapse: read back by other lanes, LDS when it fits
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
 	}
 	if (t.err) return false;
