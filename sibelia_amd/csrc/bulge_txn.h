@@ -356,6 +356,7 @@ struct BulgeWork {
 	uint32_t *wst; char *wck;     // mark at step 0 and (oriented) character at step k of each window
 	uint32_t *wbk, *wnb;          // steps at which the walk leaves consecutive slots (BT_MAX_BREAKS per window) and their number
 	uint32_t *wdel;              // elements this transaction has deleted inside each window (reach beyond the reserved range, simplify.hip)
+	unsigned long long *dirty_big; // ids with more than 256 instances: bit per window "saw the region of the last collapse" (simplify.hip)
 	bool lite;                   // verdict-only use: wel / wbf / wch are not materialised
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
@@ -407,7 +408,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.mks = BT_LDS_MARKS;
 	if (!w.wmk) { w.wmk = (uint64_t *)t.alloc(n * w.ws * 8); w.mks = w.ws; }
 	w.lite = lite;
-	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr; w.dirty_big = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
 	if (!lite) {
 		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
@@ -421,6 +422,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
 		w.lb = (uint32_t *)t.alloc2(k * 8); w.lf = (uint32_t *)t.alloc2(k * 8);   // flank lists of a collapse: read back by other lanes, LDS when it fits
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
+		if (n > 256) w.dirty_big = (unsigned long long *)t.alloc(((n + 63) / 64) * 8);
 	}
 	if (t.err) return false;
 	if (!fill_list) return true;                    // the caller lists the positions itself (64 lanes, simplify.hip: wave_list_positions)
