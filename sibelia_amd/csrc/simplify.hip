@@ -1098,8 +1098,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			// which cached windows see the region about to be rewritten (target start .. end of its look-forward flank)?
 			// only those are rescanned afterwards -- normally just the target's own window
 			unsigned long long dirty[4] = {0, 0, 0, 0};                   // up to 256 windows in registers, more in the arena (w.dirty_big)
-			const bool selective = w.n <= 256 || w.dirty_big != nullptr;
-			auto is_dirty = [&](unsigned i) { return (((w.n <= 256 ? dirty[(i >> 6) & 3u] : w.dirty_big[i >> 6]) >> (i & 63)) & 1ull) != 0; };
+			const bool big = w.n > 256, selective = !big || w.dirty_big != nullptr;
 			if (selective) {
 				const unsigned tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
 				for (unsigned i0 = 0; i0 < w.n; i0 += 64) {
@@ -1111,7 +1110,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 						d = i == tg || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0;
 					}
 					const unsigned long long bits = __ballot(d);
-					if (w.n <= 256) dirty[(i0 >> 6) & 3u] = bits; else if (lane == 0) w.dirty_big[i0 >> 6] = bits;
+					if (!big) dirty[i0 >> 6] = bits; else if (lane == 0) w.dirty_big[i0 >> 6] = bits;
 				}
 			}
 			PH_ADD(4);
@@ -1123,7 +1122,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				const unsigned F = 2 * (g.D + g.k + 2) + g.k, del = w.c_dT - w.c_dS;
 				bool escape = !selective;
 				for (unsigned i = 0; i < w.n && selective; i++)
-					if (is_dirty(i)) {
+					if (((big ? w.dirty_big[i >> 6] : dirty[i >> 6]) >> (i & 63)) & 1ull) {
 						w.wdel[i] += del;
 						if (g.D + g.k + 2 + w.wdel[i] > F || (g.D - 1) + 3 * g.k + g.D + 2 + w.wdel[i] > F + g.D - 1 - w.c_dS) escape = true;
 					}
@@ -1133,7 +1132,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			PH_ADD(6);
 			PH_ADD(7);
 			for (unsigned i = 0; i < w.n; i++)
-				if (!selective || is_dirty(i)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+				if (!selective || (((big ? w.dirty_big[i >> 6] : dirty[i >> 6]) >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			__syncthreads();
 			if (w.mk_overflow) {
 				__syncthreads();
