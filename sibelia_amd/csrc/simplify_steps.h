@@ -2,7 +2,7 @@
 //
 // SimplifyGraph (reference src/blockfinder.cpp:16-51) is strictly ordered: for iter, for id ascending,
 // RemoveBulges(id).  On the GPU one iteration becomes
-//   1. snapshot:  AnyBulges verdict of EVERY id against the graph at iteration start, one thread per id
+//   1. snapshot:  AnyBulges verdict of EVERY id against the graph at iteration start, one wave per id (one thread here)
 //                 (replaces ~instances x (D-1) x iterations cache-cold window steps of the reference);
 //   2. ordered rounds over the ids that need to run (verdict true, or made stale by an earlier commit):
 //        select   the W lowest pending ids,
@@ -13,7 +13,7 @@
 //                 ahead in the order.
 //      A committed transaction is isolated inside its round (nobody else owns anything it can reach) and
 //      no lower pending id can reach what it touches, so the result equals the sequential order.
-//   3. validation: commits publish per-32-element-block and per-id read/write stamps; touching something
+//   3. validation: commits publish per-element and per-id read/write stamps; touching something
 //      a HIGHER id already wrote (or, for writers, read) means a lower id became pending too late -- the
 //      host then restores the iteration checkpoint and replays with that id as a fence.
 // Results are therefore exact by construction + detection, never by assumption.
