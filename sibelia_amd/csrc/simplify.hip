@@ -467,6 +467,44 @@ __device__ __forceinline__ unsigned wave_walk_marks(const GraphView &g, unsigned
 	return cur;                                                                  // the element after the last one visited (BT_NONE: end of chromosome)
 }
 
+// Two independent walks advancing together (one memory round trip serves both): same visiting rules as wave_walk_marks.
+template <class F>
+__device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca, unsigned dira, unsigned na, unsigned sa,
+                                                 unsigned cb, unsigned dirb, unsigned nb, unsigned sb, unsigned lane, F f)
+{
+	unsigned da = 0, db = 0;
+	while ((da < na && ca != BT_NONE) || (db < nb && cb != BT_NONE)) {
+		const bool aa = da < na && ca != BT_NONE, ab = db < nb && cb != BT_NONE;
+		const bool ina = aa && da + lane < na && (dira ? lane <= ca : (unsigned long long)ca + lane < g.cap_e);
+		const bool inb = ab && db + lane < nb && (dirb ? lane <= cb : (unsigned long long)cb + lane < g.cap_e);
+		const unsigned xa = dira ? ca - lane : ca + lane, xb = dirb ? cb - lane : cb + lane;
+		const unsigned pla = ina && lane ? (dira ? g.pv[xa + 1] : g.nx[xa - 1]) : xa;
+		const unsigned plb = inb && lane ? (dirb ? g.pv[xb + 1] : g.nx[xb - 1]) : xb;
+		const unsigned cha = ina ? g.ch[xa] : 0u, chb = inb ? g.ch[xb] : 0u;
+		const unsigned a0 = ina && (sa & 1u) ? g.bif[0][xa] : BT_NONE, a1 = ina && (sa & 2u) ? g.bif[1][xa] : BT_NONE;
+		const unsigned b0 = inb && (sb & 1u) ? g.bif[0][xb] : BT_NONE, b1 = inb && (sb & 2u) ? g.bif[1][xb] : BT_NONE;
+		const unsigned lka = ina ? (dira ? g.pv[xa] : g.nx[xa]) : BT_NONE, lkb = inb ? (dirb ? g.pv[xb] : g.nx[xb]) : BT_NONE;
+		if (aa) {
+			unsigned long long ml = __ballot(ina && pla == xa);
+			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+			unsigned long long ms = __ballot(lane < pre && cha == BT_SEP);
+			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			bool proc = lane < pre && lane < stop;
+			f(proc ? a0 : BT_NONE, proc ? a1 : BT_NONE);
+			if (stop < pre || pre == 0) ca = BT_NONE; else { ca = __shfl(lka, pre - 1); da += pre; }
+		}
+		if (ab) {
+			unsigned long long ml = __ballot(inb && plb == xb);
+			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+			unsigned long long ms = __ballot(lane < pre && chb == BT_SEP);
+			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+			bool proc = lane < pre && lane < stop;
+			f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
+			if (stop < pre || pre == 0) cb = BT_NONE; else { cb = __shfl(lkb, pre - 1); db += pre; }
+		}
+	}
+}
+
 __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
 {
 	bool has = b != BT_NONE;
@@ -648,8 +686,9 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 		__syncthreads();
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {
 			const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
-			if (nxt != BT_NONE && fwd + 1 > core) wave_walk_marks(g, nxt, s, fwd + 1 - core, lane, 1u << (s ^ 1u), order);
-			wave_walk_marks(g, s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, lane, 1u << s, order);
+			// further downstream (opposite strand) and upstream (same strand) together
+			wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
+			                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order);
 		}
 	} else {                                                          // more instances than the LDS list holds: walk the node lists
 		unsigned k1 = 0;
