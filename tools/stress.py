@@ -24,9 +24,15 @@ while time.time() - t0 < budget:
                          inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
     stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
     print("case", seed, "n", n, "L0", L0, "stages", stages, "snp", snp, end=" ", flush=True)
-    bf, orc = BlockFinder(seqs, device=0), Oracle(seqs)
+    nshard = int(__import__("os").environ.get("SHARD", "0"))          # SHARD=3: the same run through 3 virtual ranks (sharded enumeration)
+    if nshard:
+        from sibelia_amd.dist import LocalShardedFinder
+        bf = LocalShardedFinder(seqs, [0] * nshard)
+    else:
+        bf = BlockFinder(seqs, device=0)
+    orc = Oracle(seqs)
     tg = tc = 0.0
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 and not nshard:
         bf.set_window(int(rng.choice([1, 3, 64, 1000])))
     ok = True
     for kk, dd in stages:
@@ -35,6 +41,7 @@ while time.time() - t0 < budget:
         (sa, pa), (sb, pb) = bf.state(), orc.state()
         ok = ok and a == b and sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
     st = bf.stats()
+    if nshard: st = st[0]
     done += 1
     if not ok:
         bad += 1
