@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 		bool has = verdict > 0;
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
-		if (!has) { g.need[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }
+		if (!has) { g.need[id] = 0; g.touch[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }   // verdict taken now: clean until somebody touches it again
 		else if (!t.err) g.need[id] = 2;
 		live[wi] = has ? 1 : 0;
 	}

@@ -62,7 +62,7 @@ __host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint
 	bool has = false;
 	if (bt_setup(t, w, true)) { bt_scan_all(t, w); bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 	if (t.err) return true;                    // undecidable here: let the commit path sort it out
-	if (!has) { g.need[id] = 0; bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u); }
+	if (!has) { g.need[id] = 0; g.touch[id] = 0; bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u); }   // verdict taken now: clean until touched again
 	return has;
 }
 
