@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Regenerate tests/golden/vectors.json from the UNMODIFIED reference (build container only).
 
-Test infrastructure.  Needs /root/reference and a reference build under /tmp/refbuild
-(make_golden.sh creates it with the reference's own CMake, out of tree) plus the
-ref_dump driver (ref_dump.cpp in this directory, linked against the reference's
-object files).  Nothing from the reference is copied into the repo: only inputs
+Test infrastructure.  Needs /root/reference and oracle/_ref/ref_dump (oracle/build_ref.sh compiles
+the reference's sources in place with gcc/g++ directly — no CMake — together with the
+oracle/ref_dump.cpp driver).  Nothing from the reference is copied into the repo: only inputs
 (generated here, or the two example FASTA sets the reference ships) and the sha256 /
 small literal outputs of the reference run on them are committed.
 
@@ -21,7 +20,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
 sys.path.insert(0, ROOT)
 from sibelia_amd import workloads as W  # noqa: E402
 
-REF_DUMP = "/tmp/refbuild/ref_dump"
+REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
 REF = "/root/reference"
 
 
@@ -155,7 +154,7 @@ def main():
         byname[name] = {"name": name, "input": spec, "input_sha256": W.input_digest(seqs), "outputs": outs}
         print(name, [(o["cmd"], o.get("bulges"), o.get("bif_count")) for o in outs], flush=True)
     vec = [byname[n] for n in order if n in byname]
-    json.dump({"reference": "bioinf/Sibelia 3.0.7 (unmodified, built out of tree with its own CMake, g++ 11.4, -O3 -DNDEBUG)",
+    json.dump({"reference": "bioinf/Sibelia 3.0.7 (unmodified, sources compiled in place by oracle/build_ref.sh, g++ 11.4, -O3 -DNDEBUG)",
                "skipped": sorted(skipped), "vectors": vec}, open(out, "w"), indent=0, separators=(",", ":"))
     print("wrote", out, len(vec), "vectors")
 
