@@ -27,6 +27,11 @@
 #define BT_LDS_MARKS 48u
 #endif
 #define BT_BLOCK_SHIFT 0          // validation granularity: single elements (coarser blocks flag neighbours across a chromosome boundary)
+// Fresh element slots per insertion are a multiple of this.  Validation works on single elements (BT_BLOCK_SHIFT 0), so an
+// insertion takes exactly the slots it needs: low-complexity inputs make tens of thousands of 1-3 element insertions per
+// stage and would otherwise burn the element pool 32 slots at a time (grow + replay of the iteration, again and again).
+#define BT_INSERT_ALIGN 1u
+__host__ __device__ __forceinline__ uint32_t bt_insert_span(uint32_t m) { return (m + BT_INSERT_ALIGN - 1u) & ~(BT_INSERT_ALIGN - 1u); }
 
 enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
        CTR_BIG = 8, CTR_PUSHED = 9, CTR_TXN = 10, CTR_COUNT = 16 };
@@ -592,7 +597,7 @@ __host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t d
 		g.nx[before] = cur; g.pv[cur] = before;
 	} else if (dS > dT) {                            // insert the deficit before `target`
 		uint32_t m = dS - dT;
-		uint32_t span = (m + 31u) & ~31u;            // whole validation blocks per insertion: no block is shared by two transactions
+		uint32_t span = bt_insert_span(m);
 		uint32_t base = bt_atomic_add(&g.ctr[CTR_NE], span);
 		if (base + span > g.cap_e) { t.err |= BT_ERR_ELEM_CAP; return; }
 		t.tr(target);

@@ -786,7 +786,7 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		t.wrote = true;
 		unsigned newbase = BT_NONE;
 		if (dS > dT) {
-			unsigned span = (dS - dT + 31u) & ~31u;
+			unsigned span = bt_insert_span(dS - dT);
 			unsigned base = atomicAdd(&g.ctr[CTR_NE], span);
 			if (base + span > g.cap_e) t.err |= BT_ERR_ELEM_CAP; else newbase = base;
 		}
@@ -804,7 +804,7 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		if (dS < dT) {
 			if (lane == 0) { unsigned before = P(dS - 1); g.nx[before] = Eafter; g.pv[Eafter] = before; }
 		} else if (dS > dT) {
-			const unsigned m = dS - dT, span = (m + 31u) & ~31u, before0 = P(dT - 1);
+			const unsigned m = dS - dT, span = bt_insert_span(m), before0 = P(dT - 1);
 			for (unsigned i0 = 0; i0 < span; i0 += 64) {
 				unsigned i = i0 + lane;
 				if (i >= span) break;

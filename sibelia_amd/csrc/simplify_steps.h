@@ -88,10 +88,26 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	bt_setup(t, w);
 	bt_scan_all(t, w);
 	bool more = !t.err && bt_rb_begin(t, w);
+	// windows that see the region a collapse rewrites (target start .. end of its look-forward flank) are the only ones whose
+	// cache changes: like k_commit (simplify.hip), only those are rescanned -- normally just the target's own window
+	uint64_t *dirty = more ? (uint64_t *)t.alloc(((w.n + 63) / 64) * 8) : nullptr;
+	if (more && !dirty) more = false;
 	while (more) {
 		more = bt_rb_run(t, w);
 		if (t.err) break;
-		if (more) { bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT); if (t.err) break; bt_scan_all(t, w); }
+		if (more) {
+			const uint32_t tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
+			const uint32_t tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
+			for (uint32_t i = 0; i < w.n; i++) {
+				if ((i & 63) == 0) dirty[i >> 6] = 0;
+				const uint32_t len = w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws;      // cached steps incl. the separator step
+				if (i == tg || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0) dirty[i >> 6] |= 1ull << (i & 63);
+			}
+			bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT);
+			if (t.err) break;
+			for (uint32_t i = 0; i < w.n; i++) if ((dirty[i >> 6] >> (i & 63)) & 1ull) bt_scan_instance(t, w, i);
+			if (w.mk_overflow) { bt_marks_to_arena(t, w); if (!t.err) for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
+		}
 	}
 	if (t.err) {
 		if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }

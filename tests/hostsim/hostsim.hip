@@ -208,7 +208,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 			be.bif[s].assign(cap, BT_NONE); be.nodeof[s].assign(cap, BT_NONE);
 			be.head[s].assign((size_t)bif_count + 1, BT_NONE); be.lsize[s].assign((size_t)bif_count + 1, 0);
 		}
-		size_t ncap = n0 + n1 + 1024;
+		size_t ncap = n0 + n1 + 1024 + (size_t)slack_elems * 4;   // (the product sizes its node pool 4 x instances + 1 M)
 		be.nslot.assign(ncap, 0); be.nidst.assign(ncap, 0); be.nnext.assign(ncap, BT_NONE); be.nclr.assign(ncap, BT_NONE); be.ndead.assign(ncap, 0);
 		be.ctr.assign(CTR_COUNT, 0); be.need.assign((size_t)bif_count + 1, 0); be.big.assign((size_t)bif_count + 1, 0); be.touch.assign((size_t)bif_count + 1, 0);
 		be.own.assign((size_t)bif_count + 1, 0xFFFFFFFFu);

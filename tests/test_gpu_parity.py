@@ -119,7 +119,9 @@ def test_full_size_stage_is_independent_of_the_speculation_window():
     # this input (1 120 044 ids, 7 089 276 instances, 334 284 bulges)
     import hashlib
     from sibelia_amd import workloads as W, formats as F
-    seqs = W.gen_strains(L0=4_600_000, n=8, seed=1)
+    gold = [v for v in VECS if v["name"] == "synth/strains8_4600k"][0]      # outputs of the unmodified reference on this input (499.8 s there)
+    seqs = V.vector_input(gold)
+    gold_stage = [o for o in gold["outputs"] if o["cmd"] == "stage:25:150:4"][0]
     digests = []
     for window in (16384, 3000, 16384):
         bf = _bf(seqs)
@@ -131,6 +133,22 @@ def test_full_size_stage_is_independent_of_the_speculation_window():
         digests.append(hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest())
         bf.close()
     assert digests[0] == digests[1] == digests[2]
+    assert digests[0] == gold_stage["sha256"], "post-stage state differs from the reference's (sequences + original positions, bit for bit)"
+
+
+def test_full_size_enumeration_matches_reference():
+    # E1/E2 on the metric workload: ids and instances sha256-identical to the reference's (1 120 044 ids / 7 089 276 instances)
+    gold = [v for v in VECS if v["name"] == "synth/strains8_4600k"][0]
+    o = [o for o in gold["outputs"] if o["cmd"] == "enum:25"][0]
+    bf = _bf(V.vector_input(gold))
+    got = V.run_cmd(bf, "enum:25")
+    bf.close()
+    assert len(got) == o["size"] and F_sha(got) == o["sha256"]
+
+
+def F_sha(b):
+    import hashlib
+    return hashlib.sha256(b).hexdigest()
 
 
 def test_many_strains_small_genomes_match_oracle():
