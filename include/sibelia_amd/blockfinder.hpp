@@ -8,6 +8,7 @@
 #ifndef SIBELIA_AMD_BLOCKFINDER_HPP
 #define SIBELIA_AMD_BLOCKFINDER_HPP
 #include <cstdio>
+#include <exception>
 #include <functional>
 #include <ostream>
 #include <stdexcept>
@@ -36,8 +37,11 @@ namespace SyntenyFinderAMD
 		size_t PerformGraphSimplifications(size_t k, size_t minBranchSize, size_t maxIterations, ProgressCallBack f = ProgressCallBack())
 		{
 			uint64_t bulges = 0;
-			Check(sbl_simplify_stage(ctx_, (uint32_t)k, (uint32_t)minBranchSize, (uint32_t)maxIterations,
-			                         f ? &Trampoline : nullptr, f ? &f : nullptr, &bulges), "PerformGraphSimplifications");
+			CallBackBox box{f, nullptr};
+			sbl_status st = sbl_simplify_stage(ctx_, (uint32_t)k, (uint32_t)minBranchSize, (uint32_t)maxIterations,
+			                                   f ? &Trampoline : nullptr, f ? &box : nullptr, &bulges);
+			if (box.thrown) std::rethrow_exception(box.thrown);      // a throwing callback never unwinds through the C ABI: the stage completes first
+			Check(st, "PerformGraphSimplifications");
 			return (size_t)bulges;
 		}
 
@@ -98,11 +102,15 @@ namespace SyntenyFinderAMD
 				ptr.push_back(reinterpret_cast<const uint8_t *>(s.data()));
 				len.push_back(s.size());
 			}
-			Check(sbl_load(ctx_, (uint32_t)ptr.size(), ptr.data(), len.data()), "Init");
+			try { Check(sbl_load(ctx_, (uint32_t)ptr.size(), ptr.data(), len.data()), "Init"); }
+			catch (...) { sbl_destroy(ctx_); ctx_ = nullptr; throw; }        // the destructor of a half-built object never runs
 		}
+		struct CallBackBox { ProgressCallBack &f; std::exception_ptr thrown; };
 		static void Trampoline(size_t progress, int state, void *user)
 		{
-			(*static_cast<ProgressCallBack *>(user))(progress, static_cast<State>(state));
+			CallBackBox *box = static_cast<CallBackBox *>(user);
+			if (box->thrown) return;
+			try { box->f(progress, static_cast<State>(state)); } catch (...) { box->thrown = std::current_exception(); }
 		}
 		void Check(sbl_status st, const char *what) const
 		{

@@ -83,6 +83,20 @@ static void sanitise_revert(sbl_ctx *c)
 	HIP_TRY(hipStreamSynchronize(c->stream));
 }
 void sbl_sanitise_commit(sbl_ctx *c) { c->amb_elem.clear(); c->amb_orig.clear(); }
+// sbl_enumerate / sbl_list_edges look at a sanitised COPY (a fresh IndexedSequence, reference src/indexedsequence.cpp:28-37):
+// the replacement is applied to the resident state for the duration of the call and taken back on every way out --
+// also when the enumeration throws (OOM, TOO_LARGE, a failed collective), together with the rand() stream.
+struct SanitiseScope {
+	sbl_ctx *c; bool applied; GlibcRand rng0; bool ok = false;
+	explicit SanitiseScope(sbl_ctx *cx) : c(cx), rng0(cx->rng) { applied = sanitise_apply(cx); }
+	void done() { ok = true; }
+	~SanitiseScope()
+	{
+		if (!applied) return;
+		try { sanitise_revert(c); } catch (...) { }
+		if (!ok) c->rng = rng0;
+	}
+};
 
 // K1
 void sbl_pack(sbl_ctx *c)
@@ -235,7 +249,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_longk_free(c);
 	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -288,7 +302,7 @@ extern "C" sbl_status sbl_enumerate(sbl_ctx *c, uint32_t k, uint32_t *bif_count,
 {
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-		bool temp = sanitise_apply(c);
+		SanitiseScope scope(c);
 		sbl_run_enumeration(c, k, c->nelem);
 		for (int st = 0; st < 2; st++) {
 			sbl_compact_marks(c, st);
@@ -313,7 +327,7 @@ extern "C" sbl_status sbl_enumerate(sbl_ctx *c, uint32_t k, uint32_t *bif_count,
 				a = b;
 			}
 		}
-		if (temp) sanitise_revert(c);
+		scope.done();
 		c->stats.instances = c->inst[0].size() + c->inst[1].size();
 		if (bif_count) *bif_count = c->bif_count;
 		if (pos) *pos = c->inst[0].data();
@@ -327,10 +341,10 @@ extern "C" sbl_status sbl_list_edges(sbl_ctx *c, uint32_t k, const sbl_edge **ed
 {
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-		bool temp = sanitise_apply(c);
+		SanitiseScope scope(c);
 		sbl_run_enumeration(c, k, c->nelem);
 		c->edges.clear();
-		DevBuf d_edges, d_valid;
+		DevBuf &d_edges = c->d_edges, &d_valid = c->d_valid;      // ctx-owned: nothing leaks when a later step throws
 		for (int st = 0; st < 2; st++) {
 			sbl_compact_marks(c, st);
 			unsigned m = c->nmarks[st];
@@ -357,8 +371,7 @@ extern "C" sbl_status sbl_list_edges(sbl_ctx *c, uint32_t k, const sbl_edge **ed
 				}
 			}
 		}
-		d_edges.release(); d_valid.release();
-		if (temp) sanitise_revert(c);
+		scope.done();
 		if (edges) *edges = c->edges.data();
 		if (n) *n = c->edges.size();
 	});

@@ -28,10 +28,17 @@ struct DevBuf {
 	void ensure(size_t bytes)
 	{
 		if (bytes <= cap) return;
-		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
 		size_t want = bytes + bytes / 16 + 256;
-		HIP_TRY(hipMalloc(&p, want));
-		cap = want;
+		void *q = nullptr;
+		// the new allocation first: a failure then leaves the old buffer (which views may still point into) intact ...
+		if (hipMalloc(&q, want) != hipSuccess) {
+			(void)hipGetLastError();
+			// ... unless only releasing the old one makes room (contents are not preserved by ensure() anyway)
+			if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+			HIP_TRY(hipMalloc(&q, want));
+		}
+		if (p) (void)hipFree(p);
+		p = q; cap = want;
 	}
 	// grow preserving the first `keep` bytes
 	void grow_keep(size_t bytes, size_t keep, hipStream_t s)

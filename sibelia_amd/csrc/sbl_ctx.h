@@ -48,6 +48,7 @@ struct sbl_ctx {
 	uint32_t bif_count = 0;
 	uint32_t cur_k = 0;
 	DevBuf d_inst;                       // marshalling buffer
+	DevBuf d_edges, d_valid;             // sbl_list_edges staging
 
 	// results handed out through the ABI
 	std::vector<sbl_inst> inst[2];

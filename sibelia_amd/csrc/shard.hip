@@ -23,6 +23,7 @@
 #include <chrono>
 #include <dlfcn.h>
 #include <pthread.h>
+#include <time.h>
 #include <rocprim/rocprim.hpp>
 #include <rccl/rccl.h>
 
@@ -49,6 +50,8 @@ struct RcclApi {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
 	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -67,6 +70,7 @@ static RcclApi load_rccl()
 			SBL_SYM(GetUniqueId, "ncclGetUniqueId"); SBL_SYM(CommInitRank, "ncclCommInitRank"); SBL_SYM(CommDestroy, "ncclCommDestroy");
 			SBL_SYM(AllGather, "ncclAllGather"); SBL_SYM(Send, "ncclSend"); SBL_SYM(Recv, "ncclRecv");
 			SBL_SYM(GroupStart, "ncclGroupStart"); SBL_SYM(GroupEnd, "ncclGroupEnd"); SBL_SYM(GetErrorString, "ncclGetErrorString");
+			SBL_SYM(CommAbort, "ncclCommAbort"); SBL_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
 #undef SBL_SYM
 			if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.Send || !a.Recv || !a.GroupStart || !a.GroupEnd) a.h = nullptr;
 		}
@@ -85,17 +89,47 @@ static RcclApi &rccl()
 struct RcclComm : SblComm {
 	ncclComm_t comm = nullptr;
 	~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
+	// A peer that fails inside a collective call (out of memory, a HIP error, ...) never posts its sends: a plain
+	// hipStreamSynchronize would then block for ever.  The wait polls the stream, watches the communicator's asynchronous
+	// error state and gives up after SBL_COMM_TIMEOUT_S seconds (default 600): the communicator is aborted and the call
+	// fails with an error on THIS rank too, instead of hanging the job.
+	void wait(sbl_ctx *c)
+	{
+		static const double limit = [] { const char *e = getenv("SBL_COMM_TIMEOUT_S"); double v = e ? atof(e) : 0; return v > 0 ? v : 600.0; }();
+		const auto t0 = std::chrono::steady_clock::now();
+		for (unsigned spin = 0;; spin++) {
+			hipError_t e = hipStreamQuery(c->stream);
+			if (e == hipSuccess) return;
+			if (e != hipErrorNotReady) { abort_peers(); HIP_TRY(e); }
+			if (spin > 2000) {
+				if (rccl().CommGetAsyncError && comm) {
+					ncclResult_t ar = ncclSuccess;
+					if (rccl().CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+						abort_peers();
+						throw SblError{SBL_ERR_HIP, std::string("RCCL asynchronous error: ") + (rccl().GetErrorString ? rccl().GetErrorString(ar) : "?")};
+					}
+				}
+				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+					abort_peers();
+					throw SblError{SBL_ERR_HIP, "a collective did not complete within SBL_COMM_TIMEOUT_S: a peer rank failed or left the call"};
+				}
+				struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr);
+			}
+		}
+	}
 	void allgather_host(sbl_ctx *c, const void *in, size_t bytes, void *out) override
 	{
+		SBL_CHECK(comm, SBL_ERR_HIP, "the RCCL communicator was aborted by an earlier failure");
 		c->d_stage.ensure(bytes * (n + 1));
 		char *d = c->d_stage.as<char>();
 		HIP_TRY(hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, c->stream));
 		RCCL_TRY(rccl().AllGather(d, d + bytes, bytes, ncclChar, comm, c->stream));
 		HIP_TRY(hipMemcpyAsync(out, d + bytes, bytes * n, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
+		wait(c);
 	}
 	void alltoallv(sbl_ctx *c, const char *send, const size_t *sbytes, const size_t *soff, char *recv, const size_t *rbytes, const size_t *roff) override
 	{
+		SBL_CHECK(comm, SBL_ERR_HIP, "the RCCL communicator was aborted by an earlier failure");
 		// one message per peer, all in flight together: xGMI is point to point, every link carries its own pair
 		RCCL_TRY(rccl().GroupStart());
 		for (uint32_t i = 0; i < n; i++) {
@@ -105,7 +139,15 @@ struct RcclComm : SblComm {
 			if (rbytes[q]) RCCL_TRY(rccl().Recv(recv + roff[q], rbytes[q], ncclChar, (int)q, comm, c->stream));
 		}
 		RCCL_TRY(rccl().GroupEnd());
-		HIP_TRY(hipStreamSynchronize(c->stream));
+		wait(c);
+	}
+	// this rank leaves a collective call with an error: tear the communicator down so that nothing of it stays queued here;
+	// the peers notice through their own wait() (asynchronous error or timeout)
+	void abort_peers() override
+	{
+		if (!comm) return;
+		if (rccl().CommAbort) (void)rccl().CommAbort(comm); else (void)rccl().CommDestroy(comm);
+		comm = nullptr;
 	}
 };
 
@@ -189,7 +231,12 @@ extern "C" sbl_status sbl_comm_attach_rccl(sbl_ctx *c, uint32_t rank, uint32_t n
 		c->comm = rc;
 		ncclUniqueId u;
 		memcpy(&u, id, sizeof u);
-		RCCL_TRY(rccl().CommInitRank(&rc->comm, (int)nranks, u, (int)rank));
+		ncclResult_t r = rccl().CommInitRank(&rc->comm, (int)nranks, u, (int)rank);
+		if (r != ncclSuccess) {                                   // no half-attached context: later stages run single-GPU
+			rc->comm = nullptr;
+			sbl_comm_release(c);
+			RCCL_TRY(r);
+		}
 	});
 }
 extern "C" sbl_group *sbl_group_create_local(uint32_t nranks)

@@ -1383,6 +1383,9 @@ struct DeviceBackend {
 	int prof = 0;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
+	DeviceBackend() = default;
+	DeviceBackend(const DeviceBackend &) = delete;
+	~DeviceBackend() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }      // also on the error paths out of sbl_simplify_run
 	uint32_t nid() { return nid_; }
 	void bind()
 	{
@@ -1753,7 +1756,6 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
-	for (auto &e : be.ev) (void)hipEventDestroy(e);
 	if (be.prof) {
 		unsigned long long z[16];
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));

@@ -24,13 +24,15 @@ def _bulges(v):
 # Low-complexity small cases with thousands of collapses on a few hundred bases are the dense-conflict regime: the ordered
 # rounds commit one or two transactions each there, and the driver hands the pending ids to the serial chain (k_chain).
 SUPPORTED = VECS
-# Beyond 8000 collapses (k = 3 .. 6 on a few hundred bases: a handful of ids with ~2000 instances each, i.e. a few enormous
-# single-wave transactions) a case takes 13 - 100 s on a GPU: those 7 are left to the hostsim CPU tests (six of them have
-# been replayed on the GPU once with tools/dense_vectors.py, bit-exact; small/078 -- k = 3, D = 144 on 576 bases -- takes
-# more than six minutes and was not waited for).
+# Beyond 8000 collapses (k = 3 .. 10 on a few hundred bases: ids with thousands of instances, every transaction in conflict
+# with every other) a case takes 13 - 100 s on the GPU (serial chain, one wave): six of the seven run below (HUGE_RUN).
+# small/078 -- k = 3, D = 144 on 1.4 kbp, ids grow to ~4500 instances -- takes > 10 min and is left out of the GPU suite;
+# its first stage and the other six vectors also run through the product's transaction code on the host
+# (tests/test_hostsim.py::test_transactions_match_reference_on_the_densest_vectors).
 DENSE = [v for v in VECS if v["name"].startswith("small/") and 400 <= _bulges(v) < 8000]
 HUGE = [v for v in VECS if v["name"].startswith("small/") and _bulges(v) >= 8000]
 FAST = [v for v in SUPPORTED if not v["name"].startswith(("real/", "synth/strains2", "synth/strains8")) and v not in DENSE and v not in HUGE]
+HUGE_RUN = [v for v in HUGE if v["name"] != "small/078"]
 BIG = [v for v in SUPPORTED if v["name"].startswith(("real/", "synth/strains2"))]
 
 
@@ -51,6 +53,11 @@ def test_hip_matches_reference_genomes(v):
 
 @pytest.mark.parametrize("v", DENSE, ids=[v["name"] for v in DENSE])
 def test_hip_matches_reference_dense_conflicts(v):
+    V.replay(v, _bf)
+
+
+@pytest.mark.parametrize("v", HUGE_RUN, ids=[v["name"] for v in HUGE_RUN])
+def test_hip_matches_reference_densest(v):
     V.replay(v, _bf)
 
 
@@ -160,3 +167,35 @@ def test_many_strains_small_genomes_match_oracle():
     assert bf.simplify_stage(25, 150, 4) == orc.simplify_stage(25, 150, 4)
     (sa, pa), (sb, pb) = bf.state(), orc.state()
     assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+
+
+def test_cpp_class_surface_runs_on_the_gpu(tmp_path):
+    # include/sibelia_amd/blockfinder.hpp (the reference's BlockFinder surface over the C ABI) from a plain g++ program:
+    # hand/snp_k5 -- DOT text before and after the stage must be the reference's, byte for byte
+    import os, subprocess
+    from sibelia_amd.build import LIBDIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    v = [x for x in VECS if x["name"] == "hand/snp_k5"][0]
+    seqs = V.vector_input(v)
+    src = tmp_path / "main.cpp"
+    src.write_text('#include <fstream>\n#include "sibelia_amd/blockfinder.hpp"\n'
+                   'struct Rec { std::string s; const std::string &GetSequence() const { return s; } };\n'
+                   'int main(int, char **argv) { std::vector<Rec> v(%d);\n%s'
+                   '  SyntenyFinderAMD::BlockFinder bf(v);\n'
+                   '  { std::ofstream o(std::string(argv[1]) + ".0"); bf.SerializeCondensedGraph(5, o); }\n'
+                   '  size_t calls = 0; size_t b = bf.PerformGraphSimplifications(5, 12, 4, [&](size_t, SyntenyFinderAMD::BlockFinder::State) { calls++; });\n'
+                   '  { std::ofstream o(std::string(argv[1]) + ".1"); bf.SerializeCondensedGraph(5, o); }\n'
+                   '  bool threw = false; try { bf.PerformGraphSimplifications(5, 12, 1, [](size_t, SyntenyFinderAMD::BlockFinder::State) { throw 7; }); } catch (int) { threw = true; }\n'
+                   '  std::printf("bulges %%zu calls %%zu threw %%d\\n", b, calls, (int)threw); return 0; }\n'
+                   % (len(seqs), "".join('  v[%d].s = "%s";\n' % (i, s.decode()) for i, s in enumerate(seqs))))
+    exe = tmp_path / "main"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-L", LIBDIR, "-lsibelia_amd",
+                    "-Wl,-rpath," + LIBDIR, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(tmp_path / "dot")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    stage = [o for o in v["outputs"] if o["cmd"].startswith("stage")][0]
+    assert r.stdout.startswith("bulges %d calls " % stage["bulges"]) and r.stdout.strip().endswith("threw 1")
+    dots = [o for o in v["outputs"] if o["cmd"] == "dot:5"]
+    for i, o in enumerate(dots):
+        got = open(str(tmp_path / ("dot.%d" % i)), "rb").read()
+        assert F_sha(got) == o["sha256"], "DOT text %d differs from the reference" % i

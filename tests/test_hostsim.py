@@ -63,3 +63,50 @@ def test_small_arena_goes_through_the_big_path():
     seqs, k, D = W.small_case(2)            # k=4: ids with many instances overflow a tiny arena
     st = _check(seqs, k, D, window=16, order=0, arena=1 << 12)
     assert st["solo"] > 0
+
+
+# ---- the densest golden vectors (>= 8000 collapses at k = 3 .. 10 on a few hundred bases: ids with thousands of instances,
+# every transaction in conflict with every other): the regime where the ordering logic is most fragile.  All their stage
+# commands run through the product's transaction code here, against the reference's fixtures AND the oracle.
+def _huge():
+    import json, os
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))["vectors"]
+    return [v for v in vec if v["name"].startswith("small/") and sum(o.get("bulges", 0) for o in v["outputs"]) >= 8000]
+
+
+HUGE = _huge()
+# small/078's second stage (k = 3, D = 144 on 1.4 kbp: ids grow to ~4500 instances, nearly every cached window sees every
+# collapse) takes ~9 min through the one-thread driver: its first stage runs here, the second one only on the GPU tools run
+SLOW_STAGES = {("small/078", "stage:3:144:3")}
+
+
+@pytest.mark.parametrize("v", HUGE, ids=[v["name"] for v in HUGE])
+def test_transactions_match_reference_on_the_densest_vectors(v):
+    from tests import vectors as V
+    from sibelia_amd import formats as F
+    ACGT = set(b"ACGT")
+    seqs = V.vector_input(v)
+    o, rng = Oracle(seqs), Oracle([])                      # rng: a second glibc rand() stream kept in step with the oracle's
+    cur = [bytes(s) for s in seqs]
+    op = [np.arange(len(s), dtype=np.uint32) for s in seqs]
+    for out in v["outputs"]:
+        p = out["cmd"].split(":")
+        namb = sum(1 for s in cur for c in s if c not in ACGT)
+        if p[0] != "stage":                                 # a fresh IndexedSequence sanitises a COPY: rand() advances, the state does not
+            for _ in range(namb):
+                rng.rand()
+            (o.enumerate if p[0] == "enum" else o.list_edges)(int(p[1]))
+            continue
+        if (v["name"], out["cmd"]) in SLOW_STAGES:
+            break
+        k, D, it = int(p[1]), int(p[2]), int(p[3])
+        if namb:                                            # reference src/indexedsequence.cpp:31-37
+            cur = [bytes((c if c in ACGT else b"ACGT"[rng.rand() % 4]) for c in s) for s in cur]
+        bc, pp, nn = Oracle(cur).enumerate(k)
+        hb, hs, hp, st = H.stage(cur, op, k, D, it, bc, pp, nn, window=64, order_mode=2, arena_bytes=1 << 16, slack=1 << 21)
+        ob = o.simplify_stage(k, D, it)
+        es, ep = o.state()
+        assert hb == ob == out["bulges"] and hs == es and all(np.array_equal(a, c) for a, c in zip(hp, ep)), (out["cmd"], st)
+        got = F.state_bytes(hb, hs, hp)
+        assert len(got) == out["size"] and F.sha256(got) == out["sha256"], "differs from the reference fixture"
+        cur, op = hs, hp
