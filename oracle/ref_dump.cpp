@@ -17,6 +17,7 @@
 #include "blockfinder.h"
 #undef private
 #include <stdint.h>
+#include <time.h>
 
 const std::string VERSION("golden-dump");
 using namespace SyntenyFinder;
@@ -86,9 +87,14 @@ int main(int argc, char **argv)
 		}
 		else if(sscanf(argv[a], "stage:%u:%u:%u", &k, &d, &it) == 3)
 		{
+			struct timespec t0, t1;
+			clock_gettime(CLOCK_MONOTONIC, &t0);
 			size_t bulges = finder.PerformGraphSimplifications(k, d, it);
+			clock_gettime(CLOCK_MONOTONIC, &t1);
 			dump_state(finder, bulges, prefix + buf);
-			fprintf(stderr, "stage k=%u D=%u iter=%u -> bulges=%zu\n", k, d, it, bulges);
+			// seconds = wall time of the reference's own BlockFinder::PerformGraphSimplifications (bench.py: cpu_baseline kind "reference")
+			fprintf(stderr, "stage k=%u D=%u iter=%u -> bulges=%zu seconds=%.6f\n", k, d, it, bulges,
+			        (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
 		}
 		else if(sscanf(argv[a], "dot:%u", &k) == 1)
 		{
