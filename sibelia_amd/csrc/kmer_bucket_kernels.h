@@ -1,0 +1,196 @@
+// kmer_bucket_kernels.h -- radix-bucketed k-mer table for bifurcation enumeration at k <= 32 (single-GPU path).
+//
+// Replaces the suffix-array + LCP group scan of IndexedSequence::EnumerateBifurcationsSArrayInRAM
+// (reference src/vertexenumeration.cpp:288-362) -- same order-free formulation as kmer_kernels.h -- with a table that never
+// makes a random access to HBM:
+//   B1 k_kmer_records   every base position -> one 16-B record {key = mix64(canonical code), value = element | masks | orientation},
+//                       written in position order (coalesced); mix64 is a bijection, so equal keys <=> equal k-mers
+//   B2 radix partition  by `bits` bits of the key = hash PREFIX (rocPRIM onesweep, 8 bits per pass): buckets of ~512 records,
+//                       contiguous in HBM, each the size of an LDS table  (north_star: "radix-bucketed open-address hash")
+//   B3 k_bucket_classify one workgroup per bucket: open-addressing table in LDS (ds atomics), masks OR-ed per distinct k-mer,
+//                       Bifurcation() test (vertexenumeration.cpp:67-70,:330), sort keys of the bifurcation k-mers for the
+//                       global ranking (id = lexicographic rank, :348-355) and the list of member positions (element, pair)
+//   B4 rocPRIM sort of the bifurcation codes + k_scatter_ids (kmer_kernels.h)
+//   B5 k_scatter_members bif[0][g] / bif[1][g+k-1] for the member positions only (marking, indexedsequence.cpp:49-67)
+// HBM traffic: 16 B written + ~(8 + 2 x 32) B sort + 16 B read per position, all streaming; nothing else scales with N.
+// The same hash prefix is the shard key of the multi-GPU path (shard.hip: owner = prefix x ranks >> 32).
+#pragma once
+#include "kmer_kernels.h"
+
+// inverse of kmer_hash (murmur3 fmix64 is a bijection on 64-bit words)
+__device__ __host__ __forceinline__ unsigned long long kmer_unhash(unsigned long long x)
+{
+	x ^= x >> 33; x *= 0x9cb4b2f8129337dbull;
+	x ^= x >> 33; x *= 0x4f74430c22a54005ull;
+	x ^= x >> 33;
+	return x;
+}
+
+// Empty-slot marker of the LDS tables: mix64(~0).  ~0 is never a CANONICAL code (for k = 32 it is TT..T, whose reverse complement
+// AA..A = 0 is smaller; for k < 32 it is not a code at all) and mix64 is a bijection, so no valid record carries this key.
+#define KB_EMPTY_KEY 0x64b5720b4b825f21ull
+#define KB_INVALID 0xFFFFFFFFFFFFFFFFull       // value of a position whose k-window holds a separator (or lies beyond the input)
+// value layout: bits 0-31 element index g | bits 32-44 mask (canonical orientation, as KmerSlot::mask) | bit 48 fwd <= rev | bit 49 rev <= fwd
+
+// B1: one record per element index of the tile (invalid positions get KB_INVALID), coalesced 8-B stores.
+static __global__ void __launch_bounds__(KM_THREADS) k_kmer_records(const unsigned long long *__restrict__ pk, const unsigned *__restrict__ sp,
+                                                             size_t nwords, size_t nelem, unsigned k, size_t ntiles,
+                                                             unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals)
+{
+	__shared__ KmerTile t;
+	const unsigned long long kshift = 64 - 2 * k;
+	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		__syncthreads();
+		tile_load(t, pk, sp, tile, nwords);
+		__syncthreads();
+		const size_t base = tile * (size_t)(KM_TILE_WORDS * 32);
+#pragma unroll 4
+		for (int i = 0; i < KM_PER_THREAD; i++) {
+			const int e = i * KM_THREADS + (int)threadIdx.x;          // element relative to the tile start
+			const size_t g = base + (size_t)e;
+			const int j = (e + 32) >> 5, o = (e + 32) & 31;
+			// k consecutive elements starting at e: at most two packed words
+			const unsigned long long w0 = t.w[j], w1 = t.w[j + 1];
+			const unsigned long long x = o ? (w0 << (2 * o)) | (w1 >> (64 - 2 * o)) : w0;
+			const unsigned long long sx = (((unsigned long long)t.s[j] << 32) | t.s[j + 1]) << o;
+			const bool valid = g < nelem && (sx >> (64 - k)) == 0;
+			unsigned long long key = kmer_hash((unsigned long long)g), val = KB_INVALID;      // invalid records: spread over the buckets, skipped by value
+			if (valid) {
+				const unsigned long long fwd = x >> kshift, rev = rc_code(fwd, k);
+				const unsigned ps = tile_sep(t, e - 1) ? 4u : tile_base(t, e - 1);
+				const unsigned ns = tile_sep(t, e + (int)k) ? 4u : tile_base(t, e + (int)k);
+				unsigned m = 0, fl = 0;
+				// syms: complement of base b is 3-b; '#' (4) stays '#'
+				if (fwd <= rev) { m |= (1u << ps) | (1u << (8 + ns)); fl |= 1u; }
+				if (rev <= fwd) { m |= (1u << (ns == 4 ? 4 : 3 - ns)) | (1u << (8 + (ps == 4 ? 4 : 3 - ps))); fl |= 2u; }
+				key = kmer_hash(fwd < rev ? fwd : rev);
+				val = (unsigned long long)(unsigned)g | ((unsigned long long)m << 32) | ((unsigned long long)fl << 48);
+			}
+			keys[g] = key;
+			vals[g] = val;
+		}
+	}
+}
+
+// bucket b = records whose key's LOW `bits` bits equal b: boff[b] = first record (lower bound in the partitioned array).
+// (The low end of the mixed key is as good a hash prefix as the high end; rocPRIM 4.2's radix_sort_pairs returns unsorted,
+// mismatched pairs for begin_bit > 0 below ~1 M items -- tools/dbg/sort_dbg.hip -- so the partition sorts bits [0, bits).)
+static __global__ void __launch_bounds__(256) k_bucket_bounds(const unsigned long long *__restrict__ skeys, size_t n, unsigned bits, unsigned *__restrict__ boff)
+{
+	const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nb = (size_t)1 << bits;
+	if (b > nb) return;
+	if (b == nb) { boff[b] = (unsigned)n; return; }
+	size_t lo = 0, hi = n;
+	while (lo < hi) { size_t mid = (lo + hi) >> 1; if ((skeys[mid] & (nb - 1)) < b) lo = mid + 1; else hi = mid; }
+	boff[b] = (unsigned)lo;
+}
+
+#define KB_SLOTS 2048u                          // LDS table of a bucket: 2048 x (8 + 4 + 4) B = 32 KB
+#define KB_MAX_DISTINCT 1536u
+#define KB_THREADS 256
+// counters: [0] pairs [1] keys [2] members [3] overflow flag
+// B3: see the header comment.  Capacities (maxpairs, maxmembers) guard the writes; the host re-runs with larger buffers / more
+// bucket bits when a counter exceeds them or the overflow flag is set.
+static __global__ void __launch_bounds__(KB_THREADS) k_bucket_classify(const unsigned long long *__restrict__ skeys, const unsigned long long *__restrict__ svals,
+                                                                const unsigned *__restrict__ boff, unsigned k,
+                                                                unsigned *__restrict__ counters,
+                                                                unsigned long long *__restrict__ rank_keys, unsigned *__restrict__ rank_payload, unsigned maxpairs,
+                                                                unsigned long long *__restrict__ members, unsigned maxmembers)
+{
+	__shared__ unsigned long long tkey[KB_SLOTS];
+	__shared__ unsigned tmask[KB_SLOTS];
+	__shared__ unsigned taux[KB_SLOTS];
+	__shared__ unsigned s_used, s_pairs, s_keys, s_bpairs, s_bkeys, s_bmem, s_wsum[KB_THREADS / 64];
+	const unsigned lo = boff[blockIdx.x], hi = boff[blockIdx.x + 1];
+	if (lo >= hi) return;
+	for (unsigned i = threadIdx.x; i < KB_SLOTS; i += KB_THREADS) { tkey[i] = KB_EMPTY_KEY; tmask[i] = 0; taux[i] = SBL_NONE; }
+	if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; s_keys = 0; }
+	__syncthreads();
+	// ---- insert: one ds cmpswap (key claim) + one ds or (mask merge) per record.  At most KB_MAX_DISTINCT + KB_THREADS slots
+	// are ever claimed (every thread re-reads the count before each record), so a probe always finds a free slot or its key.
+	for (unsigned i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
+		if (*(volatile unsigned *)&s_used > KB_MAX_DISTINCT) break;        // too many distinct k-mers for this table: the host re-buckets
+		const unsigned long long v = svals[i];
+		if (v == KB_INVALID) continue;
+		const unsigned long long key = skeys[i];
+		unsigned h = (unsigned)(key >> 44) & (KB_SLOTS - 1);            // bits above the bucket prefix (<= 40 bits)
+		for (;;) {
+			unsigned long long old = atomicCAS(&tkey[h], KB_EMPTY_KEY, key);
+			if (old == KB_EMPTY_KEY) atomicAdd(&s_used, 1u);
+			if (old == KB_EMPTY_KEY || old == key) { atomicOr(&tmask[h], (unsigned)(v >> 32) & 0x1FFFu); break; }
+			h = (h + 1) & (KB_SLOTS - 1);
+		}
+	}
+	__syncthreads();
+	if (s_used > KB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[3], 1u); return; }
+	// ---- classify the distinct k-mers of the bucket
+	for (unsigned sidx = threadIdx.x; sidx < KB_SLOTS; sidx += KB_THREADS) {
+		if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx])) continue;
+		const unsigned long long canon = kmer_unhash(tkey[sidx]);
+		const unsigned nk = rc_code(canon, k) == canon ? 1u : 2u;
+		const unsigned lp = atomicAdd(&s_pairs, 1u), lk = atomicAdd(&s_keys, nk);
+		taux[sidx] = lp | (lk << 12);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		s_bpairs = s_pairs ? atomicAdd(&counters[0], s_pairs) : 0u;
+		s_bkeys = s_keys ? atomicAdd(&counters[1], s_keys) : 0u;
+	}
+	__syncthreads();
+	if (s_pairs == 0) return;
+	for (unsigned sidx = threadIdx.x; sidx < KB_SLOTS; sidx += KB_THREADS) {
+		const unsigned a = taux[sidx];
+		if (a == SBL_NONE) continue;
+		const unsigned pi = s_bpairs + (a & 0xFFFu), ki = s_bkeys + (a >> 12);
+		const unsigned long long canon = kmer_unhash(tkey[sidx]), r = rc_code(canon, k);
+		if (pi < maxpairs && ki + 2 <= 2 * maxpairs) {
+			rank_keys[ki] = canon; rank_payload[ki] = 2 * pi;
+			if (r != canon) { rank_keys[ki + 1] = r; rank_payload[ki + 1] = 2 * pi + 1; }
+		}
+		taux[sidx] = pi;
+	}
+	__syncthreads();
+	// ---- member positions of the bifurcation k-mers: count per thread, workgroup scan, one global reservation, write
+	auto probe = [&](unsigned long long key) -> unsigned {
+		unsigned h = (unsigned)(key >> 44) & (KB_SLOTS - 1);
+		while (tkey[h] != key) h = (h + 1) & (KB_SLOTS - 1);
+		return taux[h];
+	};
+	unsigned cnt = 0;
+	for (unsigned i = lo + threadIdx.x; i < hi; i += KB_THREADS)
+		if (svals[i] != KB_INVALID && probe(skeys[i]) != SBL_NONE) cnt++;
+	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned incl = cnt;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { unsigned x = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += x; }
+	if (lane == 63) s_wsum[wv] = incl;
+	__syncthreads();
+	unsigned woff = 0, total = 0;
+	for (unsigned w = 0; w < KB_THREADS / 64; w++) { if (w < wv) woff += s_wsum[w]; total += s_wsum[w]; }
+	if (threadIdx.x == 0) s_bmem = total ? atomicAdd(&counters[2], total) : 0u;
+	__syncthreads();
+	unsigned at = s_bmem + woff + incl - cnt;
+	for (unsigned i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
+		const unsigned long long v = svals[i];
+		if (v == KB_INVALID) continue;
+		const unsigned pi = probe(skeys[i]);
+		if (pi == SBL_NONE) continue;
+		// payload of the code this position spells on the + strand: 2 * pair + (0: canonical, 1: reverse complement)
+		const unsigned o = ((v >> 48) & 1ull) ? 0u : 1u;
+		if (at < maxmembers) members[at] = (v & 0xFFFFFFFFull) | ((unsigned long long)(2 * pi + o) << 32);
+		at++;
+	}
+}
+
+// B5: marks of the member positions.  bif[0][g] = id of the + strand k-mer starting at g, bif[1][g+k-1] = id of its reverse
+// complement (the - strand k-mer starting at g+k-1); arrays pre-filled with SBL_NONE.
+static __global__ void __launch_bounds__(256) k_scatter_members(const unsigned long long *__restrict__ members, unsigned n, unsigned k,
+                                                         const unsigned *__restrict__ pairids, unsigned *__restrict__ bif0, unsigned *__restrict__ bif1)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long m = members[i];
+	const unsigned g = (unsigned)m, p = (unsigned)(m >> 32);
+	bif0[g] = pairids[p];
+	bif1[g + k - 1] = pairids[p ^ 1u];
+}

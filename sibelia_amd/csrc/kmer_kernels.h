@@ -30,7 +30,7 @@ struct alignas(16) KmerSlot {
 	unsigned int aux;         // after classification: index of the bifurcation pair, or SBL_NONE
 };
 
-__device__ __forceinline__ unsigned long long kmer_hash(unsigned long long x)
+__device__ __host__ __forceinline__ unsigned long long kmer_hash(unsigned long long x)
 {
 	x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
 	x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;

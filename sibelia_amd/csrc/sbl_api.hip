@@ -8,6 +8,7 @@
 
 #include "sbl_ctx.h"
 #include "kmer_kernels.h"
+#include "kmer_bucket_kernels.h"
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
@@ -122,51 +123,72 @@ static void device_exclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_
 	HIP_TRY(rocprim::exclusive_scan(c->d_scantmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
 }
 
-// E1 (+ the dense form of E2): pack -> table build -> classify -> rank -> resolve.
+static void device_sort_records(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned long long *vin, unsigned long long *vout,
+                                size_t n, unsigned begin_bit, unsigned end_bit)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+	c->d_sorttmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+}
+
+// E1 (+ the dense form of E2): pack -> k-mer records -> radix partition by hash prefix -> per-bucket LDS tables (classify)
+// -> rank of the bifurcation codes -> marks of the member positions (kmer_bucket_kernels.h).
 // elem_capacity >= nelem is the allocated length of the mark arrays (simplification appends elements).
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }      // long k: every GPU enumerates the whole input
+	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }      // long k: rank doubling (longk.hip)
 	if (c->comm) { sbl_run_enumeration_sharded(c, k, elem_capacity); return; }    // k-mer table sharded by hash prefix over the attached GPUs
+	SBL_CHECK(kmer_hash(~0ull) == KB_EMPTY_KEY && kmer_unhash(kmer_hash(0x123456789ABCDEFull)) == 0x123456789ABCDEFull, SBL_ERR_INTERNAL, "k-mer hash constants");
 	hipStream_t s = c->stream;
-	size_t E = c->nelem, nwords = (E + 31) / 32;
-	size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
+	const size_t E = c->nelem, nwords = (E + 31) / 32;
+	const size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
+	const size_t n = ntiles * (size_t)(KM_TILE_WORDS * 32);                          // records (one per element slot of the tiles)
+	SBL_CHECK(n < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many positions for 32-bit record indices");
 	c->cur_k = k;
 	sbl_pack(c);
-
-	// table capacity: power of two >= 1.5 x number of base positions (an upper bound of the distinct canonical k-mers)
-	size_t cap = 1024;
-	while (cap < E + E / 2) cap <<= 1;
-	SBL_CHECK(cap <= 0xFFFFFFFFull, SBL_ERR_TOO_LARGE, "k-mer table too large for 32-bit slot indices");
-	c->d_usedslots.ensure(E * 4 + 64);
-	c->d_table.ensure(cap * sizeof(KmerSlot));
-	c->table_cap = cap;
+	for (int i = 0; i < 2; i++) { c->d_rec_keys[i].ensure(n * 8); c->d_rec_vals[i].ensure(n * 8); }
 	c->d_counters.ensure(64 * 4);
-	k_table_init<<<(unsigned)std::min<size_t>((cap + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap);
-	HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+	unsigned long long *k0 = c->d_rec_keys[0].as<unsigned long long>(), *k1 = c->d_rec_keys[1].as<unsigned long long>();
+	unsigned long long *v0 = c->d_rec_vals[0].as<unsigned long long>(), *v1 = c->d_rec_vals[1].as<unsigned long long>();
 
-	unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 8);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
-	k_kmer_table_build<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-	                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, (size_t)0, ntiles,
-	                                               c->d_counters.as<unsigned>() + 8, c->d_usedslots.as<unsigned>());
-	HIP_TRY(hipEventRecord(c->ev[1], s));
+	const unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 16);
+	k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, ntiles, k0, v0);
 	HIP_TRY(hipGetLastError());
 
-	// classify the claimed slots in ONE pass: every claimed slot yields at most one pair / two keys, so the key buffers are
-	// sized by that bound (16 + 8 B per distinct k-mer, transient) instead of by a counting pre-pass over the random slots
-	unsigned nused = 0;
-	HIP_TRY(hipMemcpyAsync(&nused, c->d_counters.as<unsigned>() + 8, 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	unsigned cgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)nused + 255) / 256, 256 * 16));
-	c->d_keys.ensure((size_t)nused * 16 + 16); c->d_payload.ensure((size_t)nused * 8 + 16);
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, k, c->d_counters.as<unsigned>(),
-	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), nused);
-	unsigned cnt[4];
-	HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	unsigned npairs = cnt[0], nkeys = cnt[1];
+	// buckets of ~350-700 records (an LDS table holds KB_MAX_DISTINCT distinct k-mers); more bits if a bucket overflows
+	unsigned bits = 4;
+	while (bits < 30 && (n >> bits) > 700) bits++;
+	size_t maxpairs = n / 8 + 4096, maxmembers = n;              // capacities of the classification outputs; grown on demand
+	unsigned cnt[4] = {0, 0, 0, 0};
+	unsigned long long *members = k0;                            // the unsorted records are dead after the partition: their space holds the member list
+	for (int attempt = 0;; attempt++) {
+		SBL_CHECK(attempt < 8, SBL_ERR_INTERNAL, "k-mer bucket classification did not converge");
+		if (attempt == 0 || (cnt[3] & 1u)) {
+			if (attempt) {                                       // re-bucket with a longer prefix: the records have to be generated again (k0 was reused)
+				bits = std::min(bits + 2, 40u);
+				k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, ntiles, k0, v0);
+			}
+			device_sort_records(c, k0, k1, v0, v1, n, 0, bits);
+			c->d_boff.ensure((((size_t)1 << bits) + 1) * 4 + 64);
+			k_bucket_bounds<<<nblocks(((size_t)1 << bits) + 1, 256), 256, 0, s>>>(k1, n, bits, c->d_boff.as<unsigned>());
+		}
+		c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
+		HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+		k_bucket_classify<<<(unsigned)((size_t)1 << bits), KB_THREADS, 0, s>>>(k1, v1, c->d_boff.as<unsigned>(), k, c->d_counters.as<unsigned>(),
+		                                                                      c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), (unsigned)maxpairs,
+		                                                                      members, (unsigned)maxmembers);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (cnt[3] & 1u) continue;
+		if (cnt[0] > maxpairs || (size_t)cnt[1] > 2 * maxpairs) { maxpairs = std::max<size_t>(cnt[0], ((size_t)cnt[1] + 1) / 2) + 1024; continue; }
+		break;
+	}
+	HIP_TRY(hipEventRecord(c->ev[1], s));
+	const unsigned npairs = cnt[0], nkeys = cnt[1], nmem = cnt[2];
 	c->d_skeys.ensure((size_t)nkeys * 8 + 16); c->d_spayload.ensure((size_t)nkeys * 4 + 16);
 	c->d_pairids.ensure((size_t)npairs * 8 + 16);
 	if (nkeys) {
@@ -181,15 +203,14 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		c->d_bif[st].ensure(elem_capacity * 4);
 		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
 	}
-	k_resolve_marks<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-	                                            c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, c->d_pairids.as<unsigned>(),
-	                                            c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(), ntiles);
+	if (nmem)
+		k_scatter_members<<<nblocks(nmem, 256), 256, 0, s>>>(members, nmem, k, c->d_pairids.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
 	c->stats.kmer_table_ms = ms;
-	// algorithmic bytes of the table build: 2-bit sequence read once + one 16-B slot read and written per base position
+	// algorithmic bytes of the table build (SURVEY.md 8d): 2-bit sequence read once + one 16-B slot read and written per base position
 	size_t positions = 0;
 	for (uint32_t ch = 0; ch < c->nchr; ch++) {
 		size_t len = c->sepidx[ch + 1] - c->sepidx[ch] - 1;
@@ -249,7 +270,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_longk_free(c);
 	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
