@@ -28,24 +28,27 @@ __global__ void __launch_bounds__(256) k_init_links(unsigned *__restrict__ nx, u
 // + src/bifurcationstorage.cpp:122): + list = elements descending; - list = chromosomes descending, elements ascending.
 __global__ void __launch_bounds__(256) k_instance_keys(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, unsigned n, unsigned strand,
                                                        const unsigned *__restrict__ sepidx, unsigned nchr, unsigned E,
-                                                       unsigned long long *__restrict__ keys)
+                                                       unsigned long long *__restrict__ keys, unsigned *__restrict__ midx)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
+	midx[i] = i;                                    // payload of the sort: index into the positional (compact) mark arrays
 	unsigned e = elem[i], ord;
 	if (strand == 0) ord = 0xFFFFFFFFu - e;
 	else { unsigned c = chr_of(sepidx, nchr, e); ord = (E - sepidx[c + 1]) + (e - sepidx[c]); }
 	keys[i] = ((unsigned long long)id[i] << 32) | ord;
 }
 
-__global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ selem, unsigned n,
+__global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ smidx, const unsigned *__restrict__ melem, unsigned n,
                                                      unsigned node_base, unsigned strand, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext, unsigned *__restrict__ nidst,
                                                      uint8_t *__restrict__ ndead, unsigned *__restrict__ head, unsigned *__restrict__ lsize,
-                                                     unsigned *__restrict__ nodeof)
+                                                     unsigned *__restrict__ nodeof, unsigned *__restrict__ nmark)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	unsigned id = (unsigned)(skeys[i] >> 32), nd = node_base + i, e = selem[i];
+	const unsigned j = smidx[i];
+	unsigned id = (unsigned)(skeys[i] >> 32), nd = node_base + i, e = melem[j];
+	nmark[nd] = j;                                  // where the instance sits in the positional mark arrays (k_snapshot_first)
 	bool last = i + 1 >= n || (unsigned)(skeys[i + 1] >> 32) != id;
 	bool first = i == 0 || (unsigned)(skeys[i - 1] >> 32) != id;
 	nslot[nd] = e; ndead[nd] = 0; nidst[nd] = (id << 1) | strand;
@@ -274,6 +277,92 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 		}
 	}
 	return __any(found) ? 1 : 0;
+}
+
+// ---- first snapshot of a stage: a stream over the position-ordered marks ------------------------------------------------
+// At the start of iteration 1 the list is still position-linear (element index = position) and the compacted marks of the
+// enumeration (melem / mid per strand, ascending element) ARE every window: instance j of strand 0 sees the marks j+1, j+2, ...
+// while melem - pos < min(D, distance to the chromosome end), strand 1 the marks j-1, j-2, ... -- a dozen consecutive 8-byte
+// records instead of 150 x (link + character + mark) per instance.  k_mark_aux adds, per mark, the endChar of the instance
+// (bulgeremoval.cpp:340-347) and its distance to the end of the chromosome in walk direction.
+__global__ void __launch_bounds__(256) k_mark_aux(const unsigned *__restrict__ melem, unsigned n, unsigned strand, const unsigned *__restrict__ sepidx, unsigned nchr,
+                                                  const uint8_t *__restrict__ ch, unsigned k, unsigned *__restrict__ aux)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned e = melem[i], c = chr_of(sepidx, nchr, e);
+	const unsigned dist = strand == 0 ? sepidx[c + 1] - e : e - sepidx[c];      // valid steps from the instance (inclusive) to the separator
+	unsigned bit = 0;
+	if (dist >= k + 1) {                                                         // ProperKMer(k + 1): endChar = character at step k, oriented
+		const uint8_t x = strand == 0 ? ch[e + k] : ch[e - k];
+		const unsigned code = x == 'A' ? 0u : x == 'C' ? 1u : x == 'G' ? 2u : 3u;
+		bit = 1u << (strand == 0 ? code : 3u - code);
+	}
+	aux[i] = (bit << 24) | (dist < 0xFFFFFFu ? dist : 0xFFFFFFu);
+}
+
+struct MarkStream { const unsigned *elem[2], *id[2], *aux[2]; unsigned n[2]; };
+
+// AnyBulges verdict (see wave_verdict) of every id on the pristine graph; need[id] = 2 (known live) / 0 (clean) / 1 (the LDS
+// table could not decide: the probe of its round does).  Four instances per step, 16 lanes each.
+__global__ void __launch_bounds__(64) k_snapshot_first(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm)
+{
+	__shared__ VerdictTable vt;
+	const unsigned lane = threadIdx.x, sub = lane >> 4, sl = lane & 15u;
+	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);      // XCD-aware positional order, as k_snapshot
+	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
+		if (base + slot >= g.nid) continue;
+		const unsigned id = perm[base + slot];
+		const unsigned n0 = g.lsize[0][id], n1 = g.lsize[1][id], n = n0 + n1;
+		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
+		const unsigned h0 = g.head[0][id], h1 = g.head[1][id];                     // initial lists: runs of consecutive nodes (k_build_lists)
+		__syncthreads();
+		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+		__syncthreads();
+		bool found = false, undecided = false;
+		unsigned distinct = 0;
+		for (unsigned ib = 0; ib < n && !found && !undecided; ib += 4) {
+			const unsigned i = ib + sub;
+			const bool act = i < n;
+			const unsigned s = act && i >= n0 ? 1u : 0u;
+			const unsigned nd = s ? h1 + (i - n0) : h0 + i;
+			const unsigned j = act ? nmark[nd] : 0u;
+			const unsigned ax = act ? ms.aux[s][j] : 0u, pos = act ? ms.elem[s][j] : 0u;
+			const unsigned bit = ax >> 24, dist = ax & 0xFFFFFFu, lim = dist < g.D ? dist : g.D;
+			bool go = act && bit != 0;                                              // endChar == ' ': the instance takes no part
+			for (unsigned t = 0; __any(go); t += 16) {
+				const unsigned off = t + sl;
+				const bool inr = go && (s == 0 ? (unsigned long long)j + 1 + off < ms.n[0] : off < j);
+				const unsigned jj = s == 0 ? j + 1 + off : j - 1 - off;
+				const unsigned p = inr ? ms.elem[s][jj] : 0u, b = inr ? ms.id[s][jj] : BT_NONE;
+				const unsigned step = s == 0 ? p - pos : pos - p;
+				const bool stop = !inr || step >= lim || b == id;                   // window end, or the instance's own id recurs
+				const unsigned long long bal = __ballot(stop);
+				const unsigned grp = (unsigned)(bal >> (sub * 16)) & 0xFFFFu;
+				const unsigned upto = grp ? (unsigned)__builtin_ctz(grp) : 16u;      // marks of this instance before its first stop
+				const unsigned total = (unsigned)__popcll(__ballot(go && sl < upto));
+				if (distinct + total > (VT_SLOTS * 3) / 4) { undecided = true; break; }      // (uniform: the table could fill up)
+				bool fresh = false;
+				if (go && sl < upto) {
+					unsigned h = (b * 2654435761u) >> 23;
+					for (;;) {
+						unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
+						if (old == BT_NONE || old == b) {
+							fresh = old == BT_NONE;
+							unsigned m = atomicOr(&vt.mask[h], bit) | bit;
+							if (m & (m - 1)) found = true;
+							break;
+						}
+						h = (h + 1) & (VT_SLOTS - 1);
+					}
+				}
+				distinct += (unsigned)__popcll(__ballot(fresh));
+				if (__any(found)) { found = true; break; }
+				if (upto < 16) go = false;
+			}
+		}
+		if (lane == 0) g.need[id] = found ? 2 : undecided ? 1 : 0;
+	}
 }
 
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
@@ -1365,6 +1454,7 @@ struct SimplifyState {
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
+	DevBuf nmark, maux[2], iota;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
 	unsigned *h_ctr = nullptr;            // pinned
 };
@@ -1380,6 +1470,7 @@ struct DeviceBackend {
 	size_t nres = 0;
 	hipEvent_t ev[8] = {};
 	bool timed_reserve = false, timed_commit = false, timed_probe = false;
+	bool first_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr;      // measurement switch: the generic window-walking snapshot for iteration 1 too
 	int prof = 0;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
@@ -1444,6 +1535,13 @@ struct DeviceBackend {
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[6], c->stream));
+		if (!incremental && first_stream) {
+			// iteration 1 (also after a replay: the checkpoint restored is the pristine graph): stream over the position-ordered marks
+			MarkStream ms;
+			for (int t = 0; t < 2; t++) { ms.elem[t] = c->d_melem[t].as<unsigned>(); ms.id[t] = c->d_mid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = c->nmarks[t]; }
+			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
+			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>());
+		} else
 		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>());
 		HIP_TRY(hipEventRecord(ev[7], c->stream));
 		HIP_TRY(hipGetLastError());
@@ -1565,7 +1663,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
-	                   &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
@@ -1630,16 +1728,20 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		HIP_TRY(hipMemsetAsync(st->lsize[t].p, 0, nidp * 4, s));
 	}
 	size_t nmax = std::max(n0, n1);
-	st->keys.ensure(nmax * 8 + 16); st->skeys.ensure(nmax * 8 + 16); st->selem.ensure(nmax * 4 + 16);
+	st->keys.ensure(nmax * 8 + 16); st->skeys.ensure(nmax * 8 + 16); st->selem.ensure(nmax * 4 + 16); st->iota.ensure(nmax * 4 + 16);
+	st->nmark.ensure(cap_n * 4);
+	for (int t = 0; t < 2; t++) st->maux[t].ensure(16);
 	for (int t = 0; t < 2; t++) {
 		unsigned n = c->nmarks[t];
 		if (!n) continue;
 		k_instance_keys<<<nblocks(n, 256), 256, 0, s>>>(c->d_melem[t].as<unsigned>(), c->d_mid[t].as<unsigned>(), n, (unsigned)t,
-		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, st->keys.as<unsigned long long>());
-		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), c->d_melem[t].as<unsigned>(), st->selem.as<unsigned>(), n);
-		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), n, t ? (unsigned)n0 : 0u, (unsigned)t,
+		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, st->keys.as<unsigned long long>(), st->iota.as<unsigned>());
+		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->iota.as<unsigned>(), st->selem.as<unsigned>(), n);
+		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), c->d_melem[t].as<unsigned>(), n, t ? (unsigned)n0 : 0u, (unsigned)t,
 		                                             st->nslot.as<unsigned>(), st->nnext.as<unsigned>(), st->nidst.as<unsigned>(), st->ndead.as<uint8_t>(),
-		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>());
+		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>(), st->nmark.as<unsigned>());
+		st->maux[t].ensure((size_t)n * 4 + 16);
+		k_mark_aux<<<nblocks(n, 256), 256, 0, s>>>(c->d_melem[t].as<unsigned>(), n, (unsigned)t, c->d_sepidx.as<unsigned>(), c->nchr, c->d_ch.as<uint8_t>(), k, st->maux[t].as<unsigned>());
 	}
 	HIP_TRY(hipGetLastError());
 	// positional order of the ids for the snapshot kernel
