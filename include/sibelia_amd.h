@@ -84,6 +84,15 @@ void sbl_destroy(sbl_ctx *ctx);
  * Uploads the state to HBM; inputs are borrowed for the call only. */
 sbl_status sbl_load(sbl_ctx *ctx, uint32_t nchr, const uint8_t *const *seq, const uint64_t *len);
 
+/* Upstream of the hot path: replaces FASTAReader::GetSequences (src/fasta.cpp:23-104) + BlockFinder::Init.
+ * The file is mapped and copied to the device as text; line splitting, trimming, header / sequence classification,
+ * upper-casing, validation ("ACGTURYKMSWBDHWNX-"), concatenation, identity original positions and the scan for non-ACGT
+ * characters run in kernels.  Parse errors come back as SBL_ERR_BAD_ARG with the reference's message
+ * ("parse error in <file> on line <n>: empty sequence | empty header | illegal character: <c>") in sbl_last_error.
+ * sbl_record_name: FASTARecord::GetDescription (text between '>' and the first blank), valid until the next load. */
+sbl_status sbl_load_fasta(sbl_ctx *ctx, const char *path);
+const char *sbl_record_name(const sbl_ctx *ctx, uint32_t chr);
+
 /* Replaces IndexedSequence::Init's enumeration (src/indexedsequence.cpp:28-47 ->
  * src/vertexenumeration.cpp:263-364) on the current state at vertex size k.
  * Arrays are owned by the ctx, sorted by (chr,pos), valid until the next call on the ctx. */

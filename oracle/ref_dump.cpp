@@ -9,7 +9,7 @@
 // into flat binary files that make_golden.py turns into committed fixtures.
 //
 // usage: ref_dump <in.fasta> <out-prefix> <cmd>...
-//   cmd = enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+//   cmd = state | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
 #include "common.h"
 #include "fasta.h"
 #include "dnasequence.h"
@@ -17,6 +17,7 @@
 #include "blockfinder.h"
 #undef private
 #include <stdint.h>
+#include <string.h>
 #include <time.h>
 
 const std::string VERSION("golden-dump");
@@ -74,8 +75,15 @@ int main(int argc, char **argv)
 	std::vector<FASTARecord> chrList;
 	FASTAReader reader(argv[1]);
 	if(!reader.IsOk()) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
-	reader.GetSequences(chrList);
 	std::string prefix(argv[2]);
+	try { reader.GetSequences(chrList); }
+	catch(const std::exception & e)                    // parse errors of the reference's FASTA reader (src/fasta.cpp:66-71): <prefix>.err
+	{
+		FILE *f = fopen((prefix + ".err").c_str(), "wb");
+		fputs(e.what(), f);
+		fclose(f);
+		return 4;
+	}
 	BlockFinder finder(chrList);
 	for(int a = 3; a < argc; a++)
 	{
@@ -95,6 +103,13 @@ int main(int argc, char **argv)
 			// seconds = wall time of the reference's own BlockFinder::PerformGraphSimplifications (bench.py: cpu_baseline kind "reference")
 			fprintf(stderr, "stage k=%u D=%u iter=%u -> bulges=%zu seconds=%.6f\n", k, d, it, bulges,
 			        (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+		}
+		else if(strcmp(argv[a], "state") == 0)             // rawSeq_ / originalPos_ as BlockFinder::Init leaves them + the record descriptions
+		{
+			dump_state(finder, 0, prefix + buf);
+			FILE *f = fopen((prefix + buf + ".names").c_str(), "wb");
+			for(size_t i = 0; i < chrList.size(); i++) fprintf(f, "%s\n", chrList[i].GetDescription().c_str());
+			fclose(f);
 		}
 		else if(sscanf(argv[a], "dot:%u", &k) == 1)
 		{

@@ -23,7 +23,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
-           "sbl_save_state", "sbl_restore_state"]
+           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name"]
 
 
 class StageStats(C.Structure):
@@ -73,6 +73,9 @@ def load_library():
         L.sbl_set_window.argtypes = [C.c_void_p, C.c_uint32]
         L.sbl_save_state.argtypes = [C.c_void_p]
         L.sbl_restore_state.argtypes = [C.c_void_p]
+        L.sbl_load_fasta.argtypes = [C.c_void_p, C.c_char_p]
+        L.sbl_record_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.sbl_record_name.restype = C.c_char_p
         L.sbl_comm_unique_id.argtypes = [C.c_void_p]
         L.sbl_comm_attach_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.sbl_group_create_local.argtypes = [C.c_uint32]
@@ -97,16 +100,26 @@ class BlockFinder:
 
     seqs: upper-case sequences as delivered by the reference FASTA reader (one per FASTARecord)."""
 
-    def __init__(self, seqs: Sequence[bytes], device: int = -1):
+    def __init__(self, seqs: Sequence[bytes], device: int = -1, fasta: Optional[str] = None):
         self.L = load_library()
         self.h = C.c_void_p()
         rc = self.L.sbl_create(C.byref(self.h), device)
         if rc:
             raise SibeliaError("sbl_create: " + self.L.sbl_strerror(rc).decode())
+        if fasta is not None:          # FASTAReader + Init on the device (reference src/fasta.cpp:23-104, src/blockfinder.cpp:65-76)
+            self._check(self.L.sbl_load_fasta(self.h, os.fsencode(fasta)), "sbl_load_fasta")
+            return
         n = len(seqs)
         arr = (C.c_char_p * n)(*[bytes(s) for s in seqs])
         lens = (C.c_uint64 * n)(*[len(s) for s in seqs])
         self._check(self.L.sbl_load(self.h, n, arr, lens), "sbl_load")
+
+    @classmethod
+    def from_fasta(cls, path: str, device: int = -1) -> "BlockFinder":
+        return cls((), device=device, fasta=path)
+
+    def record_names(self) -> List[str]:
+        return [self.L.sbl_record_name(self.h, i).decode() for i in range(self.L.sbl_nchr(self.h))]
 
     def _check(self, rc, what):
         if rc:

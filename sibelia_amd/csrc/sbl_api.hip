@@ -270,7 +270,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_longk_free(c);
 	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -288,31 +288,24 @@ extern "C" sbl_status sbl_load(sbl_ctx *c, uint32_t nchr, const uint8_t *const *
 		}
 		SBL_CHECK(L <= (1ull << 30), SBL_ERR_TOO_LARGE, "total input larger than 2^30 bp");
 		size_t E = (size_t)L + nchr + 1, Epad = (E + 31) / 32 * 32 + 64;
+		// the element array '$' c0 '$' c1 '$' ...: one memcpy per record on the host (1 B/base); original positions and the
+		// list of non-ACGT positions are derived on the device (sbl_finish_load, fasta_load.hip)
 		std::vector<uint8_t> ch(Epad, (uint8_t)'$');
-		std::vector<uint32_t> op(E, 0);
 		c->sepidx.assign(nchr + 1, 0);
-		c->amb_elem.clear(); c->amb_orig.clear();
 		size_t e = 1;
 		for (uint32_t i = 0; i < nchr; i++) {
 			c->sepidx[i] = (uint32_t)(e - 1);
-			memcpy(&ch[e], seq[i], len[i]);
-			for (uint64_t j = 0; j < len[i]; j++) {
-				uint8_t x = seq[i][j];
-				if (x != 'A' && x != 'C' && x != 'G' && x != 'T') { c->amb_elem.push_back((uint32_t)(e + j)); c->amb_orig.push_back(x); }
-				op[e + j] = (uint32_t)j;                         // Counter<Pos>, reference src/blockfinder.cpp:74
-			}
-			e += len[i];
-			op[e] = (uint32_t)len[i];                            // trailing '$' stores the length, reference src/dnasequence.cpp:96
-			e++;
+			if (len[i]) memcpy(&ch[e], seq[i], len[i]);
+			e += len[i] + 1;
 		}
 		c->sepidx[nchr] = (uint32_t)(e - 1);
 		c->nchr = nchr; c->nelem = E;
-		c->d_ch.ensure(Epad); c->d_op.ensure(E * 4); c->d_sepidx.ensure((size_t)(nchr + 1) * 4);
+		c->fa_names.clear();
+		c->d_ch.ensure(Epad); c->d_sepidx.ensure((size_t)(nchr + 1) * 4);
 		HIP_TRY(hipMemcpyAsync(c->d_ch.p, ch.data(), Epad, hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipMemcpyAsync(c->d_op.p, op.data(), E * 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(c->d_sepidx.p, c->sepidx.data(), (size_t)(nchr + 1) * 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		drop_host_state(c);
+		sbl_finish_load(c);
 	});
 }
 

@@ -20,6 +20,8 @@ struct sbl_ctx {
 	std::vector<uint32_t> amb_elem;      // element indices, chromosome-major order
 	std::vector<uint8_t> amb_orig;       // their original characters
 	DevBuf d_amb_elem, d_amb_char;
+	DevBuf d_fa_text, d_fa_lines, d_fa_recs;   // sbl_load_fasta: file text, per-line and per-record tables
+	std::vector<std::string> fa_names;   // record descriptions of the last sbl_load_fasta
 
 	// stage-boundary checkpoint (sbl_save_state / sbl_restore_state)
 	DevBuf d_save_ch, d_save_op;
@@ -95,6 +97,8 @@ static sbl_status guarded(sbl_ctx *c, F f)
 void sbl_pack(sbl_ctx *c);
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // fills d_bif[0..1], bif_count
 void sbl_compact_marks(sbl_ctx *c, int strand);
+// implemented in fasta_load.hip
+void sbl_finish_load(sbl_ctx *c);   // d_ch / sepidx in place: original positions + list of non-ACGT elements, on the device
 // implemented in shard.hip
 void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k <= 32, c->comm attached: hash-prefix sharded table
 void sbl_comm_release(sbl_ctx *c);
