@@ -114,6 +114,12 @@ uint32_t sbl_nchr(const sbl_ctx *ctx);
  * observation channel behind SerializeCondensedGraph (src/serialization.cpp:88-110). */
 sbl_status sbl_list_edges(sbl_ctx *ctx, uint32_t k, const sbl_edge **edges, uint64_t *n);
 
+/* H0: the k-mer hash of the reference's hashing.h (SlidingWindow / KMerHashFunction, src/hashing.h:14-112; HASH_BASE 57,
+ * arithmetic mod 2^64) for every k-mer of the current state: strand 0 then strand 1 (complemented characters, walk order),
+ * chromosomes ascending.  The reference's production path never executes it; provided with a known-answer test.
+ * Array owned by the ctx, valid until the next call. */
+sbl_status sbl_kmer_hashes(sbl_ctx *ctx, uint32_t k, const uint64_t **values, uint64_t *n);
+
 /* Stage-boundary checkpoint of the resident state (sequences + original positions), device to device.
  * The reference keeps no resumable state; the stage boundary is the natural one. */
 sbl_status sbl_save_state(sbl_ctx *ctx);

@@ -47,6 +47,8 @@ def lib():
         L.orc_nchr.argtypes = [C.c_void_p]
         L.orc_nchr.restype = C.c_uint32
         L.orc_list_edges.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_free.argtypes = [C.c_void_p]
         L.orc_force_long_k_path.argtypes = [C.c_void_p, C.c_int]
         L.orc_rand.argtypes = [C.c_void_p]
         L.orc_rand.restype = C.c_uint32
@@ -123,6 +125,15 @@ class Oracle:
         if rc:
             raise ValueError("orc_list_edges failed: %d" % rc)
         return _view(e.value, n.value, EDGE_DTYPE)
+
+    def kmer_hashes(self, k: int) -> np.ndarray:
+        v, n = C.c_void_p(), C.c_uint64()
+        rc = self.L.orc_kmer_hashes(self.h, k, C.byref(v), C.byref(n))
+        if rc:
+            raise ValueError("orc_kmer_hashes failed: %d" % rc)
+        a = _view(v.value, n.value, np.dtype("<u8"))
+        self.L.orc_free(v)
+        return a
 
     def last_timing(self) -> Tuple[float, float, float]:
         a, b, c = C.c_double(), C.c_double(), C.c_double()

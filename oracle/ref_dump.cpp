@@ -9,13 +9,14 @@
 // into flat binary files that make_golden.py turns into committed fixtures.
 //
 // usage: ref_dump <in.fasta> <out-prefix> <cmd>...
-//   cmd = state | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+//   cmd = state | hash:K | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
 #include "common.h"
 #include "fasta.h"
 #include "dnasequence.h"
 #define private public
 #include "blockfinder.h"
 #undef private
+#include "hashing.h"
 #include <stdint.h>
 #include <string.h>
 #include <time.h>
@@ -51,6 +52,35 @@ static void dump_enum(BlockFinder &bf, size_t k, const std::string &path)
 		}
 		put64(f, rec.size() / 3);
 		if(!rec.empty()) fwrite(&rec[0], 4, rec.size(), f);
+	}
+	fclose(f);
+}
+
+// H0 (reference src/hashing.h:14-100): SlidingWindow<StrandIterator> hash of every k-mer, strand 0 then 1, chromosomes ascending,
+// walk order; per (strand, chr): u64 count, count x u64.  Every value is what Move() maintains and (assert) CalcKMerHash gives.
+static void dump_hashes(BlockFinder &bf, size_t k, const std::string &path)
+{
+	std::vector<std::vector<Pos> > opos(bf.originalPos_);
+	DNASequence seq(bf.rawSeq_, opos);
+	FILE *f = fopen(path.c_str(), "wb");
+	for(size_t strand = 0; strand < 2; strand++)
+	{
+		for(size_t chr = 0; chr < seq.ChrNumber(); chr++)
+		{
+			std::vector<uint64_t> val;
+			StrandIterator begin = seq.Begin((DNASequence::Direction)strand, chr), end = seq.End((DNASequence::Direction)strand, chr);
+			if(bf.rawSeq_[chr].size() >= k)
+			{
+				SlidingWindow<StrandIterator> window(begin, end, k);
+				for(bool ok = window.Valid(); ok; ok = window.Move())
+				{
+					val.push_back(window.GetValue());
+					if(window.GetValue() != SlidingWindow<StrandIterator>::CalcKMerHash(window.GetBegin(), k)) { fprintf(stderr, "rolling hash differs from CalcKMerHash\n"); exit(5); }
+				}
+			}
+			put64(f, val.size());
+			if(!val.empty()) fwrite(&val[0], 8, val.size(), f);
+		}
 	}
 	fclose(f);
 }
@@ -103,6 +133,10 @@ int main(int argc, char **argv)
 			// seconds = wall time of the reference's own BlockFinder::PerformGraphSimplifications (bench.py: cpu_baseline kind "reference")
 			fprintf(stderr, "stage k=%u D=%u iter=%u -> bulges=%zu seconds=%.6f\n", k, d, it, bulges,
 			        (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+		}
+		else if(sscanf(argv[a], "hash:%u", &k) == 1)
+		{
+			dump_hashes(finder, k, prefix + buf);
 		}
 		else if(strcmp(argv[a], "state") == 0)             // rawSeq_ / originalPos_ as BlockFinder::Init leaves them + the record descriptions
 		{

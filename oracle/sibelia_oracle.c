@@ -959,3 +959,41 @@ int orc_list_edges(orc_ctx *c, uint32_t k, const orc_edge **edges, uint64_t *nou
 	if (nout) *nout = c->nedge;
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * H0: the k-mer hash of the reference's hashing.h (SlidingWindow / KMerHashFunction, src/hashing.h:14-112), which
+ * the production path never executes: H(w) = sum w[i] * 57^(k-1-i) mod 2^64 over the characters a
+ * StrandIterator yields (negative strand: DNASequence::Translate of the character, src/dnasequence.cpp:10-28,41-44).
+ * Computed here the way Move() does (hashing.h:52-66): value = (value - first * 57^(k-1)) * 57 + next.
+ * out: for strand 0 then 1, chromosomes ascending: len - k + 1 values in walk order (none if len < k); malloc'd. */
+static unsigned char orc_translate(unsigned char c)
+{
+	switch (c) { case 'a': return 't'; case 't': return 'a'; case 'g': return 'c'; case 'c': return 'g';
+	             case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; default: return c; }
+}
+int orc_kmer_hashes(orc_ctx *c, uint32_t k, uint64_t **out, uint64_t *nout)
+{
+	uint64_t total = 0, at = 0, high = 1;
+	if (k < 1) return 1;
+	for (uint32_t ch = 0; ch < c->nchr; ch++) if (c->len[ch] >= k) total += 2 * (c->len[ch] - k + 1);
+	for (uint32_t i = 1; i < k; i++) high *= 57;
+	uint64_t *v = (uint64_t *)malloc((total ? total : 1) * sizeof *v);
+	if (!v) return 2;
+	for (int strand = 0; strand < 2; strand++)
+		for (uint32_t ch = 0; ch < c->nchr; ch++) {
+			uint64_t n = c->len[ch];
+			if (n < k) continue;
+#define ORC_AT(p) ((uint64_t)(signed char)(strand ? orc_translate(c->seq[ch][n - 1 - (p)]) : c->seq[ch][(p)]))
+			uint64_t h = 0;
+			for (uint32_t i = 0; i < k; i++) h = h * 57 + ORC_AT(i);          /* CalcKMerHash, hashing.h:73-88 */
+			v[at++] = h;
+			for (uint64_t p = 1; p + k <= n; p++) {
+				h = (h - ORC_AT(p - 1) * high) * 57 + ORC_AT(p + k - 1);  /* Move() */
+				v[at++] = h;
+			}
+#undef ORC_AT
+		}
+	*out = v; *nout = total;
+	return 0;
+}
+void orc_free(void *p) { free(p); }

@@ -62,6 +62,10 @@ uint32_t orc_nchr(const orc_ctx *c);
 /* BlockFinder::ListEdges on a fresh IndexedSequence at k (src/serialization.cpp:56-86). */
 int orc_list_edges(orc_ctx *c, uint32_t k, const orc_edge **edges, uint64_t *n);
 
+/* H0: k-mer hashes of the reference's hashing.h (src/hashing.h:14-112) over the current state, both strands; malloc'd, orc_free. */
+int orc_kmer_hashes(orc_ctx *c, uint32_t k, uint64_t **out, uint64_t *n);
+void orc_free(void *p);
+
 /* test hooks */
 void orc_force_long_k_path(orc_ctx *c, int on);      /* use the rank-doubling grouping even for k <= 32 */
 uint32_t orc_rand(orc_ctx *c);                       /* next value of the ctx's glibc rand() stream   */

@@ -57,6 +57,30 @@ __global__ void __launch_bounds__(256) k_list_edges(const unsigned *__restrict__
 	valid[i] = 1;
 }
 
+// H0: the k-mer hash of the reference's hashing.h (SlidingWindow::CalcKMerHash, src/hashing.h:73-88):
+// H(w) = sum w[i] * 57^(k-1-i) mod 2^64 over the characters a StrandIterator yields (negative strand: complemented,
+// DNASequence::Translate).  One thread per k-mer; out index = [strand 0: chromosomes ascending, walk order][strand 1: the same].
+__global__ void __launch_bounds__(256) k_kmer_hashes(const uint8_t *__restrict__ ch, const unsigned *__restrict__ sepidx, unsigned nchr, unsigned k,
+                                                     const unsigned long long *__restrict__ chroff /* nchr + 1: k-mers before chromosome c on one strand */,
+                                                     unsigned long long per_strand, unsigned long long *__restrict__ out)
+{
+	unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= 2 * per_strand) return;
+	const unsigned strand = i >= per_strand;
+	const unsigned long long j = strand ? i - per_strand : i;
+	unsigned lo = 0, hi = nchr;                               // chromosome c with chroff[c] <= j < chroff[c + 1]
+	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (chroff[mid] <= j) lo = mid; else hi = mid; }
+	const unsigned c = lo, p = (unsigned)(j - chroff[c]);
+	const unsigned first = sepidx[c] + 1, last = sepidx[c + 1] - 1;
+	unsigned long long h = 0;
+	for (unsigned t = 0; t < k; t++) {
+		uint8_t x = strand ? ch[last - p - t] : ch[first + p + t];
+		if (strand) x = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x == 'a' ? 't' : x == 't' ? 'a' : x == 'c' ? 'g' : x == 'g' ? 'c' : x;
+		h = h * 57ull + (unsigned long long)(long long)(signed char)x;
+	}
+	out[i] = h;
+}
+
 // ------------------------------------------------------------------------------------------- helpers
 static void drop_host_state(sbl_ctx *c) { c->host_state_valid = false; }
 
@@ -426,6 +450,31 @@ extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **se
 		if (seq) *seq = c->h_seq[chr].data();
 		if (orig_pos) *orig_pos = c->h_op[chr].data();
 		if (len) *len = c->h_seq[chr].size();
+	});
+}
+
+extern "C" sbl_status sbl_kmer_hashes(sbl_ctx *c, uint32_t k, const uint64_t **values, uint64_t *n)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(k >= 1, SBL_ERR_BAD_ARG, "k must be at least 1");
+		std::vector<unsigned long long> off(c->nchr + 1, 0);
+		for (uint32_t ch = 0; ch < c->nchr; ch++) {
+			size_t len = c->sepidx[ch + 1] - c->sepidx[ch] - 1;
+			off[ch + 1] = off[ch] + (len >= k ? len - k + 1 : 0);
+		}
+		const unsigned long long per = off[c->nchr];
+		c->h_hashes.resize(2 * per);
+		if (per) {
+			c->d_inst.ensure(2 * per * 8 + (size_t)(c->nchr + 1) * 8 + 64);
+			unsigned long long *d_out = c->d_inst.as<unsigned long long>(), *d_off = d_out + 2 * per;
+			HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t)(c->nchr + 1) * 8, hipMemcpyHostToDevice, c->stream));
+			k_kmer_hashes<<<nblocks(2 * per, 256), 256, 0, c->stream>>>(c->d_ch.as<uint8_t>(), c->d_sepidx.as<unsigned>(), c->nchr, k, d_off, per, d_out);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(c->h_hashes.data(), d_out, 2 * per * 8, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+		}
+		if (values) *values = c->h_hashes.data();
+		if (n) *n = 2 * per;
 	});
 }
 

@@ -57,6 +57,7 @@ struct sbl_ctx {
 	// results handed out through the ABI
 	std::vector<sbl_inst> inst[2];
 	std::vector<sbl_edge> edges;
+	std::vector<uint64_t> h_hashes;
 
 	// ---- multi-GPU enumeration (shard.hip): attached communicator + exchange buffers
 	struct SblComm *comm = nullptr;

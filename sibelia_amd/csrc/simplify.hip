@@ -435,86 +435,109 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	}
 }
 
-// one workgroup: the lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window
-// (and runs alone if it is the lowest).  Eight ids per thread and step (8-byte loads of the need / big flags).
-// out: ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag)
-#define SEL_WORDS 4                          // 8-id words per thread and step: 1024 threads x 32 ids = 32768 ids per step
-__global__ void __launch_bounds__(1024) k_select(GraphView g, unsigned *win, unsigned lo, unsigned limit, unsigned W)
+// The lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window (and runs alone if it is the lowest).
+// out: win[], ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag).
+// Two launches over chunks of `chunk` ids (256 threads x chunk/256 flags, 8-byte loads of the need / big bytes):
+//   k_select_count  pending ids per chunk, first pending id, first pending big id (atomicMin)
+//   k_select_write  every chunk below the window limit places its ids after the chunks ahead of it; the last one finalises
+// sel: [0] first pending big id  [1] first pending id  [2] pending ids below the big id  [3] ticket  [8 ...] per-chunk counts
+#define SEL_THREADS 256
+template <class F>
+__device__ __forceinline__ void select_scan_flags(const GraphView &g, unsigned long long id0, unsigned per_thread, unsigned lo, unsigned limit, F f)
 {
-	__shared__ unsigned s_wave[16];
-	__shared__ unsigned s_base, s_first, s_bigid, s_stop, s_solo;
-	const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	if (threadIdx.x == 0) { s_base = 0; s_first = SBL_NONE; s_stop = 0; s_solo = 0; }
+	// f(first id of the word, pending bytes (0x01 per pending id), big-and-pending bytes)
+	for (unsigned q = 0; q < per_thread; q += 8) {
+		const unsigned long long idq = id0 + q;
+		if (idq > limit) break;
+		unsigned long long nb = *reinterpret_cast<const unsigned long long *>(g.need + idq);
+		unsigned long long bb = *reinterpret_cast<const unsigned long long *>(g.big + idq);
+#pragma unroll
+		for (int j = 0; j < 8; j++) if (idq + j < lo || idq + j > limit) nb &= ~(0xFFull << (8 * j));
+		nb = (nb | (nb >> 1) | (nb >> 2) | (nb >> 3) | (nb >> 4) | (nb >> 5) | (nb >> 6) | (nb >> 7)) & 0x0101010101010101ull;
+		bb = (bb | (bb >> 1) | (bb >> 2) | (bb >> 3) | (bb >> 4) | (bb >> 5) | (bb >> 6) | (bb >> 7)) & nb;
+		f(idq, nb, bb);
+	}
+}
+__global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsigned *__restrict__ sel, unsigned lo, unsigned limit, unsigned chunk0, unsigned chunk)
+{
+	__shared__ unsigned s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
-	for (unsigned long long start = lo & ~7ull; start <= limit; start += 8192ull * SEL_WORDS) {
-		const unsigned long long id0 = start + 8ull * SEL_WORDS * threadIdx.x;
-		unsigned long long nb[SEL_WORDS], bb[SEL_WORDS];         // byte j of word q = id0 + 8q + j: 1 = pending / pending and big
-		unsigned firstp = SBL_NONE, firstb = SBL_NONE;
+	const unsigned per = chunk / SEL_THREADS;
+	const unsigned long long id0 = (unsigned long long)(chunk0 + blockIdx.x) * chunk + (unsigned long long)threadIdx.x * per;
+	unsigned cnt = 0, firstp = SBL_NONE, firstb = SBL_NONE;
+	select_scan_flags(g, id0, per, lo, limit, [&](unsigned long long idq, unsigned long long nb, unsigned long long bb) {
+		cnt += __popcll(nb);
+		if (nb && firstp == SBL_NONE) firstp = (unsigned)(idq + (__builtin_ctzll(nb) >> 3));
+		if (bb && firstb == SBL_NONE) firstb = (unsigned)(idq + (__builtin_ctzll(bb) >> 3));
+	});
+	if (cnt) atomicAdd(&s_cnt, cnt);
+	if (firstp != SBL_NONE) atomicMin(&sel[1], firstp);
+	if (firstb != SBL_NONE) atomicMin(&sel[0], firstb);
+	__syncthreads();
+	if (threadIdx.x == 0) sel[8 + blockIdx.x] = s_cnt;
+}
+__global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsigned *__restrict__ sel, unsigned *__restrict__ win, unsigned lo, unsigned limit, unsigned W,
+                                                              unsigned chunk0, unsigned chunk, unsigned nchunks)
+{
+	__shared__ unsigned s_wave[SEL_THREADS / 64], s_prefix, s_last;
+	const unsigned bigid = sel[0], per = chunk / SEL_THREADS, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long cstart = (unsigned long long)(chunk0 + blockIdx.x) * chunk;
+	unsigned total = 0;
+	if (cstart < bigid) {                                            // (ids at or above the first pending big id are not selected)
+		// ids selected by the chunks ahead of this one: all of them lie below the big id, their counts are exact
+		unsigned pre = 0;
+		for (unsigned j = threadIdx.x; j < blockIdx.x; j += SEL_THREADS) pre += sel[8 + j];
 #pragma unroll
-		for (int q = 0; q < SEL_WORDS; q++) {
-			const unsigned long long idq = id0 + 8ull * q;
-			nb[q] = 0; bb[q] = 0;
-			if (idq <= limit) {
-				nb[q] = *reinterpret_cast<const unsigned long long *>(g.need + idq);
-				bb[q] = *reinterpret_cast<const unsigned long long *>(g.big + idq);
-#pragma unroll
-				for (int j = 0; j < 8; j++) if (idq + j < lo || idq + j > limit) nb[q] &= ~(0xFFull << (8 * j));
-				nb[q] = (nb[q] | (nb[q] >> 1) | (nb[q] >> 2) | (nb[q] >> 3) | (nb[q] >> 4) | (nb[q] >> 5) | (nb[q] >> 6) | (nb[q] >> 7)) & 0x0101010101010101ull;
-				bb[q] = (bb[q] | (bb[q] >> 1) | (bb[q] >> 2) | (bb[q] >> 3) | (bb[q] >> 4) | (bb[q] >> 5) | (bb[q] >> 6) | (bb[q] >> 7)) & nb[q];
-				if (bb[q] && firstb == SBL_NONE) firstb = (unsigned)(idq + (__builtin_ctzll(bb[q]) >> 3));
-				if (nb[q] && firstp == SBL_NONE) firstp = (unsigned)(idq + (__builtin_ctzll(nb[q]) >> 3));
-			}
-		}
-		if (threadIdx.x == 0) s_bigid = SBL_NONE;
+		for (int d = 32; d > 0; d >>= 1) pre += __shfl_down(pre, d);
+		if (lane == 0) s_wave[wv] = pre;
 		__syncthreads();
-		if (firstb != SBL_NONE) atomicMin(&s_bigid, firstb);
-		if (firstp != SBL_NONE) atomicMin(&s_first, firstp);
+		if (threadIdx.x == 0) { unsigned t = 0; for (unsigned w = 0; w < SEL_THREADS / 64; w++) t += s_wave[w]; s_prefix = t; }
 		__syncthreads();
-		const unsigned bigid = s_bigid;
+		const unsigned prefix = s_prefix;
+		__syncthreads();
+		const unsigned long long id0 = cstart + (unsigned long long)threadIdx.x * per;
 		unsigned cnt = 0;
+		select_scan_flags(g, id0, per, lo, limit, [&](unsigned long long idq, unsigned long long nb, unsigned long long) {
 #pragma unroll
-		for (int q = 0; q < SEL_WORDS; q++) {
-			if (bigid != SBL_NONE) {
-#pragma unroll
-				for (int j = 0; j < 8; j++) if (id0 + 8ull * q + j >= bigid) nb[q] &= ~(0xFFull << (8 * j));
-			}
-			cnt += __popcll(nb[q]);
-		}
+			for (int j = 0; j < 8; j++) if (idq + j >= bigid) nb &= ~(0xFFull << (8 * j));
+			cnt += __popcll(nb);
+		});
 		unsigned incl = cnt;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
 		if (lane == 63) s_wave[wv] = incl;
 		__syncthreads();
-		unsigned woff = 0, total = 0;
-		for (unsigned w = 0; w < 16; w++) { unsigned v = s_wave[w]; if (w < wv) woff += v; total += v; }
-		unsigned pos = s_base + woff + incl - cnt;
-#pragma unroll
-		for (int q = 0; q < SEL_WORDS; q++) {
-			unsigned long long tk = nb[q];
-			while (tk) {
-				unsigned j = __builtin_ctzll(tk) >> 3;
-				if (pos < W) win[pos] = (unsigned)(id0 + 8ull * q + j);
-				pos++;
-				tk &= tk - 1;
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			unsigned c = s_base + total;
-			if (c >= W) { c = W; s_stop = 1; }
-			else if (bigid != SBL_NONE) {
-				s_stop = 1;
-				if (c == 0) { win[0] = bigid; c = 1; s_solo = 1; }
-			}
-			s_base = c;
-		}
-		__syncthreads();
-		if (s_stop) break;
+		unsigned woff = 0;
+		for (unsigned w = 0; w < SEL_THREADS / 64; w++) { if (w < wv) woff += s_wave[w]; total += s_wave[w]; }
+		unsigned pos = prefix + woff + incl - cnt;
+		if (prefix < W && cnt)
+			select_scan_flags(g, id0, per, lo, limit, [&](unsigned long long idq, unsigned long long nb, unsigned long long) {
+				while (nb) {
+					unsigned j = __builtin_ctzll(nb) >> 3;
+					if (idq + j < bigid) { if (pos < W) win[pos] = (unsigned)(idq + j); pos++; }
+					nb &= nb - 1;
+				}
+			});
 	}
+	// the last chunk to finish publishes the result
+	__syncthreads();
 	if (threadIdx.x == 0) {
-		g.ctr[CTR_NWIN] = s_base;
-		g.ctr[CTR_LO] = s_first == SBL_NONE ? lo : s_first;
-		g.ctr[CTR_PUSHED] = s_solo;
+		if (total) atomicAdd(&sel[2], total);
+		__threadfence();
+		s_last = atomicAdd(&sel[3], 1u) == nchunks - 1;
+	}
+	__syncthreads();
+	if (s_last && threadIdx.x == 0) {
+		__threadfence();
+		unsigned n = *(volatile unsigned *)&sel[2], solo = 0;
+		if (n > W) n = W;
+		if (n == 0 && bigid != SBL_NONE) { win[0] = bigid; n = 1; solo = 1; }
+		const unsigned first = *(volatile unsigned *)&sel[1];
+		g.ctr[CTR_NWIN] = n;
+		g.ctr[CTR_LO] = first == SBL_NONE ? lo : first;
+		g.ctr[CTR_PUSHED] = solo;
+		sel[0] = SBL_NONE; sel[1] = SBL_NONE; sel[2] = 0; sel[3] = 0;      // ready for the next selection (stream order)
 	}
 }
 
@@ -1454,7 +1477,7 @@ struct SimplifyState {
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
-	DevBuf nmark, maux[2], iota;
+	DevBuf nmark, maux[2], iota, sel;
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
 	unsigned *h_ctr = nullptr;            // pinned
 };
@@ -1568,7 +1591,12 @@ struct DeviceBackend {
 	}
 	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
 	{
-		k_select<<<1, 1024, 0, c->stream>>>(g, st->win.as<unsigned>(), lo, limit, W);
+		// chunks of >= 8192 ids, at most ~1024 of them
+		unsigned chunk = 8192;
+		while ((unsigned long long)chunk * 1024 < (unsigned long long)nid_ + 1) chunk <<= 1;
+		const unsigned chunk0 = lo / chunk, nchunks = limit / chunk - chunk0 + 1;
+		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), lo, limit, chunk0, chunk);
+		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks);
 		HIP_TRY(hipGetLastError());
 		read_ctr();
 		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
@@ -1663,7 +1691,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
-	                   &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->sel, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
@@ -1760,6 +1788,12 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		unsigned v[CTR_COUNT] = {0};
 		v[CTR_NE] = (unsigned)ne0; v[CTR_NN] = (unsigned)ninst; v[CTR_VIOL] = BT_NONE;
 		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, sizeof v, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+	}
+	{	// selection scratch (k_select_*): header + one count per chunk of ids; the kernels leave the header reset
+		st->sel.ensure((1024 + 16) * 4);
+		const unsigned init[4] = { SBL_NONE, SBL_NONE, 0u, 0u };
+		HIP_TRY(hipMemcpyAsync(st->sel.p, init, sizeof init, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 	}
 	st->need.ensure(nidp); st->big.ensure(nidp); st->touch.ensure(nidp); st->own.ensure(nidp * 4);

@@ -6,6 +6,7 @@ so that sha256(serialise(result)) can be compared with tests/golden/vectors.json
   enum   u32 bif_count | for strand in (+,-): u64 n, n x (u32 id, u32 chr, u32 pos) in (chr,pos) order
   state  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
   dot    text of BlockFinder::SerializeCondensedGraph (reference src/serialization.cpp:88-110)
+  hash   for strand in (+,-), per chromosome: u64 n, n x u64 k-mer hashes of the reference's hashing.h in walk order
 """
 from __future__ import annotations
 
@@ -32,6 +33,20 @@ def state_bytes(bulges: int, seqs: Sequence[bytes], opos: Sequence[np.ndarray]) 
         out.append(struct.pack("<Q", len(s)))
         out.append(bytes(s))
         out.append(np.ascontiguousarray(p, dtype="<u4").tobytes())
+    return b"".join(out)
+
+
+def hash_bytes(values: np.ndarray, lens: Sequence[int], k: int) -> bytes:
+    """values: flat uint64 array, strand 0 then strand 1, chromosomes ascending; lens: chromosome lengths."""
+    values = np.ascontiguousarray(values, dtype="<u8")
+    out, at = [], 0
+    for _ in range(2):
+        for n in lens:
+            m = n - k + 1 if n >= k else 0
+            out.append(struct.pack("<Q", m))
+            out.append(values[at:at + m].tobytes())
+            at += m
+    assert at == len(values)
     return b"".join(out)
 
 

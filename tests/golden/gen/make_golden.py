@@ -12,6 +12,7 @@ file whose sha256 (and for tiny cases whose bytes) are stored.  Output formats:
   enum:K          u32 bif_count | per strand: u64 n, n x (u32 id, u32 chr, u32 pos) in (chr,pos) order
   stage:K:D:ITER  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
   dot:K           text of BlockFinder::SerializeCondensedGraph(K)
+  hash:K          H0: SlidingWindow hashes (src/hashing.h) of every K-mer of the current rawSeq_, per (strand, chr): u64 n, n x u64
 """
 import base64, gzip, hashlib, json, os, shutil, struct, subprocess, sys, tempfile
 
@@ -54,7 +55,7 @@ def run_case(seqs, cmds, keep_bytes=False, timeout=None):
 HAND = {
     # SURVEY.md Appendix A.1 / A.2 (SNP bulge; indel + N + reverse complement)
     "snp_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
-               ["enum:5", "dot:5", "stage:5:12:4", "enum:5", "dot:5"]),
+               ["enum:5", "dot:5", "stage:5:12:4", "enum:5", "dot:5", "hash:5", "hash:1", "hash:40", "hash:41"]),
     "indel_N_rc_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC",
                        "ACGTTGCAAGGCTTATCACGGATCCATGACCTGAATCGTTAGC",
                        "GCTAACGATTCAGGTCATGGATCCGTNAGCCTTGCAACGT"],
@@ -62,13 +63,13 @@ HAND = {
     "palindrome_k4": (["AACGCGTTAGCTAGGATCCTTAATTAAGG", "AACGCGTTAGGTAGGATCCTTAATTCAGG"],
                       ["enum:4", "stage:4:9:4", "dot:4"]),
     "tandem_k3": (["ACGACGACGACGTTACGACGACG", "ACGACGACGTTTACGACGACGACG"], ["enum:3", "stage:3:8:4", "dot:3"]),
-    "short_chr_k6": (["ACGTA", "ACGTAC", "ACGTACG", "TTACGTACGGA", "A"], ["enum:6", "stage:6:10:4", "dot:6"]),
+    "short_chr_k6": (["ACGTA", "ACGTAC", "ACGTACG", "TTACGTACGGA", "A"], ["enum:6", "stage:6:10:4", "dot:6", "hash:6", "hash:2"]),
     "identical_k5": (["ACGTTGCATGCCGTAAGCTTGGA"] * 3, ["enum:5", "stage:5:10:4", "dot:5"]),
     "three_way_k4": (["TTGACCAGTACGGTCAATGCCATAGGCTAAGC", "TTGACCAGTTCGGTCAATGCGATAGGCTAAGC",
                       "TTGACCAGTGCGGTCAATGCTATAGGCTAAGC", "TTGACCAGTACGGTCAATGCCATAGGCTAAGC"],
                      ["enum:4", "stage:4:10:4", "dot:4"]),
     "ambig_codes_k4": (["ACGTNNACGTRYACGTKMACGT-ACGTXACGU", "NACGTTGCAACGTNACGTTGCAAN"],
-                       ["dot:4", "stage:4:8:4", "dot:4", "stage:6:12:2", "dot:6"]),
+                       ["hash:4", "dot:4", "stage:4:8:4", "dot:4", "stage:6:12:2", "dot:6", "hash:33"]),
     "single_base_iter1": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
                           ["stage:5:12:1", "stage:5:3:4", "stage:2:4:4", "dot:2"]),
 }
@@ -90,7 +91,7 @@ def cases(skipped):
     sa = "Staphylococcus_aureus_pair.fa.gz"
     data = os.path.join(ROOT, "tests", "golden", "data")
     rd = lambda f: (lambda: W.read_fasta(os.path.join(data, f))[1])
-    yield "real/hpylori_k25", {"kind": "fasta", "file": hp}, rd(hp), ["enum:25", "stage:25:150:4", "enum:25", "dot:25"], False, None
+    yield "real/hpylori_k25", {"kind": "fasta", "file": hp}, rd(hp), ["enum:25", "stage:25:150:4", "enum:25", "dot:25", "hash:25"], False, None
     yield "real/hpylori_fine", {"kind": "fasta", "file": hp}, rd(hp), ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "dot:500"], False, None
     yield ("real/hpylori_loose", {"kind": "fasta", "file": hp}, rd(hp),
            ["stage:30:150:4", "stage:100:1000:4", "stage:1000:5000:4", "stage:5000:15000:4", "enum:5000"], False, None)
