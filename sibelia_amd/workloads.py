@@ -64,6 +64,23 @@ def random_dna(total: int, nrec: int, seed: int) -> List[bytes]:
     return [_ACGT[rng.integers(0, 4, per, dtype=np.uint8)].tobytes() for _ in range(nrec)]
 
 
+def longk_case(total: int, nrec: int, seed: int = 5) -> List[bytes]:
+    """Config 5 shape: uniform random DNA in nrec records with planted structure, for k in the thousands.
+
+    Random DNA has no repeated 5000-mers of its own, so everything a long-k stage finds comes from what is planted here
+    (independently of the background size): a 40 kbp segment of record 0 copied into record 1 with ONE substitution in
+    its middle (a bulge of k + 1 steps: collapsed when D > k + 1), and -- with four records or more -- a 30 kbp exact
+    duplicate between records 2 and 3.  Needs records of at least 50 kbp."""
+    seqs = [bytearray(s) for s in random_dna(total, nrec, seed)]
+    assert nrec >= 2 and len(seqs[0]) >= 50_000
+    seg = bytearray(seqs[0][5000:45000])
+    seg[20000] = ord("ACGT"["ACGT".index(chr(seg[20000])) ^ 1])      # A<->C, G<->T
+    seqs[1][1000:41000] = seg
+    if nrec >= 4:
+        seqs[3][7000:37000] = seqs[2][3000:33000]
+    return [bytes(s) for s in seqs]
+
+
 def small_case(seed: int) -> Tuple[List[bytes], int, int]:
     """A tiny randomised multi-record input plus (k, D) chosen to provoke many bulges.
 
