@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
+#include <link.h>
 #include <pthread.h>
 #include <time.h>
 #include <rocprim/rocprim.hpp>
@@ -63,8 +64,16 @@ static RcclApi load_rccl()
 {
 	RcclApi a;
 	{
-		// an already loaded librccl (e.g. the one PyTorch brought) is reused by the loader
-		for (const char *nm : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { a.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (a.h) break; }
+		// A librccl that is already in the process (the one PyTorch links against lives in torch/lib and is NOT what the
+		// loader finds under the bare soname) must be the one used: two RCCL copies in one process corrupt the heap at exit.
+		std::string loaded;
+		dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *out) -> int {
+			if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) { *static_cast<std::string *>(out) = info->dlpi_name; return 1; }
+			return 0;
+		}, &loaded);
+		if (!loaded.empty()) a.h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+		if (!a.h)
+			for (const char *nm : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { a.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (a.h) break; }
 		if (a.h) {
 #define SBL_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.h, name))
 			SBL_SYM(GetUniqueId, "ncclGetUniqueId"); SBL_SYM(CommInitRank, "ncclCommInitRank"); SBL_SYM(CommDestroy, "ncclCommDestroy");

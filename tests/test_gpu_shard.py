@@ -80,3 +80,76 @@ def test_rccl_transport_single_rank():
     c = rc.enumerate(25)
     d = one.enumerate(25)
     assert c[0] == d[0] and np.array_equal(c[1], d[1])
+
+
+def _rccl_rank(rank, world, port, q):
+    # one process per GPU: torch.distributed (backend "nccl" = RCCL) only carries the 128-byte communicator id,
+    # the exchange itself is csrc/shard.hip's grouped ncclSend / ncclRecv + ncclAllGather
+    import os
+    import hashlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from sibelia_amd import BlockFinder, workloads as W, dist as D, formats as F
+    seqs = W.gen_strains(L0=150_000, n=4, seed=12, inv_min=3000, inv_max=12000)
+    bf = BlockFinder(seqs, device=rank)
+    D.attach(bf, device=torch.device("cuda", rank))
+    bc, pos, neg = bf.enumerate(25)
+    cols = lambda a: np.stack([a["id"], a["chr"], a["pos"]], 1).astype("<u4") if len(a) else np.zeros((0, 3), "<u4")
+    d_enum = hashlib.sha256(F.enum_bytes(bc, cols(pos), cols(neg))).hexdigest()
+    bulges = bf.simplify_stage(25, 150, 4)
+    s, p = bf.state()
+    d_state = hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest()
+    st = bf.stats()
+    q.put((rank, d_enum, d_state, st["exchange_bytes"]))
+    dist.barrier()
+    bf.close()
+    dist.destroy_process_group()
+
+
+def _run_rccl(world):
+    import hashlib
+    import os
+    import multiprocessing as mp          # (not torch.multiprocessing: this process must not load a second copy of librccl, see shard.hip)
+    from sibelia_amd import BlockFinder, workloads as W, formats as F
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # the single-GPU result of the same input
+    seqs = W.gen_strains(L0=150_000, n=4, seed=12, inv_min=3000, inv_max=12000)
+    one = BlockFinder(seqs, device=0)
+    bc, pos, neg = one.enumerate(25)
+    cols = lambda a: np.stack([a["id"], a["chr"], a["pos"]], 1).astype("<u4") if len(a) else np.zeros((0, 3), "<u4")
+    d_enum = hashlib.sha256(F.enum_bytes(bc, cols(pos), cols(neg))).hexdigest()
+    bulges = one.simplify_stage(25, 150, 4)
+    s, p = one.state()
+    d_state = hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest()
+    for rank, e, t, xb in res:
+        assert e == d_enum and t == d_state, "rank %d disagrees with the single-GPU result" % rank
+        assert world == 1 or xb > 0
+    return res
+
+
+def test_rccl_launch_harness_one_process():
+    # the same one-process-per-GPU harness as the multi-rank test below, with world size 1 (always runnable)
+    _run_rccl(1)
+
+
+def test_rccl_all_to_all_across_all_gpus_of_the_node():
+    # the real thing: one rank per visible GPU, k-mer records exchanged over xGMI; skipped on a single-GPU box
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    n = min(int(out.stdout.strip() or 0), 8)
+    if n < 2:
+        pytest.skip("needs at least two GPUs (this box has %d)" % n)
+    _run_rccl(n)
