@@ -8,12 +8,12 @@ Inputs are resident in HBM when the timed region starts (sbl_restore_state is a 
 of the saved stage-boundary state and is inside the timed region).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 (launched through torch.distributed.run, one rank per GPU over RCCL): bulge removal is globally ordered
-and is >90 % of a stage, so by default every rank runs the whole job on its own strain set ("replicas",
-weak scaling, no data-path collective); value = strand-k-mers of all ranks / max time.
---shard-enum runs ONE job on all ranks instead: the k-mer table of the enumeration is sharded by hash prefix
-(RCCL all-to-all of 16-B k-mer records + all-gathers of bifurcation codes and marks, csrc/shard.hip), the
-simplification runs replicated and bit-identical; value = strand-k-mers of the one job / max time ("strong").
+N > 1 (launched through torch.distributed.run, one rank per GPU over RCCL): north_star's configuration -- ONE job on all
+ranks, the k-mer table of the enumeration sharded by hash prefix (RCCL all-to-all of 16-B k-mer records + all-gathers of
+bifurcation codes and marks, csrc/shard.hip), the globally ordered simplification replicated and bit-identical on every GPU;
+value = strand-k-mers of the one job / max time, "scaling": "strong".  The same line carries, under "replicas", the weak-scaling
+configuration (every rank runs the whole job on its own strain set, no data-path collective), measured right after with the
+same K / W; --replicas makes that one the headline instead.
 
 The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
@@ -44,9 +44,10 @@ def main():
     ap.add_argument("--D", type=int, default=150)
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--cpu-sample-L0", type=int, default=230_000)
+    ap.add_argument("--cpu-sample-L0", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard-enum", action="store_true", help="one job on all ranks: hash-prefix sharded enumeration over RCCL")
+    ap.add_argument("--shard-enum", action="store_true", help="one job on all ranks: hash-prefix sharded enumeration over RCCL (the default for --gpus > 1)")
+    ap.add_argument("--replicas", action="store_true", help="--gpus > 1: make the replicas configuration (one independent job per GPU) the headline value")
     ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
     a = ap.parse_args()
 
@@ -68,7 +69,11 @@ def main():
         dist.barrier()
     from sibelia_amd import BlockFinder, workloads as W, dist as D
 
-    # every rank owns its own strain set (same generator, rank-specific seed): independent jobs, no collective
+    # N > 1: north_star's configuration is ONE job whose k-mer table is sharded by hash prefix over the GPUs (RCCL all-to-all);
+    # the replicas configuration (every rank its own strain set, no data-path collective) is measured afterwards and reported
+    # in the same line under "replicas" (or as the headline with --replicas)
+    if world > 1 and not a.replicas:
+        a.shard_enum = True
     seqs = W.gen_strains(**D.rank_workload(0 if a.shard_enum else rank, a.strains, a.L0))
     N = W.strand_kmers(seqs, a.k)
     bf = BlockFinder(seqs, device=local)
@@ -106,6 +111,24 @@ def main():
     dt, Ntot = D.aggregate(dt, float(N), device="cuda" if world > 1 else None)
     if a.shard_enum:
         Ntot = float(N)                      # one job, however many GPUs enumerate it
+
+    # second configuration of a multi-GPU run: replicas (weak scaling), same K / W, same barrier + max-over-ranks timing
+    replicas = None
+    if world > 1 and a.shard_enum:
+        seqs2 = W.gen_strains(**D.rank_workload(rank, a.strains, a.L0))
+        N2 = W.strand_kmers(seqs2, a.k)
+        bf2 = BlockFinder(seqs2, device=local)
+        bf2.save_state()
+        for _ in range(a.warmup + a.steps):
+            if _ == a.warmup:
+                dist.barrier(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            bf2.restore_state()
+            bf2.PerformGraphSimplifications(a.k, a.D, a.iters)
+        torch.cuda.synchronize(); dist.barrier()
+        dt2, N2tot = D.aggregate(time.perf_counter() - t2, float(N2), device="cuda")
+        replicas = {"value": N2tot / (dt2 / a.steps), "unit": "strand-k-mers/s", "ms_per_step": 1000.0 * dt2 / a.steps, "scaling": "weak",
+                    "parallelism": "replicas (x%d): one independent job per GPU on its own strain set, no data-path collective" % world}
+        bf2.close()
 
     if rank == 0:
         st = bf.stats()
@@ -160,7 +183,24 @@ def main():
                          "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg[dom],
                          "all_kernels_ms_per_step": per},
         }
-        if not a.no_cpu_baseline:
+        if replicas is not None:
+            out["replicas"] = replicas
+        if world == 1:
+            # PCIe-inclusive rate (never `value`): host buffers -> device (sbl_load: 1 B/base over PCIe; original positions and the
+            # ambiguity scan are derived on the device) + one stage + the state back to the host (5 B/base)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b2 = BlockFinder(seqs, device=local)
+            t_load = time.perf_counter() - t1
+            b2.PerformGraphSimplifications(a.k, a.D, a.iters)
+            t_stage = time.perf_counter() - t1 - t_load
+            b2.state()
+            t_all = time.perf_counter() - t1
+            b2.close()
+            out["pcie_inclusive"] = {"value": N / t_all, "unit": "strand-k-mers/s", "load_ms": 1e3 * t_load, "stage_ms": 1e3 * t_stage,
+                                     "download_ms": 1e3 * (t_all - t_load - t_stage),
+                                     "note": "cold context: includes the first-call workspace allocations of the stage"}
+        if not a.no_cpu_baseline and world == 1:
             # The reference's own CPU path beside the GPU number (north_star): oracle/_ref/ref_dump is the UNMODIFIED reference
             # compiled by oracle/build_ref.sh (it travels to the GPU box as a prebuilt binary).  The reference is single-threaded
             # and superlinear in the number of strains (8 x 4.6 Mbp take 500 s), so the sample keeps the 8 strains and shortens
