@@ -365,6 +365,154 @@ __global__ void __launch_bounds__(64) k_snapshot_first(GraphView g, MarkStream m
 	}
 }
 
+// ---- later snapshots of a stage: the same stream over a LINEARISED copy of the marks -------------------------------------------
+// After an iteration the list is no longer position-linear (collapses inserted and erased elements).  The segment ranking of
+// the copy-back (k_seg_*) gives every live element its position in the list; elin[] is the inverse map.  The marks are then
+// compacted in list order (mpos = list position, mid = id; nmark[node] = index of the instance's mark) and the verdict
+// kernel is the stream again -- with the instance lists followed through their links, since they are no longer runs of nodes.
+__global__ void __launch_bounds__(256) k_lin_positions(const uint8_t *__restrict__ ch, unsigned ne, const unsigned *__restrict__ flag, const unsigned *__restrict__ segidx,
+                                                       const unsigned *__restrict__ seg_head, const unsigned long long *__restrict__ dist, unsigned long long total,
+                                                       unsigned *__restrict__ lin, unsigned *__restrict__ elin)
+{
+	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= ne) return;
+	if (ch[e] == BT_DEAD_CHAR) { lin[e] = SBL_NONE; return; }
+	unsigned seg = segidx[e] + flag[e] - 1;
+	unsigned pos = (unsigned)(total - dist[seg] + (e - seg_head[seg]));
+	lin[e] = pos; elin[pos] = e;
+}
+__global__ void __launch_bounds__(256) k_count_marks_lin(const unsigned *__restrict__ bif, const unsigned *__restrict__ elin, size_t n, unsigned *__restrict__ chunkcnt)
+{
+	__shared__ unsigned cnt;
+	if (threadIdx.x == 0) cnt = 0;
+	__syncthreads();
+	size_t base = (size_t)blockIdx.x * 1024;
+	unsigned c = 0;
+	for (unsigned i = threadIdx.x; i < 1024; i += 256) { size_t p = base + i; c += (p < n && bif[elin[p]] != SBL_NONE); }
+	atomicAdd(&cnt, c);
+	__syncthreads();
+	if (threadIdx.x == 0) chunkcnt[blockIdx.x] = cnt;
+}
+__global__ void __launch_bounds__(256) k_write_marks_lin(const unsigned *__restrict__ bif, const unsigned *__restrict__ elin, const unsigned *__restrict__ nodeof, size_t n,
+                                                         const unsigned *__restrict__ chunkoff, unsigned *__restrict__ out_pos, unsigned *__restrict__ out_id, unsigned *__restrict__ nmark)
+{
+	__shared__ unsigned wsum[4];
+	size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+	unsigned ids[4], el[4], cn = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) { size_t p = base + i; el[i] = p < n ? elin[p] : 0u; ids[i] = p < n ? bif[el[i]] : SBL_NONE; cn += ids[i] != SBL_NONE; }
+	unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, incl = cn;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
+	if (lane == 63) wsum[wv] = incl;
+	__syncthreads();
+	unsigned off = chunkoff[blockIdx.x] + incl - cn;
+	for (unsigned w = 0; w < wv; w++) off += wsum[w];
+#pragma unroll
+	for (int i = 0; i < 4; i++) if (ids[i] != SBL_NONE) { out_pos[off] = (unsigned)(base + i); out_id[off] = ids[i]; nmark[nodeof[el[i]]] = off; off++; }
+}
+// k_mark_aux in list coordinates: chromosome ends = list positions of the separators, characters through elin[]
+__global__ void __launch_bounds__(256) k_mark_aux_lin(const unsigned *__restrict__ mpos, unsigned n, unsigned strand, const unsigned *__restrict__ sepelem, unsigned nchr,
+                                                      const unsigned *__restrict__ lin, const unsigned *__restrict__ elin, const uint8_t *__restrict__ ch, unsigned k, unsigned *__restrict__ aux)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned p = mpos[i];
+	unsigned lo = 0, hi = nchr;                               // chromosome c with lin[sep c] < p < lin[sep c + 1]
+	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (lin[sepelem[mid]] < p) lo = mid; else hi = mid; }
+	const unsigned dist = strand == 0 ? lin[sepelem[lo + 1]] - p : p - lin[sepelem[lo]];
+	unsigned bit = 0;
+	if (dist >= k + 1) {
+		const uint8_t x = ch[elin[strand == 0 ? p + k : p - k]];
+		const unsigned code = x == 'A' ? 0u : x == 'C' ? 1u : x == 'G' ? 2u : 3u;
+		bit = 1u << (strand == 0 ? code : 3u - code);
+	}
+	aux[i] = (bit << 24) | (dist < 0xFFFFFFu ? dist : 0xFFFFFFu);
+}
+
+#define SNAP_MAX_INST 256u
+// AnyBulges verdict of the touched ids (incremental) on the linearised marks; ids with more than SNAP_MAX_INST instances or too
+// many distinct marks for the LDS table get need = 1 (the probe of their round decides).
+__global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm, int incremental)
+{
+	__shared__ VerdictTable vt;
+	__shared__ unsigned s_inst[SNAP_MAX_INST];                    // (mark index << 1) | strand of every live instance, list order
+	const unsigned lane = threadIdx.x, sub = lane >> 4, sl = lane & 15u;
+	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
+		if (base + slot >= g.nid) continue;
+		const unsigned id = perm[base + slot];
+		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }      // nobody touched it since its verdict was taken: still clean
+		__syncthreads();
+		if (lane == 0) g.touch[id] = 0;
+		// ---- ListPositions: + list then - list, live nodes only (64 nodes per step where the list is a run of consecutive nodes)
+		unsigned n = 0;
+		for (unsigned s = 0; s < 2; s++) {
+			unsigned cur = g.head[s][id];
+			while (cur != BT_NONE) {
+				const bool inr = (unsigned long long)cur + lane < g.cap_n;
+				const unsigned nd = cur + lane;
+				const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
+				const unsigned dead = inr ? g.ndead[nd] : 1u;
+				const unsigned mj = inr ? nmark[nd] : 0u;
+				const unsigned long long cont = __ballot(inr && nxt == nd + 1);
+				const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;
+				const bool on = lane < pre && inr;
+				const unsigned long long lv = __ballot(on && !dead);
+				const unsigned off = n + __popcll(lv & ((1ull << lane) - 1ull));
+				if (on && !dead && off < SNAP_MAX_INST) s_inst[off] = (mj << 1) | s;
+				n += (unsigned)__popcll(lv);
+				cur = __shfl(nxt, pre - 1);
+			}
+		}
+		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
+		if (n > SNAP_MAX_INST) { if (lane == 0) g.need[id] = 1; continue; }
+		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+		__syncthreads();
+		bool found = false, undecided = false;
+		unsigned distinct = 0;
+		for (unsigned ib = 0; ib < n && !found && !undecided; ib += 4) {
+			const unsigned i = ib + sub;
+			const bool act = i < n;
+			const unsigned packed = act ? s_inst[i] : 0u, s = packed & 1u, j = packed >> 1;
+			const unsigned ax = act ? ms.aux[s][j] : 0u, pos = act ? ms.elem[s][j] : 0u;
+			const unsigned bit = ax >> 24, dist = ax & 0xFFFFFFu, lim = dist < g.D ? dist : g.D;
+			bool go = act && bit != 0;
+			for (unsigned t = 0; __any(go); t += 16) {
+				const unsigned off = t + sl;
+				const bool inr = go && (s == 0 ? (unsigned long long)j + 1 + off < ms.n[0] : off < j);
+				const unsigned jj = s == 0 ? j + 1 + off : j - 1 - off;
+				const unsigned p = inr ? ms.elem[s][jj] : 0u, b = inr ? ms.id[s][jj] : BT_NONE;
+				const unsigned step = s == 0 ? p - pos : pos - p;
+				const bool stop = !inr || step >= lim || b == id;
+				const unsigned long long bal = __ballot(stop);
+				const unsigned grp = (unsigned)(bal >> (sub * 16)) & 0xFFFFu;
+				const unsigned upto = grp ? (unsigned)__builtin_ctz(grp) : 16u;
+				const unsigned total = (unsigned)__popcll(__ballot(go && sl < upto));
+				if (distinct + total > (VT_SLOTS * 3) / 4) { undecided = true; break; }
+				bool fresh = false;
+				if (go && sl < upto) {
+					unsigned h = (b * 2654435761u) >> 23;
+					for (;;) {
+						unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
+						if (old == BT_NONE || old == b) {
+							fresh = old == BT_NONE;
+							unsigned m = atomicOr(&vt.mask[h], bit) | bit;
+							if (m & (m - 1)) found = true;
+							break;
+						}
+						h = (h + 1) & (VT_SLOTS - 1);
+					}
+				}
+				distinct += (unsigned)__popcll(__ballot(fresh));
+				if (__any(found)) { found = true; break; }
+				if (upto < 16) go = false;
+			}
+		}
+		if (lane == 0) g.need[id] = found ? 2 : undecided ? 1 : 0;
+	}
+}
+
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
 // lane 0 evaluates the Boost-ordered map on the cached marks).
 __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental, const unsigned *__restrict__ perm)
@@ -1478,6 +1626,7 @@ struct SimplifyState {
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel;
+	DevBuf lin, elin, lmpos[2], lmid[2], cnt1k, off1k;      // linearised marks of the later snapshots
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
 	unsigned *h_ctr = nullptr;            // pinned
 };
@@ -1493,6 +1642,7 @@ struct DeviceBackend {
 	size_t nres = 0;
 	hipEvent_t ev[8] = {};
 	bool timed_reserve = false, timed_commit = false, timed_probe = false;
+	bool later_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr && getenv("SBL_NO_LATER_STREAM") == nullptr;
 	bool first_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr;      // measurement switch: the generic window-walking snapshot for iteration 1 too
 	int prof = 0;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
@@ -1554,6 +1704,71 @@ struct DeviceBackend {
 		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, 8, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
+	// segment ranking of the current list (shared with the copy-back): returns the list length, leaves flag / segidx / seg_head / dist[cur] filled
+	unsigned long long rank_segments(unsigned ne, int *cur_out)
+	{
+		hipStream_t s = c->stream;
+		st->flag.ensure((size_t)ne * 4 + 16); st->segidx.ensure((size_t)ne * 4 + 16);
+		k_seg_flags<<<(ne + 255) / 256, 256, 0, s>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), ne, st->flag.as<unsigned>());
+		{
+			size_t tmp = 0;
+			HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st->flag.as<unsigned>(), st->segidx.as<unsigned>(), 0u, (size_t)ne + 1, rocprim::plus<unsigned>(), s));
+			st->scantmp.ensure(tmp);
+			HIP_TRY(rocprim::exclusive_scan(st->scantmp.p, tmp, st->flag.as<unsigned>(), st->segidx.as<unsigned>(), 0u, (size_t)ne + 1, rocprim::plus<unsigned>(), s));
+		}
+		unsigned nseg = 0;
+		HIP_TRY(hipMemcpyAsync(&nseg, st->segidx.as<unsigned>() + ne, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		SBL_CHECK(nseg >= 1, SBL_ERR_INTERNAL, "segment ranking: empty list");
+		st->seg_head.ensure((size_t)nseg * 4); st->seg_len.ensure((size_t)nseg * 4); st->seg_succ_elem.ensure((size_t)nseg * 4);
+		for (int t = 0; t < 2; t++) { st->succ[t].ensure((size_t)nseg * 4); st->dist[t].ensure((size_t)nseg * 8); }
+		k_seg_tails<<<(ne + 255) / 256, 256, 0, s>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), ne, st->flag.as<unsigned>(), st->segidx.as<unsigned>(),
+		                                            st->seg_head.as<unsigned>(), st->seg_len.as<unsigned>(), st->seg_succ_elem.as<unsigned>());
+		k_seg_finish<<<(nseg + 255) / 256, 256, 0, s>>>(nseg, st->seg_head.as<unsigned>(), st->seg_len.as<unsigned>(), st->seg_succ_elem.as<unsigned>(),
+		                                               st->flag.as<unsigned>(), st->segidx.as<unsigned>(), st->succ[0].as<unsigned>(), st->dist[0].as<unsigned long long>());
+		int cur = 0;
+		for (unsigned span = 1; span < nseg; span <<= 1, cur ^= 1)
+			k_seg_jump<<<(nseg + 255) / 256, 256, 0, s>>>(nseg, st->succ[cur].as<unsigned>(), st->dist[cur].as<unsigned long long>(),
+			                                             st->succ[cur ^ 1].as<unsigned>(), st->dist[cur ^ 1].as<unsigned long long>());
+		unsigned long long total = 0;                               // segment 0 starts with element 0, the head of the whole list
+		HIP_TRY(hipMemcpyAsync(&total, st->dist[cur].p, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		*cur_out = cur;
+		return total;
+	}
+	// marks of the current graph in list order (see k_lin_positions): fills ms
+	void linearise_marks(MarkStream &ms)
+	{
+		hipStream_t s = c->stream;
+		const unsigned ne = ck_ne;                                  // (checkpoint() has just read the counters)
+		int cur = 0;
+		const unsigned long long total = rank_segments(ne, &cur);
+		st->lin.ensure((size_t)ne * 4 + 16); st->elin.ensure((size_t)total * 4 + 16);
+		k_lin_positions<<<(ne + 255) / 256, 256, 0, s>>>(st->ch.as<uint8_t>(), ne, st->flag.as<unsigned>(), st->segidx.as<unsigned>(), st->seg_head.as<unsigned>(),
+		                                                st->dist[cur].as<unsigned long long>(), total, st->lin.as<unsigned>(), st->elin.as<unsigned>());
+		const unsigned nchunks = (unsigned)((total + 1023) / 1024);
+		st->cnt1k.ensure((size_t)(nchunks + 1) * 4); st->off1k.ensure((size_t)(nchunks + 1) * 4);
+		for (int t = 0; t < 2; t++) {
+			HIP_TRY(hipMemsetAsync(st->cnt1k.p, 0, (size_t)(nchunks + 1) * 4, s));
+			k_count_marks_lin<<<nchunks, 256, 0, s>>>(c->d_bif[t].as<unsigned>(), st->elin.as<unsigned>(), (size_t)total, st->cnt1k.as<unsigned>());
+			size_t tmp = 0;
+			HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st->cnt1k.as<unsigned>(), st->off1k.as<unsigned>(), 0u, (size_t)nchunks + 1, rocprim::plus<unsigned>(), s));
+			st->scantmp.ensure(tmp);
+			HIP_TRY(rocprim::exclusive_scan(st->scantmp.p, tmp, st->cnt1k.as<unsigned>(), st->off1k.as<unsigned>(), 0u, (size_t)nchunks + 1, rocprim::plus<unsigned>(), s));
+			unsigned nm = 0;
+			HIP_TRY(hipMemcpyAsync(&nm, st->off1k.as<unsigned>() + nchunks, 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			st->lmpos[t].ensure((size_t)nm * 4 + 16); st->lmid[t].ensure((size_t)nm * 4 + 16); st->maux[t].ensure((size_t)nm * 4 + 16);
+			if (nm) {
+				k_write_marks_lin<<<nchunks, 256, 0, s>>>(c->d_bif[t].as<unsigned>(), st->elin.as<unsigned>(), st->nodeof[t].as<unsigned>(), (size_t)total, st->off1k.as<unsigned>(),
+				                                         st->lmpos[t].as<unsigned>(), st->lmid[t].as<unsigned>(), st->nmark.as<unsigned>());
+				k_mark_aux_lin<<<(nm + 255) / 256, 256, 0, s>>>(st->lmpos[t].as<unsigned>(), nm, (unsigned)t, c->d_sepidx.as<unsigned>(), c->nchr, st->lin.as<unsigned>(),
+				                                               st->elin.as<unsigned>(), st->ch.as<uint8_t>(), g.k, st->maux[t].as<unsigned>());
+			}
+			ms.elem[t] = st->lmpos[t].as<unsigned>(); ms.id[t] = st->lmid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = nm;
+		}
+		HIP_TRY(hipGetLastError());
+	}
 	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
@@ -1564,6 +1779,12 @@ struct DeviceBackend {
 			for (int t = 0; t < 2; t++) { ms.elem[t] = c->d_melem[t].as<unsigned>(); ms.id[t] = c->d_mid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = c->nmarks[t]; }
 			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
 			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>());
+		} else if (incremental && later_stream) {
+			// iterations 2 ..: the same stream over the marks of the current graph in list order
+			st->nmark.ensure((size_t)cap_n * 4);
+			MarkStream ms;
+			linearise_marks(ms);
+			k_snapshot_stream<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), 1);
 		} else
 		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>());
 		HIP_TRY(hipEventRecord(ev[7], c->stream));
@@ -1691,7 +1912,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
-	                   &st->sel, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
