@@ -114,6 +114,16 @@ uint32_t sbl_nchr(const sbl_ctx *ctx);
  * observation channel behind SerializeCondensedGraph (src/serialization.cpp:88-110). */
 sbl_status sbl_list_edges(sbl_ctx *ctx, uint32_t k, const sbl_edge **edges, uint64_t *n);
 
+/* Downstream of the hot path: replaces BlockFinder::GenerateSyntenyBlocks (src/synteny.cpp:229-286, with
+ * ResolveOverlap :124-166 and TrimBlocks :31-122; src/blockfinder.h:43) on the current state.  Both indices it needs -- the edge
+ * list at k and, per candidate block, a fresh index at trim_k over the block's ORIGINAL sequences (kept on the device since
+ * sbl_load / sbl_load_fasta) -- are built by the enumeration kernels; rand() is consumed exactly as the reference does.
+ * sbl_block = BlockInstance (src/blockinstance.h:21-47): signed block id (sign = strand), chromosome, [start, end) in original
+ * coordinates; sorted by (chr, start) like the reference's result.  Owned by the ctx, valid until the next call. */
+typedef struct { int32_t id; uint32_t chr; uint64_t start, end; } sbl_block;
+sbl_status sbl_generate_blocks(sbl_ctx *ctx, uint32_t k, uint32_t trim_k, uint32_t min_size, int shared_only,
+                               const sbl_block **blocks, uint64_t *n);
+
 /* H0: the k-mer hash of the reference's hashing.h (SlidingWindow / KMerHashFunction, src/hashing.h:14-112; HASH_BASE 57,
  * arithmetic mod 2^64) for every k-mer of the current state: strand 0 then strand 1 (complemented characters, walk order),
  * chromosomes ascending.  The reference's production path never executes it; provided with a known-answer test.

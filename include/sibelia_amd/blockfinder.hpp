@@ -1,7 +1,9 @@
 // blockfinder.hpp -- the reference's BlockFinder class surface on top of the C ABI (include/sibelia_amd.h).
 //
 // Mirrors SyntenyFinder::BlockFinder's public section (reference src/blockfinder.h:28-45) for the hot path:
-// same constructors (a FASTARecord only needs GetSequence()), same method names, argument order and meaning.
+// same constructors (a FASTARecord only needs GetSequence()), same method names, argument order and meaning:
+// PerformGraphSimplifications, GenerateSyntenyBlocks, SerializeCondensedGraph (SerializeGraph, a debugging dump of the
+// uncondensed graph that main never calls with production options, is not provided).
 // Header-only; link with -lsibelia_amd.  Errors that the reference cannot produce (no device, OOM, input
 // beyond the 29-bit limits) are thrown as std::runtime_error, the only exception type the reference itself throws
 // (src/platform.cpp:40,79,118,126).
@@ -19,6 +21,24 @@
 
 namespace SyntenyFinderAMD
 {
+	// BlockInstance (reference src/blockinstance.h:21-47): signed block id (sign = strand), chromosome, [start, end) in original coordinates
+	struct BlockInstance
+	{
+		int id; size_t chr, start, end;
+		int GetSignedBlockId() const { return id; }
+		int GetBlockId() const { return id < 0 ? -id : id; }
+		int GetSign() const { return id > 0 ? +1 : -1; }
+		size_t GetChrId() const { return chr; }
+		size_t GetStart() const { return start; }
+		size_t GetEnd() const { return end; }
+		size_t GetLength() const { return end - start; }
+		size_t GetConventionalStart() const { return id > 0 ? start + 1 : end; }      // blockinstance.cpp:57-75
+		size_t GetConventionalEnd() const { return id > 0 ? end : start + 1; }
+		bool operator<(const BlockInstance &o) const { return chr != o.chr ? chr < o.chr : start < o.start; }
+	};
+
+	struct FromFasta { std::string path; };     // BlockFinder(FromFasta{"genomes.fasta"}): FASTAReader + Init on the device (sbl_load_fasta)
+
 	class BlockFinder
 	{
 	public:
@@ -29,7 +49,16 @@ namespace SyntenyFinderAMD
 		explicit BlockFinder(const FASTARecordVector &chrList, int device = -1) { Init(chrList, device); }
 		template <class FASTARecordVector>
 		BlockFinder(const FASTARecordVector &chrList, const std::string & /*tempDir: nothing is spilled*/, int device = -1) { Init(chrList, device); }
+		explicit BlockFinder(const FromFasta &f, int device = -1)
+		{
+			sbl_status st = sbl_create(&ctx_, device);
+			if (st != SBL_OK) throw std::runtime_error(std::string("sibelia_amd: ") + sbl_strerror(st));
+			try { Check(sbl_load_fasta(ctx_, f.path.c_str()), "FASTAReader"); }
+			catch (...) { sbl_destroy(ctx_); ctx_ = nullptr; throw; }
+		}
 		~BlockFinder() { sbl_destroy(ctx_); }
+		size_t ChrNumber() const { return sbl_nchr(ctx_); }
+		std::string Description(size_t chr) const { return sbl_record_name(ctx_, (uint32_t)chr); }      // FASTARecord::GetDescription
 		BlockFinder(const BlockFinder &) = delete;
 		BlockFinder &operator=(const BlockFinder &) = delete;
 
@@ -43,6 +72,16 @@ namespace SyntenyFinderAMD
 			if (box.thrown) std::rethrow_exception(box.thrown);      // a throwing callback never unwinds through the C ABI: the stage completes first
 			Check(st, "PerformGraphSimplifications");
 			return (size_t)bulges;
+		}
+
+		// synteny.cpp:229-286 (blockfinder.h:43)
+		void GenerateSyntenyBlocks(size_t k, size_t trimK, size_t minSize, std::vector<BlockInstance> &block, bool sharedOnly = false, ProgressCallBack = ProgressCallBack())
+		{
+			const sbl_block *b = nullptr;
+			uint64_t n = 0;
+			Check(sbl_generate_blocks(ctx_, (uint32_t)k, (uint32_t)trimK, (uint32_t)minSize, sharedOnly ? 1 : 0, &b, &n), "GenerateSyntenyBlocks");
+			block.clear();
+			for (uint64_t i = 0; i < n; i++) block.push_back(BlockInstance{b[i].id, b[i].chr, (size_t)b[i].start, (size_t)b[i].end});
 		}
 
 		// serialization.cpp:88-110 (same text, byte for byte)

@@ -16,15 +16,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsibelia_oracle.so")
 SRC = os.path.join(HERE, "sibelia_oracle.c")
 
+BLOCK_DTYPE = np.dtype([("id", "<i4"), ("chr", "<u4"), ("start", "<u8"), ("end", "<u8")])
 INST_DTYPE = np.dtype([("id", "<u4"), ("chr", "<u4"), ("pos", "<u4")])
 EDGE_DTYPE = np.dtype([("chr", "<u4"), ("strand", "<u4"), ("start_vertex", "<u4"), ("end_vertex", "<u4"),
                        ("pos", "<u4"), ("len", "<u4"), ("orig_pos", "<u4"), ("orig_len", "<u4"),
                        ("first_char", "S1"), ("_pad", "V3")])
 
 
+SRC_CPP = os.path.join(HERE, "synteny_oracle.cpp")
+
+
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", LIB, SRC], check=True)
+    srcs = [SRC, SRC_CPP, os.path.join(HERE, "sibelia_oracle.h")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(x) for x in srcs):
+        obj = os.path.join(HERE, "sibelia_oracle.o")
+        subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-c", "-o", obj, SRC], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-o", LIB, SRC_CPP, obj], check=True)
+        os.remove(obj)
     return LIB
 
 
@@ -47,6 +55,8 @@ def lib():
         L.orc_nchr.argtypes = [C.c_void_p]
         L.orc_nchr.restype = C.c_uint32
         L.orc_list_edges.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_generate_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_force_long_k_path.argtypes = [C.c_void_p, C.c_int]
@@ -76,6 +86,7 @@ class Oracle:
         arr = (C.c_char_p * n)(*[bytes(s) for s in seqs])
         lens = (C.c_uint64 * n)(*[len(s) for s in seqs])
         self.L.orc_load(self.h, n, arr, lens)
+        self._orig = [bytes(s) for s in seqs]           # originalChrList_ (GenerateSyntenyBlocks trims on the original sequences)
 
     def close(self):
         if self.h:
@@ -125,6 +136,18 @@ class Oracle:
         if rc:
             raise ValueError("orc_list_edges failed: %d" % rc)
         return _view(e.value, n.value, EDGE_DTYPE)
+
+    def generate_blocks(self, k: int, trim_k: int, min_size: int, shared_only: bool = False) -> np.ndarray:
+        n = len(self._orig)
+        arr = (C.c_char_p * n)(*self._orig)
+        lens = (C.c_uint64 * n)(*[len(s) for s in self._orig])
+        v, m = C.c_void_p(), C.c_uint64()
+        rc = self.L.orc_generate_blocks(self.h, arr, lens, k, trim_k, min_size, int(shared_only), C.byref(v), C.byref(m))
+        if rc:
+            raise ValueError("orc_generate_blocks failed: %d" % rc)
+        a = _view(v.value, m.value, BLOCK_DTYPE)
+        self.L.orc_free(v)
+        return a
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         v, n = C.c_void_p(), C.c_uint64()

@@ -9,7 +9,7 @@
 // into flat binary files that make_golden.py turns into committed fixtures.
 //
 // usage: ref_dump <in.fasta> <out-prefix> <cmd>...
-//   cmd = state | hash:K | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+//   cmd = state | hash:K | blocks:K:TRIMK:MINSIZE:SHARED | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
 #include "common.h"
 #include "fasta.h"
 #include "dnasequence.h"
@@ -117,7 +117,7 @@ int main(int argc, char **argv)
 	BlockFinder finder(chrList);
 	for(int a = 3; a < argc; a++)
 	{
-		unsigned k = 0, d = 0, it = 0;
+		unsigned k = 0, d = 0, it = 0, sh = 0;
 		char buf[64]; sprintf(buf, ".%d.out", a - 3);      // one output file per command, in order
 		if(sscanf(argv[a], "enum:%u", &k) == 1)
 		{
@@ -144,6 +144,26 @@ int main(int argc, char **argv)
 			FILE *f = fopen((prefix + buf + ".names").c_str(), "wb");
 			for(size_t i = 0; i < chrList.size(); i++) fprintf(f, "%s\n", chrList[i].GetDescription().c_str());
 			fclose(f);
+		}
+		else if(sscanf(argv[a], "blocks:%u:%u:%u:%u", &k, &d, &it, &sh) == 4)
+		{
+			// N2: BlockFinder::GenerateSyntenyBlocks(k, trimK, minSize, block, sharedOnly) (src/synteny.cpp:229-286);
+			// per BlockInstance, in output order: i32 signed block id | u32 chr | u64 start | u64 end
+			std::vector<BlockInstance> block;
+			struct timespec t0, t1;
+			clock_gettime(CLOCK_MONOTONIC, &t0);
+			finder.GenerateSyntenyBlocks(k, d, it, block, sh != 0);
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			FILE *f = fopen((prefix + buf).c_str(), "wb");
+			put64(f, block.size());
+			for(size_t i = 0; i < block.size(); i++)
+			{
+				put32(f, (uint32_t)block[i].GetSignedBlockId()); put32(f, (uint32_t)block[i].GetChrId());
+				put64(f, block[i].GetStart()); put64(f, block[i].GetEnd());
+			}
+			fclose(f);
+			fprintf(stderr, "blocks k=%u trimK=%u minSize=%u shared=%u -> %zu instances seconds=%.6f\n", k, d, it, sh, block.size(),
+			        (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
 		}
 		else if(sscanf(argv[a], "dot:%u", &k) == 1)
 		{

@@ -134,6 +134,7 @@ void orc_destroy(orc_ctx *c)
 uint32_t orc_nchr(const orc_ctx *c) { return c->nchr; }
 void orc_force_long_k_path(orc_ctx *c, int on) { c->force_long = on; }
 uint32_t orc_rand(orc_ctx *c) { return grand_next(&c->rng); }
+void orc_rng_copy(orc_ctx *dst, const orc_ctx *src) { dst->rng = src->rng; }
 void orc_last_timing(const orc_ctx *c, double *e, double *s, double *b)
 { if (e) *e = c->t_enum; if (s) *s = c->t_simp; if (b) *b = c->t_copy; }
 

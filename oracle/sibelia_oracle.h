@@ -66,6 +66,13 @@ int orc_list_edges(orc_ctx *c, uint32_t k, const orc_edge **edges, uint64_t *n);
 int orc_kmer_hashes(orc_ctx *c, uint32_t k, uint64_t **out, uint64_t *n);
 void orc_free(void *p);
 
+/* N2: BlockFinder::GenerateSyntenyBlocks (src/synteny.cpp:229-286; synteny_oracle.cpp).  orig_seq / orig_len: the records the
+ * BlockFinder was built from (originalChrList_).  out: malloc'd (orc_free), sorted like the reference's result. */
+typedef struct { int32_t id; uint32_t chr; uint64_t start, end; } orc_block;      /* BlockInstance: signed block id, chr, [start, end) */
+int orc_generate_blocks(orc_ctx *c, const uint8_t *const *orig_seq, const uint64_t *orig_len, uint32_t k, uint32_t trimK, uint32_t minSize,
+                        int sharedOnly, orc_block **out, uint64_t *n);
+void orc_rng_copy(orc_ctx *dst, const orc_ctx *src);   /* a child index shares the parent's rand() stream */
+
 /* test hooks */
 void orc_force_long_k_path(orc_ctx *c, int on);      /* use the rank-doubling grouping even for k <= 32 */
 uint32_t orc_rand(orc_ctx *c);                       /* next value of the ctx's glibc rand() stream   */

@@ -23,7 +23,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
-           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes"]
+           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks"]
 
 
 class StageStats(C.Structure):
@@ -76,6 +76,7 @@ def load_library():
         L.sbl_load_fasta.argtypes = [C.c_void_p, C.c_char_p]
         L.sbl_record_name.argtypes = [C.c_void_p, C.c_uint32]
         L.sbl_record_name.restype = C.c_char_p
+        L.sbl_generate_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_comm_unique_id.argtypes = [C.c_void_p]
         L.sbl_comm_attach_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -174,6 +175,14 @@ class BlockFinder:
         e, n = C.c_void_p(), C.c_uint64()
         self._check(self.L.sbl_list_edges(self.h, k, C.byref(e), C.byref(n)), "sbl_list_edges")
         return _view(e.value, n.value, EDGE_DTYPE)
+
+    def GenerateSyntenyBlocks(self, k: int, trimK: int, minSize: int, sharedOnly: bool = False) -> np.ndarray:
+        """BlockFinder::GenerateSyntenyBlocks (reference src/blockfinder.h:43): BlockInstance records (id, chr, start, end)."""
+        b, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.sbl_generate_blocks(self.h, k, trimK, minSize, int(sharedOnly), C.byref(b), C.byref(n)), "sbl_generate_blocks")
+        return _view(b.value, n.value, formats.BLOCK_DTYPE)
+
+    generate_blocks = GenerateSyntenyBlocks
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         """H0: hashes of the reference's hashing.h for every k-mer, strand 0 then 1, chromosomes ascending, walk order."""

@@ -195,6 +195,11 @@ void sbl_finish_load(sbl_ctx *c)
 		HIP_TRY(hipStreamSynchronize(s));
 	}
 	c->host_state_valid = false;
+	// keep the records as loaded: the synteny stage trims on them
+	c->d_orig_ch.ensure(E + 64);
+	HIP_TRY(hipMemcpyAsync(c->d_orig_ch.p, c->d_ch.p, E, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	c->orig_sepidx = c->sepidx;
 }
 
 namespace {

@@ -289,12 +289,13 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
+	if (c->child) { sbl_destroy(c->child); c->child = nullptr; }
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);
 	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs, &c->d_orig_ch };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);

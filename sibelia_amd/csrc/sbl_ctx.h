@@ -23,6 +23,11 @@ struct sbl_ctx {
 	DevBuf d_fa_text, d_fa_lines, d_fa_recs;   // sbl_load_fasta: file text, per-line and per-record tables
 	std::vector<std::string> fa_names;   // record descriptions of the last sbl_load_fasta
 
+	// the records as loaded (originalChrList_): GenerateSyntenyBlocks trims blocks on the ORIGINAL sequences (src/synteny.cpp:36-40)
+	DevBuf d_orig_ch;
+	std::vector<uint32_t> orig_sepidx;
+	sbl_ctx *child = nullptr;            // index over block sequences (TrimBlocks), same device
+
 	// stage-boundary checkpoint (sbl_save_state / sbl_restore_state)
 	DevBuf d_save_ch, d_save_op;
 	size_t save_nelem = 0;
@@ -58,6 +63,7 @@ struct sbl_ctx {
 	std::vector<sbl_inst> inst[2];
 	std::vector<sbl_edge> edges;
 	std::vector<uint64_t> h_hashes;
+	std::vector<sbl_block> blocks;
 
 	// ---- multi-GPU enumeration (shard.hip): attached communicator + exchange buffers
 	struct SblComm *comm = nullptr;

@@ -98,6 +98,15 @@ class LocalShardedFinder:
         assert all(np.array_equal(x, res[0]) for x in res), "ranks disagree"
         return res[0]
 
+    def generate_blocks(self, k, trim_k, min_size, shared_only=False):
+        import numpy as np
+        res = self._all("generate_blocks", k, trim_k, min_size, shared_only)
+        assert all(np.array_equal(x, res[0]) for x in res), "ranks disagree"
+        return res[0]
+
+    def kmer_hashes(self, k):
+        return self.ranks[0].kmer_hashes(k)
+
     def stats(self):
         return [bf.stats() for bf in self.ranks]
 

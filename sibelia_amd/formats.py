@@ -6,6 +6,7 @@ so that sha256(serialise(result)) can be compared with tests/golden/vectors.json
   enum   u32 bif_count | for strand in (+,-): u64 n, n x (u32 id, u32 chr, u32 pos) in (chr,pos) order
   state  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
   dot    text of BlockFinder::SerializeCondensedGraph (reference src/serialization.cpp:88-110)
+  blocks u64 n | n x (i32 signed block id, u32 chr, u64 start, u64 end): BlockFinder::GenerateSyntenyBlocks' result, in its order
   hash   for strand in (+,-), per chromosome: u64 n, n x u64 k-mer hashes of the reference's hashing.h in walk order
 """
 from __future__ import annotations
@@ -34,6 +35,14 @@ def state_bytes(bulges: int, seqs: Sequence[bytes], opos: Sequence[np.ndarray]) 
         out.append(bytes(s))
         out.append(np.ascontiguousarray(p, dtype="<u4").tobytes())
     return b"".join(out)
+
+
+BLOCK_DTYPE = np.dtype([("id", "<i4"), ("chr", "<u4"), ("start", "<u8"), ("end", "<u8")])
+
+
+def blocks_bytes(blocks: np.ndarray) -> bytes:
+    b = np.ascontiguousarray(blocks, dtype=BLOCK_DTYPE)
+    return struct.pack("<Q", len(b)) + b.tobytes()
 
 
 def hash_bytes(values: np.ndarray, lens: Sequence[int], k: int) -> bytes:

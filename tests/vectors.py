@@ -5,6 +5,7 @@ A backend is any object with the reference-shaped surface
     simplify_stage(k, min_branch, max_iter) -> bulges
     state() -> (list[bytes], list[np.ndarray uint32])
     list_edges(k) -> structured edge array
+    generate_blocks(k, trim_k, min_size, shared_only) -> structured block array (N2, reference src/synteny.cpp)
     kmer_hashes(k) -> flat uint64 array (H0, reference src/hashing.h)
 """
 from __future__ import annotations
@@ -56,6 +57,8 @@ def run_cmd(backend, cmd: str) -> bytes:
         bulges = backend.simplify_stage(int(p[1]), int(p[2]), int(p[3]))
         seqs, opos = backend.state()
         return F.state_bytes(bulges, seqs, opos)
+    if p[0] == "blocks":
+        return F.blocks_bytes(backend.generate_blocks(int(p[1]), int(p[2]), int(p[3]), bool(int(p[4]))))
     if p[0] == "hash":
         k = int(p[1])
         return F.hash_bytes(backend.kmer_hashes(k), [len(x) for x in backend.state()[0]], k)
