@@ -121,6 +121,7 @@ struct Synteny {
 	// closest to its two ends; a sequence sharing none makes the caller try again without it
 	bool trim_blocks(std::vector<BEdge> &block)
 	{
+		if (block.empty()) return false;                         // (an index over no sequences: nothing to trim, nothing dropped, no rand() drawn)
 		uint32_t bifCount = 0; const sbl_inst *inst[2]; uint64_t ninst[2];
 		child_index(block, &bifCount, inst, ninst);
 		const size_t nrec = block.size();
