@@ -30,16 +30,17 @@ __device__ __host__ __forceinline__ unsigned long long kmer_unhash(unsigned long
 // AA..A = 0 is smaller; for k < 32 it is not a code at all) and mix64 is a bijection, so no valid record carries this key.
 #define KB_EMPTY_KEY 0x64b5720b4b825f21ull
 #define KB_INVALID 0xFFFFFFFFFFFFFFFFull       // value of a position whose k-window holds a separator (or lies beyond the input)
-// value layout: bits 0-31 element index g | bits 32-44 mask (canonical orientation, as KmerSlot::mask) | bit 48 fwd <= rev | bit 49 rev <= fwd
+// value layout: bits 0-31 element index g | bits 32-44 mask in canonical orientation (bits 0-4: prev {A,C,G,T,#}, bits 8-12: next) | bit 48 fwd <= rev | bit 49 rev <= fwd
 
 // B1: one record per element index of the tile (invalid positions get KB_INVALID), coalesced 8-B stores.
 static __global__ void __launch_bounds__(KM_THREADS) k_kmer_records(const unsigned long long *__restrict__ pk, const unsigned *__restrict__ sp,
-                                                             size_t nwords, size_t nelem, unsigned k, size_t ntiles,
+                                                             size_t nwords, size_t nelem, unsigned k, size_t tile_begin, size_t tile_end /* this GPU's slice of tiles */,
                                                              unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals)
 {
 	__shared__ KmerTile t;
 	const unsigned long long kshift = 64 - 2 * k;
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	const size_t out0 = tile_begin * (size_t)(KM_TILE_WORDS * 32);      // records are stored relative to the slice
+	for (size_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
 		__syncthreads();
 		tile_load(t, pk, sp, tile, nwords);
 		__syncthreads();
@@ -66,8 +67,8 @@ static __global__ void __launch_bounds__(KM_THREADS) k_kmer_records(const unsign
 				key = kmer_hash(fwd < rev ? fwd : rev);
 				val = (unsigned long long)(unsigned)g | ((unsigned long long)m << 32) | ((unsigned long long)fl << 48);
 			}
-			keys[g] = key;
-			vals[g] = val;
+			keys[g - out0] = key;
+			vals[g - out0] = val;
 		}
 	}
 }
@@ -193,4 +194,30 @@ static __global__ void __launch_bounds__(256) k_scatter_members(const unsigned l
 	const unsigned g = (unsigned)m, p = (unsigned)(m >> 32);
 	bif0[g] = pairids[p];
 	bif1[g + k - 1] = pairids[p ^ 1u];
+}
+
+// ---- multi-GPU pieces (shard.hip): owner of bucket b among R ranks = (b * R) >> bits (contiguous bucket ranges)
+// rank of the owner's own bifurcation codes in the globally sorted list = id; pairids[payload] as k_scatter_ids leaves it
+static __global__ void __launch_bounds__(256) k_rank_own_keys(const unsigned long long *__restrict__ mykeys, const unsigned *__restrict__ mypayload, unsigned nmine,
+                                                       const unsigned long long *__restrict__ allsorted, unsigned nall, unsigned k, unsigned *__restrict__ pairids)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nmine) return;
+	const unsigned long long key = mykeys[i];
+	unsigned lo = 0, hi = nall;
+	while (lo < hi) { unsigned mid = (lo + hi) >> 1; if (allsorted[mid] < key) lo = mid + 1; else hi = mid; }
+	const unsigned p = mypayload[i];
+	pairids[p] = lo;
+	if (!(p & 1) && rc_code(key, k) == key) pairids[p + 1] = lo;      // palindrome: one vertex for both orientations
+}
+// member positions of the owner's buckets -> the two marks each of them sets (what k_scatter_members writes locally)
+static __global__ void __launch_bounds__(256) k_member_marks(const unsigned long long *__restrict__ members, unsigned n, unsigned k, const unsigned *__restrict__ pairids,
+                                                      unsigned *__restrict__ elem0, unsigned *__restrict__ id0, unsigned *__restrict__ elem1, unsigned *__restrict__ id1)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long m = members[i];
+	const unsigned g = (unsigned)m, p = (unsigned)(m >> 32);
+	elem0[i] = g; id0[i] = pairids[p];
+	elem1[i] = g + k - 1; id1[i] = pairids[p ^ 1u];
 }

@@ -179,7 +179,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 
 	HIP_TRY(hipEventRecord(c->ev[0], s));
 	const unsigned grid = (unsigned)std::min<size_t>(ntiles, 256 * 16);
-	k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, ntiles, k0, v0);
+	k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, (size_t)0, ntiles, k0, v0);
 	HIP_TRY(hipGetLastError());
 
 	// buckets of ~350-700 records (an LDS table holds KB_MAX_DISTINCT distinct k-mers); more bits if a bucket overflows
@@ -193,7 +193,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		if (attempt == 0 || (cnt[3] & 1u)) {
 			if (attempt) {                                       // re-bucket with a longer prefix: the records have to be generated again (k0 was reused)
 				bits = std::min(bits + 2, 40u);
-				k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, ntiles, k0, v0);
+				k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, (size_t)0, ntiles, k0, v0);
 			}
 			device_sort_records(c, k0, k1, v0, v1, n, 0, bits);
 			c->d_boff.ensure((((size_t)1 << bits) + 1) * 4 + 64);
@@ -293,9 +293,9 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);
-	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_table, &c->d_counters,
+	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
-	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_usedslots, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs, &c->d_orig_ch };
+	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs, &c->d_orig_ch };
 	for (DevBuf *b : bufs) b->release();
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);

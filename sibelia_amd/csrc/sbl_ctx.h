@@ -45,9 +45,6 @@ struct sbl_ctx {
 	DevBuf d_pk, d_sp;                   // packed bases / separator bits
 	DevBuf d_rec_keys[2], d_rec_vals[2]; // k-mer records {mix64(canonical code), element | masks}: position order / partitioned by hash prefix
 	DevBuf d_boff;                       // bucket offsets (2^bits + 1)
-	DevBuf d_table;                      // KmerSlot[cap] (sharded path: local pre-aggregation / owner table)
-	DevBuf d_usedslots;                  // uint32 [positions]: slots claimed by the table build, in claim order
-	size_t table_cap = 0;
 	DevBuf d_counters;                   // small uint32 scratch block
 	DevBuf d_keys, d_payload, d_skeys, d_spayload, d_pairids, d_sorttmp;
 	DevBuf d_bif[2];                     // dense marks, uint32 [element capacity]

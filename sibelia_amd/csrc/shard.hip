@@ -30,6 +30,7 @@
 
 #include "sbl_ctx.h"
 #include "kmer_kernels.h"
+#include "kmer_bucket_kernels.h"
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
@@ -318,123 +319,137 @@ void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 }
 static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
+	// The radix-bucketed table of the single-GPU path (kmer_bucket_kernels.h), cut along its hash prefix:
+	//   A  every GPU turns ITS slice of tiles into k-mer records and partitions them by the low `bits` bits of the mixed key;
+	//      bucket b belongs to rank (b * R) >> bits, so what goes to one owner is one contiguous range of the partitioned array
+	//   B  ONE all-to-all of the 16-B records (keys, then values): grouped ncclSend / ncclRecv, one message per peer and array
+	//   C  owners partition what they received again, build the per-bucket LDS tables, classify: bifurcation codes + member positions
+	//   D  all-gather of the bifurcation codes, sorted identically everywhere: rank = id
+	//   E  owners turn their member positions into (element, id) marks, all-gather, everybody scatters them into the dense arrays
+	// Slices hold the same number of positions and buckets the same number of k-mers whatever the input: balanced by construction.
 	SblComm *cm = c->comm;
 	const uint32_t R = cm->n, r = cm->rank;
 	hipStream_t s = c->stream;
 	Clock clk;
 	c->stats.exchange_bytes = 0;
-	size_t E = c->nelem, nwords = (E + 31) / 32;
-	size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
-	size_t t0 = ntiles * r / R, t1 = ntiles * (r + 1) / R;
+	const size_t E = c->nelem, nwords = (E + 31) / 32;
+	const size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
+	const size_t t0 = ntiles * r / R, t1 = ntiles * (r + 1) / R;
+	const size_t nall = ntiles * (size_t)(KM_TILE_WORDS * 32), nmine = (t1 - t0) * (size_t)(KM_TILE_WORDS * 32);
+	SBL_CHECK(nall < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many positions for 32-bit record indices");
 	c->cur_k = k;
 	sbl_pack(c);
-
-	// ---- A: local pre-aggregation of this GPU's slice
-	size_t slice = (t1 - t0) * (size_t)(KM_TILE_WORDS * 32);
-	size_t cap = 1024;
-	while (cap < slice + slice / 2) cap <<= 1;
-	SBL_CHECK(cap <= 0xFFFFFFFFull, SBL_ERR_TOO_LARGE, "k-mer table too large for 32-bit slot indices");
-	c->d_usedslots.ensure(slice * 4 + 64);
-	c->d_table.ensure(cap * sizeof(KmerSlot));
-	c->table_cap = cap;
 	c->d_counters.ensure(256 * 4);
-	unsigned *ctr = c->d_counters.as<unsigned>();      // [0..1] classify, [8] used (scan), [9] used (owner), [64..127] counts, [128..191] cursors
-	k_table_init<<<(unsigned)std::min<size_t>((cap + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_table.as<KmerSlot>(), cap);
-	HIP_TRY(hipMemsetAsync(ctr, 0, 256 * 4, s));
-	unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(t1 - t0, 256 * 8));
-	HIP_TRY(hipEventRecord(c->ev[0], s));
-	if (t1 > t0)
-		k_kmer_table_build<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-		                                               c->d_table.as<KmerSlot>(), (unsigned long long)cap - 1, t0, t1, ctr + 8, c->d_usedslots.as<unsigned>());
-	HIP_TRY(hipEventRecord(c->ev[1], s));
-	HIP_TRY(hipGetLastError());
-	unsigned nused = 0;
-	HIP_TRY(hipMemcpyAsync(&nused, ctr + 8, 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-
-	// ---- B: bucket by owner (hash prefix) and exchange
-	unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)nused + 255) / 256, 256 * 16));
-	std::vector<unsigned> cnt(R, 0), off(R, 0);
-	if (nused) k_shard_count<<<pgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, R, ctr + 64);
-	HIP_TRY(hipMemcpyAsync(cnt.data(), ctr + 64, R * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	for (uint32_t p = 1; p < R; p++) off[p] = off[p - 1] + cnt[p - 1];
-	HIP_TRY(hipMemcpyAsync(ctr + 192, off.data(), R * 4, hipMemcpyHostToDevice, s));
-	c->d_send.ensure((size_t)nused * sizeof(KmerRecord) + 16);
-	if (nused) k_shard_scatter<<<pgrid, 256, 0, s>>>(c->d_table.as<KmerSlot>(), c->d_usedslots.as<unsigned>(), nused, R, ctr + 192, ctr + 128,
-	                                                  c->d_send.as<KmerRecord>());
-	HIP_TRY(hipGetLastError());
-	std::vector<unsigned long long> scount(R), allcount((size_t)R * R);
-	for (uint32_t p = 0; p < R; p++) scount[p] = cnt[p];
-	clk.time([&] { cm->allgather_host(c, scount.data(), R * 8, allcount.data()); });
-	std::vector<size_t> sb(R), so(R), rb(R), ro(R);
+	unsigned *ctr = c->d_counters.as<unsigned>();
+	unsigned bits = 4;
+	while (bits < 30 && (nall >> bits) > 700) bits++;              // the same on every rank: buckets are sized by the WHOLE input
+	size_t maxpairs = nall / R / 8 + 4096;
+	unsigned cnt[4] = {0, 0, 0, 0};
 	size_t nrecv = 0;
-	for (uint32_t p = 0; p < R; p++) {
-		sb[p] = (size_t)cnt[p] * sizeof(KmerRecord); so[p] = (size_t)off[p] * sizeof(KmerRecord);
-		size_t m = allcount[(size_t)p * R + r];
-		rb[p] = m * sizeof(KmerRecord); ro[p] = nrecv * sizeof(KmerRecord);
-		nrecv += m;
-		if (p != r) c->stats.exchange_bytes += sb[p];
+	HIP_TRY(hipEventRecord(c->ev[0], s));
+	for (int attempt = 0;; attempt++) {
+		SBL_CHECK(attempt < 8, SBL_ERR_INTERNAL, "k-mer bucket classification did not converge");
+		const size_t nb = (size_t)1 << bits;
+		// ---- A: records of my slice, partitioned by hash prefix
+		for (int i = 0; i < 2; i++) { c->d_rec_keys[i].ensure(nmine * 8 + 16); c->d_rec_vals[i].ensure(nmine * 8 + 16); }
+		c->d_boff.ensure((nb + 1) * 4 + 64);
+		std::vector<unsigned> fb(R + 1), send_at(R + 1, 0);
+		for (uint32_t p = 0; p <= R; p++) fb[p] = (unsigned)(((unsigned long long)p * nb + R - 1) / R);      // first bucket of owner p
+		if (nmine) {
+			k_kmer_records<<<(unsigned)std::min<size_t>(t1 - t0, 256 * 16), KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, t0, t1,
+			                                                                                  c->d_rec_keys[0].as<unsigned long long>(), c->d_rec_vals[0].as<unsigned long long>());
+			size_t tmp = 0;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rec_keys[0].as<unsigned long long>(), c->d_rec_keys[1].as<unsigned long long>(),
+			                                  c->d_rec_vals[0].as<unsigned long long>(), c->d_rec_vals[1].as<unsigned long long>(), nmine, 0, bits, s));
+			c->d_sorttmp.ensure(tmp);
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp, c->d_rec_keys[0].as<unsigned long long>(), c->d_rec_keys[1].as<unsigned long long>(),
+			                                  c->d_rec_vals[0].as<unsigned long long>(), c->d_rec_vals[1].as<unsigned long long>(), nmine, 0, bits, s));
+			k_bucket_bounds<<<nblocks(nb + 1, 256), 256, 0, s>>>(c->d_rec_keys[1].as<unsigned long long>(), nmine, bits, c->d_boff.as<unsigned>());
+			HIP_TRY(hipGetLastError());
+			for (uint32_t p = 0; p <= R; p++) HIP_TRY(hipMemcpyAsync(&send_at[p], c->d_boff.as<unsigned>() + fb[p], 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+		}
+		// ---- B: the exchange
+		std::vector<unsigned long long> scount(R), allcount((size_t)R * R);
+		for (uint32_t p = 0; p < R; p++) scount[p] = send_at[p + 1] - send_at[p];
+		clk.time([&] { cm->allgather_host(c, scount.data(), R * 8, allcount.data()); });
+		std::vector<size_t> sb(R), so(R), rb(R), ro(R);
+		nrecv = 0;
+		for (uint32_t p = 0; p < R; p++) {
+			sb[p] = (size_t)scount[p] * 8; so[p] = (size_t)send_at[p] * 8;
+			const size_t m = allcount[(size_t)p * R + r];
+			rb[p] = m * 8; ro[p] = nrecv * 8;
+			nrecv += m;
+			if (p != r) c->stats.exchange_bytes += 2 * sb[p];
+		}
+		SBL_CHECK(nrecv < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many records for one owner");
+		c->d_recv.ensure(nrecv * 8 + 16); c->d_send.ensure(nrecv * 8 + 16);      // received keys / values
+		clk.time([&] { cm->alltoallv(c, c->d_rec_keys[1].as<char>(), sb.data(), so.data(), c->d_recv.as<char>(), rb.data(), ro.data()); });
+		clk.time([&] { cm->alltoallv(c, c->d_rec_vals[1].as<char>(), sb.data(), so.data(), c->d_send.as<char>(), rb.data(), ro.data()); });
+		// ---- C: owner side: partition again (R runs, each sorted by bucket), per-bucket tables
+		for (int i = 0; i < 2; i++) { c->d_otable.ensure(nrecv * 8 + 16); c->d_oused.ensure(nrecv * 8 + 16); }
+		unsigned long long *ok = c->d_otable.as<unsigned long long>(), *ov = c->d_oused.as<unsigned long long>();
+		if (nrecv) {
+			size_t tmp = 0;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, c->d_recv.as<unsigned long long>(), ok, c->d_send.as<unsigned long long>(), ov, nrecv, 0, bits, s));
+			c->d_sorttmp.ensure(tmp);
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp, c->d_recv.as<unsigned long long>(), ok, c->d_send.as<unsigned long long>(), ov, nrecv, 0, bits, s));
+		}
+		k_bucket_bounds<<<nblocks(nb + 1, 256), 256, 0, s>>>(ok, nrecv, bits, c->d_boff.as<unsigned>());
+		unsigned long long *members = c->d_recv.as<unsigned long long>();          // the unsorted received keys are dead: their space holds the member list
+		bool rebucket = false;
+		for (;;) {
+			c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
+			HIP_TRY(hipMemsetAsync(ctr, 0, 64 * 4, s));
+			k_bucket_classify<<<(unsigned)nb, KB_THREADS, 0, s>>>(ok, ov, c->d_boff.as<unsigned>(), k, ctr, c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(),
+			                                                     (unsigned)maxpairs, members, (unsigned)nrecv);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(cnt, ctr, 16, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (cnt[3] & 1u) { rebucket = true; break; }
+			if (cnt[0] > maxpairs || (size_t)cnt[1] > 2 * maxpairs) { maxpairs = std::max<size_t>(cnt[0], ((size_t)cnt[1] + 1) / 2) + 1024; continue; }
+			break;
+		}
+		// a bucket that overflowed anywhere makes everybody re-bucket with a longer prefix
+		std::vector<unsigned long long> flag(1, rebucket ? 1 : 0), flags(R);
+		clk.time([&] { cm->allgather_host(c, flag.data(), 8, flags.data()); });
+		if (std::find(flags.begin(), flags.end(), 1ull) == flags.end()) break;
+		bits = std::min(bits + 2, 40u);
 	}
-	c->d_recv.ensure(nrecv * sizeof(KmerRecord) + 16);
-	clk.time([&] { cm->alltoallv(c, c->d_send.as<char>(), sb.data(), so.data(), c->d_recv.as<char>(), rb.data(), ro.data()); });
-
-	// ---- C: owner merge + classification
-	size_t ocap = 1024;
-	while (ocap < nrecv + nrecv / 2) ocap <<= 1;
-	SBL_CHECK(ocap <= 0xFFFFFFFFull && nrecv < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "owner table too large for 32-bit slot indices");
-	c->d_otable.ensure(ocap * sizeof(KmerSlot)); c->d_oused.ensure(nrecv * 4 + 64);
-	k_table_init<<<(unsigned)std::min<size_t>((ocap + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_otable.as<KmerSlot>(), ocap);
-	if (nrecv) k_shard_merge<<<(unsigned)std::min<size_t>((nrecv + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_recv.as<KmerRecord>(), nrecv, c->d_otable.as<KmerSlot>(),
-	                                                                                                  (unsigned long long)ocap - 1, ctr + 9, c->d_oused.as<unsigned>());
-	unsigned oused = 0;
-	HIP_TRY(hipMemcpyAsync(&oused, ctr + 9, 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	unsigned cgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)oused + 255) / 256, 256 * 16));
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_otable.as<KmerSlot>(), c->d_oused.as<unsigned>(), oused, k, ctr, nullptr, nullptr, 0);
-	unsigned pc[2];
-	HIP_TRY(hipMemcpyAsync(pc, ctr, 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	unsigned npairs = pc[0], mykeys = pc[1];
-	c->d_keys.ensure((size_t)mykeys * 8 + 16); c->d_payload.ensure((size_t)mykeys * 4 + 16);
-	HIP_TRY(hipMemsetAsync(ctr, 0, 8, s));
-	k_classify_slots<<<cgrid, 256, 0, s>>>(c->d_otable.as<KmerSlot>(), c->d_oused.as<unsigned>(), oused, k, ctr,
-	                                       c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), npairs);
-	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev[1], s));
+	const unsigned npairs = cnt[0], mykeys = cnt[1], nmem = cnt[2];
+	unsigned long long *members = c->d_recv.as<unsigned long long>();
 
 	// ---- D: gather the bifurcation codes, rank them identically everywhere
 	std::vector<size_t> gb, go;
 	size_t nkeys = allgatherv(c, clk, c->d_keys.as<char>(), (size_t)mykeys * 8, c->d_allkeys, gb, go) / 8;
 	SBL_CHECK(nkeys < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many bifurcations");
 	c->d_allkeys2.ensure(nkeys * 8 + 16);
-	size_t bcap = 1024;
-	while (bcap < 2 * nkeys) bcap <<= 1;
-	c->d_otable.ensure(bcap * sizeof(KmerSlot));                 // the owner table is done: reuse it as the bifurcation-only table
-	k_table_init<<<(unsigned)std::min<size_t>((bcap + 255) / 256, 256 * 16), 256, 0, s>>>(c->d_otable.as<KmerSlot>(), bcap);
+	c->d_pairids.ensure((size_t)npairs * 8 + 16);
 	if (nkeys) {
 		size_t tmp = 0;
 		HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp, c->d_allkeys.as<unsigned long long>(), c->d_allkeys2.as<unsigned long long>(), nkeys, 0, 2 * k, s));
 		c->d_sorttmp.ensure(tmp);
 		HIP_TRY(rocprim::radix_sort_keys(c->d_sorttmp.p, tmp, c->d_allkeys.as<unsigned long long>(), c->d_allkeys2.as<unsigned long long>(), nkeys, 0, 2 * k, s));
-		k_bif_table_build<<<nblocks(nkeys, 256), 256, 0, s>>>(c->d_allkeys2.as<unsigned long long>(), (unsigned)nkeys, k, c->d_otable.as<KmerSlot>(), (unsigned long long)bcap - 1);
+		if (mykeys)
+			k_rank_own_keys<<<nblocks(mykeys, 256), 256, 0, s>>>(c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), mykeys,
+			                                                    c->d_allkeys2.as<unsigned long long>(), (unsigned)nkeys, k, c->d_pairids.as<unsigned>());
 	}
 	c->bif_count = (uint32_t)nkeys;
 
-	// ---- E: resolve my slice, compact, gather the marks, scatter them into the dense arrays
+	// ---- E: marks of my buckets' member positions, gathered and scattered into the dense arrays everywhere
 	for (int st = 0; st < 2; st++) {
 		c->d_bif[st].ensure(elem_capacity * 4);
 		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
+		c->d_melem[st].ensure((size_t)nmem * 4 + 16); c->d_mid[st].ensure((size_t)nmem * 4 + 16);
 	}
-	if (t1 > t0 && nkeys)
-		k_resolve_marks_bif<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k,
-		                                                c->d_otable.as<KmerSlot>(), (unsigned long long)bcap - 1,
-		                                                c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(), t0, t1);
+	if (nmem)
+		k_member_marks<<<nblocks(nmem, 256), 256, 0, s>>>(members, nmem, k, c->d_pairids.as<unsigned>(), c->d_melem[0].as<unsigned>(), c->d_mid[0].as<unsigned>(),
+		                                                 c->d_melem[1].as<unsigned>(), c->d_mid[1].as<unsigned>());
 	HIP_TRY(hipGetLastError());
 	for (int st = 0; st < 2; st++) {
-		sbl_compact_marks(c, st);
-		size_t mine = c->nmarks[st];
-		size_t tot = allgatherv(c, clk, c->d_melem[st].as<char>(), mine * 4, c->d_gelem[st], gb, go) / 4;
-		allgatherv(c, clk, c->d_mid[st].as<char>(), mine * 4, c->d_gid[st], gb, go);
+		size_t tot = allgatherv(c, clk, c->d_melem[st].as<char>(), (size_t)nmem * 4, c->d_gelem[st], gb, go) / 4;
+		allgatherv(c, clk, c->d_mid[st].as<char>(), (size_t)nmem * 4, c->d_gid[st], gb, go);
 		if (tot) k_scatter_marks<<<nblocks(tot, 256), 256, 0, s>>>(c->d_gelem[st].as<unsigned>(), c->d_gid[st].as<unsigned>(), tot, c->d_bif[st].as<unsigned>());
 	}
 	HIP_TRY(hipGetLastError());
