@@ -124,6 +124,15 @@ typedef struct { int32_t id; uint32_t chr; uint64_t start, end; } sbl_block;
 sbl_status sbl_generate_blocks(sbl_ctx *ctx, uint32_t k, uint32_t trim_k, uint32_t min_size, int shared_only,
                                const sbl_block **blocks, uint64_t *n);
 
+/* what the reference's main runs after GenerateSyntenyBlocks (src/sibelia.cpp:287-315) on the blocks of the last
+ * sbl_generate_blocks: Postprocessor::GlueStripes (src/postprocessor.cpp:37-154; skipped when glue == 0) and the texts of
+ * blocks_coords.txt (OutputGenerator::ListBlocksIndices, src/outputgenerator.cpp:227-233), genomes_permutations.txt
+ * (ListChromosomesAsPermutations, :203-219) and coverage_report.txt (GenerateReport, :162-201), byte for byte.
+ * names: record descriptions (NULL: those of the last sbl_load_fasta).  Host-side bookkeeping and formatting only.
+ * Everything returned is owned by the ctx and valid until the next call. */
+sbl_status sbl_postprocess(sbl_ctx *ctx, int glue, const char *const *names, const sbl_block **blocks, uint64_t *n,
+                           const char **blocks_coords, const char **genomes_permutations, const char **coverage_report);
+
 /* H0: the k-mer hash of the reference's hashing.h (SlidingWindow / KMerHashFunction, src/hashing.h:14-112; HASH_BASE 57,
  * arithmetic mod 2^64) for every k-mer of the current state: strand 0 then strand 1 (complemented characters, walk order),
  * chromosomes ascending.  The reference's production path never executes it; provided with a known-answer test.

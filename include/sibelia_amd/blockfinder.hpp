@@ -84,6 +84,22 @@ namespace SyntenyFinderAMD
 			for (uint64_t i = 0; i < n; i++) block.push_back(BlockInstance{b[i].id, b[i].chr, (size_t)b[i].start, (size_t)b[i].end});
 		}
 
+		// What main runs after GenerateSyntenyBlocks (sibelia.cpp:287-315) on the blocks of the last call: Postprocessor::GlueStripes
+		// (postprocessor.cpp:37-154, unless glue is false) and the texts of blocks_coords.txt / genomes_permutations.txt /
+		// coverage_report.txt (outputgenerator.cpp:162-233).  descriptions: FASTARecord::GetDescription per record (empty: those of the FASTA file).
+		void PostProcess(bool glue, std::vector<BlockInstance> &block, std::string &blocksCoords, std::string &permutations, std::string &coverageReport,
+		                 const std::vector<std::string> &descriptions = std::vector<std::string>())
+		{
+			std::vector<const char *> nm;
+			for (const std::string &d : descriptions) nm.push_back(d.c_str());
+			const sbl_block *b = nullptr; uint64_t n = 0;
+			const char *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
+			Check(sbl_postprocess(ctx_, glue ? 1 : 0, nm.empty() ? nullptr : nm.data(), &b, &n, &t0, &t1, &t2), "PostProcess");
+			block.clear();
+			for (uint64_t i = 0; i < n; i++) block.push_back(BlockInstance{b[i].id, b[i].chr, (size_t)b[i].start, (size_t)b[i].end});
+			blocksCoords = t0; permutations = t1; coverageReport = t2;
+		}
+
 		// serialization.cpp:88-110 (same text, byte for byte)
 		void SerializeCondensedGraph(size_t k, std::ostream &out, ProgressCallBack = ProgressCallBack())
 		{

@@ -42,9 +42,9 @@ pids=()
 for f in divsufsort sssort trsort utils; do
   gcc $CFLAGS $CDEFS -I"$DSS/include" -I"$OUT/include" -c "$DSS/lib/$f.c" -o "$OUT/obj/dss_$f.o" & pids+=($!)
 done
-# the reference's translation units the BlockFinder class needs (src/CMakeLists.txt:11 minus main, writers, resources)
+# the reference's translation units the BlockFinder class, the post-processor and the writers need (src/CMakeLists.txt:11 minus main and the unit test)
 UNITS="indexedsequence blockfinder bifurcationstorage bulgeremoval dnasequence edge fasta serialization synteny
- platform stranditerator vertexenumeration blockinstance util"
+ platform stranditerator vertexenumeration blockinstance util postprocessor outputgenerator resource"
 for f in $UNITS; do
   g++ $CXXFLAGS -I"$SRC/include" -I"$OUT/include" -c "$SRC/$f.cpp" -o "$OUT/obj/$f.o" & pids+=($!)
 done

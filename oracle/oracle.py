@@ -24,14 +24,15 @@ EDGE_DTYPE = np.dtype([("chr", "<u4"), ("strand", "<u4"), ("start_vertex", "<u4"
 
 
 SRC_CPP = os.path.join(HERE, "synteny_oracle.cpp")
+SRC_CPP2 = os.path.join(HERE, "output_oracle.cpp")
 
 
 def build(force: bool = False) -> str:
-    srcs = [SRC, SRC_CPP, os.path.join(HERE, "sibelia_oracle.h")]
+    srcs = [SRC, SRC_CPP, SRC_CPP2, os.path.join(HERE, "sibelia_oracle.h")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(x) for x in srcs):
         obj = os.path.join(HERE, "sibelia_oracle.o")
         subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-c", "-o", obj, SRC], check=True)
-        subprocess.run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-o", LIB, SRC_CPP, obj], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-o", LIB, SRC_CPP, SRC_CPP2, obj], check=True)
         os.remove(obj)
     return LIB
 
@@ -57,6 +58,8 @@ def lib():
         L.orc_list_edges.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_generate_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_postprocess.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_force_long_k_path.argtypes = [C.c_void_p, C.c_int]
@@ -148,6 +151,24 @@ class Oracle:
         a = _view(v.value, m.value, BLOCK_DTYPE)
         self.L.orc_free(v)
         return a
+
+    def postprocess(self, blocks: np.ndarray, names: Sequence[str], glue: bool = True):
+        """GlueStripes + the three writers: (blocks, [blocks_coords.txt, genomes_permutations.txt, coverage_report.txt])."""
+        b = np.ascontiguousarray(blocks, dtype=BLOCK_DTYPE)
+        n = len(self._orig)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        sz = (C.c_uint64 * n)(*[len(s) for s in self._orig])
+        ob, no = C.c_void_p(), C.c_uint64()
+        tx, tl = (C.c_void_p * 3)(), (C.c_uint64 * 3)()
+        rc = self.L.orc_postprocess(b.ctypes.data, len(b), n, nm, sz, int(glue), C.byref(ob), C.byref(no), tx, tl)
+        if rc:
+            raise ValueError("orc_postprocess failed: %d" % rc)
+        out = _view(ob.value, no.value, BLOCK_DTYPE)
+        texts = [C.string_at(tx[i], tl[i]) for i in range(3)]
+        self.L.orc_free(ob)
+        for i in range(3):
+            self.L.orc_free(tx[i])
+        return out, texts
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         v, n = C.c_void_p(), C.c_uint64()

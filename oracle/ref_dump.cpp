@@ -9,7 +9,7 @@
 // into flat binary files that make_golden.py turns into committed fixtures.
 //
 // usage: ref_dump <in.fasta> <out-prefix> <cmd>...
-//   cmd = state | hash:K | blocks:K:TRIMK:MINSIZE:SHARED | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+//   cmd = state | hash:K | blocks:K:TRIMK:MINSIZE:SHARED | write:K:TRIMK:MINSIZE:SHARED:GLUE | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
 #include "common.h"
 #include "fasta.h"
 #include "dnasequence.h"
@@ -17,6 +17,8 @@
 #include "blockfinder.h"
 #undef private
 #include "hashing.h"
+#include "postprocessor.h"
+#include "outputgenerator.h"
 #include <stdint.h>
 #include <string.h>
 #include <time.h>
@@ -117,7 +119,7 @@ int main(int argc, char **argv)
 	BlockFinder finder(chrList);
 	for(int a = 3; a < argc; a++)
 	{
-		unsigned k = 0, d = 0, it = 0, sh = 0;
+		unsigned k = 0, d = 0, it = 0, sh = 0, gl = 0;
 		char buf[64]; sprintf(buf, ".%d.out", a - 3);      // one output file per command, in order
 		if(sscanf(argv[a], "enum:%u", &k) == 1)
 		{
@@ -164,6 +166,37 @@ int main(int argc, char **argv)
 			fclose(f);
 			fprintf(stderr, "blocks k=%u trimK=%u minSize=%u shared=%u -> %zu instances seconds=%.6f\n", k, d, it, sh, block.size(),
 			        (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+		}
+		else if(sscanf(argv[a], "write:%u:%u:%u:%u:%u", &k, &d, &it, &sh, &gl) == 5)
+		{
+			// N4: what main does after the stages (src/sibelia.cpp:287-315): GenerateSyntenyBlocks, Postprocessor::GlueStripes (unless
+			// GL = 0), then the writers ListBlocksIndices (blocks_coords.txt), ListChromosomesAsPermutations, GenerateReport.
+			// Output: u64 n, n x (i32 id, u32 chr, u64 start, u64 end) after glueing | 3 x (u64 len, text)
+			std::vector<BlockInstance> block;
+			finder.GenerateSyntenyBlocks(k, d, it, block, sh != 0);
+			Postprocessor processor(chrList, it);
+			if(gl) processor.GlueStripes(block);
+			OutputGenerator generator(chrList);
+			std::string tmp = prefix + buf + ".tmp";
+			FILE *f = fopen((prefix + buf).c_str(), "wb");
+			put64(f, block.size());
+			for(size_t i = 0; i < block.size(); i++)
+			{
+				put32(f, (uint32_t)block[i].GetSignedBlockId()); put32(f, (uint32_t)block[i].GetChrId());
+				put64(f, block[i].GetStart()); put64(f, block[i].GetEnd());
+			}
+			for(int w = 0; w < 3; w++)
+			{
+				if(w == 0) generator.ListBlocksIndices(block, tmp);
+				if(w == 1) generator.ListChromosomesAsPermutations(block, tmp);
+				if(w == 2) generator.GenerateReport(block, tmp);
+				std::ifstream in(tmp.c_str(), std::ios::binary);
+				std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+				put64(f, text.size());
+				fwrite(text.data(), 1, text.size(), f);
+			}
+			fclose(f);
+			remove(tmp.c_str());
 		}
 		else if(sscanf(argv[a], "dot:%u", &k) == 1)
 		{

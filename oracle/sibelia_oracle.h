@@ -71,7 +71,11 @@ void orc_free(void *p);
 typedef struct { int32_t id; uint32_t chr; uint64_t start, end; } orc_block;      /* BlockInstance: signed block id, chr, [start, end) */
 int orc_generate_blocks(orc_ctx *c, const uint8_t *const *orig_seq, const uint64_t *orig_len, uint32_t k, uint32_t trimK, uint32_t minSize,
                         int sharedOnly, orc_block **out, uint64_t *n);
-void orc_rng_copy(orc_ctx *dst, const orc_ctx *src);   /* a child index shares the parent's rand() stream */
+void orc_rng_copy(orc_ctx *dst, const orc_ctx *src);
+/* N4: Postprocessor::GlueStripes (src/postprocessor.cpp:37-154) + the writers of blocks_coords.txt, genomes_permutations.txt and
+ * coverage_report.txt (src/outputgenerator.cpp:162-233; output_oracle.cpp).  Everything returned is malloc'd (orc_free). */
+int orc_postprocess(const orc_block *in, uint64_t n, uint32_t nchr, const char *const *names, const uint64_t *sizes, int glue,
+                    orc_block **out_blocks, uint64_t *nout, char **texts /* 3 */, uint64_t *text_len /* 3 */);   /* a child index shares the parent's rand() stream */
 
 /* test hooks */
 void orc_force_long_k_path(orc_ctx *c, int on);      /* use the rank-doubling grouping even for k <= 32 */

@@ -23,7 +23,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
-           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks"]
+           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess"]
 
 
 class StageStats(C.Structure):
@@ -77,6 +77,8 @@ def load_library():
         L.sbl_record_name.argtypes = [C.c_void_p, C.c_uint32]
         L.sbl_record_name.restype = C.c_char_p
         L.sbl_generate_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.sbl_postprocess.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.sbl_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_comm_unique_id.argtypes = [C.c_void_p]
         L.sbl_comm_attach_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -183,6 +185,17 @@ class BlockFinder:
         return _view(b.value, n.value, formats.BLOCK_DTYPE)
 
     generate_blocks = GenerateSyntenyBlocks
+
+    def postprocess(self, names: Optional[Sequence[str]] = None, glue: bool = True):
+        """GlueStripes (reference src/postprocessor.cpp:37-154) on the blocks of the last GenerateSyntenyBlocks + the texts of
+        blocks_coords.txt, genomes_permutations.txt, coverage_report.txt (src/outputgenerator.cpp:162-233)."""
+        nm = None
+        if names is not None:
+            nm = (C.c_char_p * len(names))(*[x.encode() for x in names])
+        b, n = C.c_void_p(), C.c_uint64()
+        t = [C.c_char_p() for _ in range(3)]
+        self._check(self.L.sbl_postprocess(self.h, int(glue), nm, C.byref(b), C.byref(n), C.byref(t[0]), C.byref(t[1]), C.byref(t[2])), "sbl_postprocess")
+        return _view(b.value, n.value, formats.BLOCK_DTYPE), [x.value for x in t]
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         """H0: hashes of the reference's hashing.h for every k-mer, strand 0 then 1, chromosomes ascending, walk order."""

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsibelia_amd.so")
-SOURCES = ["sbl_api.hip", "simplify.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip"]
+SOURCES = ["sbl_api.hip", "simplify.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
 HEADERS = ["sbl_common.h", "sbl_ctx.h", "kmer_kernels.h", "kmer_bucket_kernels.h", "bulge_txn.h", "simplify_steps.h", "simplify_driver.h",
            os.path.join("..", "..", "include", "sibelia_amd.h")]
 

@@ -1,0 +1,193 @@
+// postprocess.hip -- downstream of the synteny stage: Postprocessor::GlueStripes and the three text reports.
+//
+// Replaces Postprocessor::GlueStripes (reference src/postprocessor.cpp:37-154) and OutputGenerator::ListBlocksIndices,
+// ListChromosomesAsPermutations and GenerateReport (src/outputgenerator.cpp:227-233 + :44-67, :203-219, :162-201 + :116-160): what
+// main runs between GenerateSyntenyBlocks and the end (src/sibelia.cpp:287-315) to produce blocks_coords.txt,
+// genomes_permutations.txt and coverage_report.txt.  A few hundred to a few thousand block instances of host bookkeeping and
+// text formatting -- there is nothing here for the GPU; it lives behind the C ABI so that the reference's pipeline is complete
+// on top of it.  Row order follows the reference's unstable sorts (the same libstdc++ calls on the same element order).
+#include <climits>
+#include <cstring>
+#include <algorithm>
+#include <sstream>
+#include <iterator>
+
+#include "sbl_ctx.h"
+
+namespace {
+
+inline int iabs(int x) { return x > 0 ? x : -x; }
+struct ById { bool operator()(const sbl_block &a, const sbl_block &b) const { return (size_t)iabs(a.id) < (size_t)iabs(b.id); } };
+struct ByChr { bool operator()(const sbl_block &a, const sbl_block &b) const { return a.chr < b.chr; } };
+struct ByChrStart { bool operator()(const sbl_block &a, const sbl_block &b) const { return a.chr != b.chr ? a.chr < b.chr : a.start < b.start; } };
+
+// runs of equal elements after a sort by `less` (GroupBy, src/common.h:150-160)
+template <class T, class Less> std::vector<std::pair<size_t, size_t>> group_by(std::vector<T> &v, Less less)
+{
+	std::vector<std::pair<size_t, size_t>> g;
+	std::sort(v.begin(), v.end(), less);
+	for (size_t i = 0; i < v.size();) {
+		size_t j = i;
+		while (j < v.size() && !less(v[i], v[j])) j++;
+		g.push_back({i, j});
+		i = j;
+	}
+	return g;
+}
+
+// GlueStripes: two blocks that always occur next to each other, in the same relative orientation and as often as each other, are
+// merged into one; repeated until nothing glues; ids renumbered densely at the end
+void glue_stripes(std::vector<sbl_block> &block, uint32_t nchr)
+{
+	std::vector<std::vector<sbl_block>> perm(nchr);
+	for (const sbl_block &b : block) perm[b.chr].push_back(b);
+	for (auto &p : perm) std::sort(p.begin(), p.end(), [](const sbl_block &a, const sbl_block &b) { return a.start < b.start; });
+	const int sentinel = INT_MAX >> 1;
+	struct Stripe { int first, second; };
+	for (;;) {
+		// (block, what follows it when read in its own orientation)
+		std::vector<Stripe> stripe;
+		for (auto &p : perm)
+			for (size_t i = 0; i < p.size(); i++) {
+				const int bid = p[i].id;
+				if (bid > 0) stripe.push_back({bid, i + 1 < p.size() ? p[i + 1].id : sentinel});
+				else stripe.push_back({-bid, -(i > 0 ? p[i - 1].id : -sentinel)});
+			}
+		std::sort(stripe.begin(), stripe.end(), [](const Stripe &a, const Stripe &b) { return a.first < b.first; });
+		int glueBid = 0;
+		for (size_t now = 0, next = 0; now < stripe.size(); now = next) {
+			bool same = true;
+			for (; next < stripe.size() && stripe[next].first == stripe[now].first; next++)
+				if (stripe[next].second != stripe[now].second || stripe[next].second == sentinel || iabs(stripe[next].second) == stripe[next].first) same = false;
+			if (!same) continue;
+			// the follower must occur exactly as often as the block itself
+			const int follower = iabs(stripe[now].second);
+			auto lo = std::lower_bound(stripe.begin(), stripe.end(), follower, [](const Stripe &s, int v) { return s.first < v; });
+			auto hi = std::upper_bound(stripe.begin(), stripe.end(), follower, [](int v, const Stripe &s) { return v < s.first; });
+			if ((size_t)(hi - lo) == next - now) { glueBid = stripe[now].first; break; }
+		}
+		if (!glueBid) break;
+		for (auto &p : perm)
+			for (size_t i = 0; i < p.size(); i++) {
+				if (iabs(p[i].id) != glueBid) continue;
+				if (p[i].id > 0) { p[i].end = p[i + 1].end; p.erase(p.begin() + i + 1); }
+				else { --i; p[i].id = p[i + 1].id; p[i].end = p[i + 1].end; p.erase(p.begin() + i + 1); }
+			}
+	}
+	block.clear();
+	std::vector<int> ids;
+	for (auto &p : perm) for (const sbl_block &b : p) { block.push_back(b); ids.push_back(iabs(b.id)); }
+	std::sort(ids.begin(), ids.end());
+	ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+	for (sbl_block &b : block) {
+		const int rank = (int)(std::lower_bound(ids.begin(), ids.end(), iabs(b.id)) - ids.begin()) + 1;
+		b.id = b.id > 0 ? rank : -rank;
+	}
+}
+
+struct Records { std::vector<std::string> name; std::vector<uint64_t> size; };
+const std::string kDelimiter(80, '-');                              // DELIMITER, src/util.cpp:9
+
+void list_chrs(const Records &r, std::ostream &out)
+{
+	out << "Seq_id\tSize\tDescription" << std::endl;
+	for (size_t i = 0; i < r.size.size(); i++) out << i + 1 << '\t' << r.size[i] << '\t' << r.name[i] << std::endl;
+	out << kDelimiter << std::endl;
+}
+
+std::string blocks_coords(const std::vector<sbl_block> &block, const Records &r)
+{
+	std::ostringstream out;
+	list_chrs(r, out);
+	std::vector<sbl_block> v = block;
+	for (const auto &g : group_by(v, ById())) {
+		std::sort(v.begin() + g.first, v.begin() + g.second, ByChr());
+		out << "Block #" << iabs(v[g.first].id) << std::endl << "Seq_id\tStrand\tStart\tEnd\tLength" << std::endl;
+		for (size_t i = g.first; i < g.second; i++) {
+			const sbl_block &b = v[i];
+			// conventional (1-based, strand-aware) coordinates: src/blockinstance.cpp:57-75
+			out << b.chr + 1 << '\t' << (b.id < 0 ? '-' : '+') << '\t' << (b.id > 0 ? b.start + 1 : b.end) << '\t' << (b.id > 0 ? b.end : b.start + 1)
+			    << '\t' << b.end - b.start << "\n";
+		}
+		out << kDelimiter << std::endl;
+	}
+	return out.str();
+}
+
+std::string permutations(const std::vector<sbl_block> &block, const Records &r)
+{
+	std::ostringstream out;
+	std::vector<sbl_block> v = block;
+	for (const auto &g : group_by(v, ByChr())) {
+		out.setf(std::ios_base::showpos);
+		out << '>' << r.name[v[g.first].chr] << std::endl;
+		std::sort(v.begin() + g.first, v.begin() + g.second, ByChrStart());
+		for (size_t i = g.first; i < g.second; i++) out << v[i].id << " ";
+		out << "$" << std::endl;
+	}
+	return out.str();
+}
+
+std::string coverage_report(const std::vector<sbl_block> &block, const Records &r)
+{
+	std::ostringstream out;
+	std::vector<sbl_block> v = block;
+	typedef std::pair<size_t, std::pair<size_t, size_t>> Deg;          // (degree, range of the block's instances in v)
+	std::vector<Deg> byBlock;
+	for (const auto &g : group_by(v, ById())) byBlock.push_back({g.second - g.first, g});
+	list_chrs(r, out);
+	out << "Degree\tCount\tTotal";
+	for (size_t i = 0; i < r.size.size(); i++) out << "\tSeq " << i + 1;
+	out << std::endl;
+	auto groups = group_by(byBlock, [](const Deg &a, const Deg &b) { return a.first < b.first; });
+	groups.push_back({0, byBlock.size()});
+	std::vector<uint8_t> cover;
+	for (size_t gi = 0; gi < groups.size(); gi++) {
+		const auto &g = groups[gi];
+		if (gi + 1 != groups.size()) out << byBlock[g.first].first << '\t' << g.second - g.first << '\t';
+		else out << "All\t" << g.second - g.first << "\t";
+		out.precision(2);
+		out.setf(std::ostream::fixed);
+		std::vector<double> pct;
+		double totalBp = 0, totalCovered = 0;
+		for (size_t c = 0; c < r.size.size(); c++) {
+			totalBp += r.size[c];
+			cover.assign(r.size[c], 0);
+			for (size_t x = g.first; x < g.second; x++)
+				for (size_t i = byBlock[x].second.first; i < byBlock[x].second.second; i++)
+					if (v[i].chr == c) memset(cover.data() + v[i].start, 1, v[i].end - v[i].start);
+			const double covered = (double)std::count(cover.begin(), cover.end(), 1);
+			pct.push_back(covered / cover.size() * 100);
+			totalCovered += covered;
+		}
+		pct.insert(pct.begin(), totalCovered / totalBp * 100);
+		std::copy(pct.begin(), pct.end(), std::ostream_iterator<double>(out, "%\t"));
+		out << std::endl;
+	}
+	out << kDelimiter << std::endl;
+	return out.str();
+}
+
+}  // namespace
+
+extern "C" sbl_status sbl_postprocess(sbl_ctx *c, int glue, const char *const *names, const sbl_block **blocks, uint64_t *n,
+                                      const char **coords, const char **perms, const char **coverage)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(c->orig_sepidx.size() == (size_t)c->nchr + 1, SBL_ERR_BAD_ARG, "no records loaded");
+		Records r;
+		for (uint32_t i = 0; i < c->nchr; i++) {
+			r.size.push_back(c->orig_sepidx[i + 1] - c->orig_sepidx[i] - 1);
+			r.name.push_back(names ? std::string(names[i]) : i < c->fa_names.size() ? c->fa_names[i] : std::string());
+		}
+		if (glue) glue_stripes(c->blocks, c->nchr);
+		c->report[0] = blocks_coords(c->blocks, r);
+		c->report[1] = permutations(c->blocks, r);
+		c->report[2] = coverage_report(c->blocks, r);
+		if (blocks) *blocks = c->blocks.data();
+		if (n) *n = c->blocks.size();
+		if (coords) *coords = c->report[0].c_str();
+		if (perms) *perms = c->report[1].c_str();
+		if (coverage) *coverage = c->report[2].c_str();
+	});
+}

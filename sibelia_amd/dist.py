@@ -104,6 +104,9 @@ class LocalShardedFinder:
         assert all(np.array_equal(x, res[0]) for x in res), "ranks disagree"
         return res[0]
 
+    def postprocess(self, names=None, glue=True):
+        return self.ranks[0].postprocess(names, glue)
+
     def kmer_hashes(self, k):
         return self.ranks[0].kmer_hashes(k)
 

@@ -7,6 +7,7 @@ so that sha256(serialise(result)) can be compared with tests/golden/vectors.json
   state  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
   dot    text of BlockFinder::SerializeCondensedGraph (reference src/serialization.cpp:88-110)
   blocks u64 n | n x (i32 signed block id, u32 chr, u64 start, u64 end): BlockFinder::GenerateSyntenyBlocks' result, in its order
+  write  blocks (as above, after GlueStripes) | 3 x (u64 len, text): blocks_coords.txt, genomes_permutations.txt, coverage_report.txt
   hash   for strand in (+,-), per chromosome: u64 n, n x u64 k-mer hashes of the reference's hashing.h in walk order
 """
 from __future__ import annotations

@@ -13,6 +13,7 @@ file whose sha256 (and for tiny cases whose bytes) are stored.  Output formats:
   stage:K:D:ITER  u64 bulges | u32 nchr | per chr: u64 len, len bytes, len x u32 original positions
   dot:K           text of BlockFinder::SerializeCondensedGraph(K)
   blocks:K:T:M:S  N2: BlockFinder::GenerateSyntenyBlocks(K, trimK=T, minSize=M, sharedOnly=S): u64 n, n x (i32 id, u32 chr, u64 start, u64 end)
+  write:K:T:M:S:G N4: GenerateSyntenyBlocks, GlueStripes if G, then the texts of blocks_coords.txt / genomes_permutations.txt / coverage_report.txt
   hash:K          H0: SlidingWindow hashes (src/hashing.h) of every K-mer of the current rawSeq_, per (strand, chr): u64 n, n x u64
 """
 import base64, gzip, hashlib, json, os, shutil, struct, subprocess, sys, tempfile
@@ -65,7 +66,7 @@ HAND = {
                       ["enum:4", "stage:4:9:4", "dot:4"]),
     "tandem_k3": (["ACGACGACGACGTTACGACGACG", "ACGACGACGTTTACGACGACGACG"], ["enum:3", "stage:3:8:4", "dot:3"]),
     "short_chr_k6": (["ACGTA", "ACGTAC", "ACGTACG", "TTACGTACGGA", "A"], ["enum:6", "stage:6:10:4", "dot:6", "hash:6", "hash:2"]),
-    "identical_k5": (["ACGTTGCATGCCGTAAGCTTGGA"] * 3, ["enum:5", "stage:5:10:4", "dot:5", "blocks:5:4:6:0", "blocks:5:5:10:1"]),
+    "identical_k5": (["ACGTTGCATGCCGTAAGCTTGGA"] * 3, ["enum:5", "stage:5:10:4", "dot:5", "blocks:5:4:6:0", "blocks:5:5:10:1", "write:5:4:6:0:1"]),
     "three_way_k4": (["TTGACCAGTACGGTCAATGCCATAGGCTAAGC", "TTGACCAGTTCGGTCAATGCGATAGGCTAAGC",
                       "TTGACCAGTGCGGTCAATGCTATAGGCTAAGC", "TTGACCAGTACGGTCAATGCCATAGGCTAAGC"],
                      ["enum:4", "stage:4:10:4", "dot:4"]),
@@ -90,21 +91,23 @@ def cases(skipped):
         if seed % 5 == 0:                       # N2 on what the stages left (trimK <= k, small minimum block size)
             kb = k2 if seed % 2 == 0 else k
             cmds += ["blocks:%d:%d:%d:%d" % (kb, max(2, min(kb, 5 + seed % 7)), kb + seed % 13, seed % 3 == 0)]
-        yield "small/%03d" % seed, {"kind": "small_case", "seed": seed}, (lambda seqs=seqs: seqs), cmds, False, 20
+            if seed % 10 == 0:
+                cmds += ["write:%d:%d:%d:0:1" % (kb, max(2, min(kb, 5 + seed % 7)), kb + seed % 13)]
+        yield "small/%03d" % seed, {"kind": "small_case", "seed": seed}, (lambda seqs=seqs: seqs), cmds, False, int(os.environ.get("GOLDEN_SMALL_TIMEOUT", "20"))
     hp = "Helicobacter_pylori.fa.gz"
     sa = "Staphylococcus_aureus_pair.fa.gz"
     data = os.path.join(ROOT, "tests", "golden", "data")
     rd = lambda f: (lambda: W.read_fasta(os.path.join(data, f))[1])
     yield "real/hpylori_k25", {"kind": "fasta", "file": hp}, rd(hp), ["enum:25", "stage:25:150:4", "enum:25", "dot:25", "hash:25"], False, None
-    yield "real/hpylori_fine", {"kind": "fasta", "file": hp}, rd(hp), ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "dot:500", "blocks:500:30:500:0", "blocks:500:30:5000:1"], False, None
+    yield "real/hpylori_fine", {"kind": "fasta", "file": hp}, rd(hp), ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "dot:500", "blocks:500:30:500:0", "blocks:500:30:5000:1", "write:500:30:500:0:1", "write:500:30:500:0:0"], False, None
     yield ("real/hpylori_loose", {"kind": "fasta", "file": hp}, rd(hp),
-           ["stage:30:150:4", "stage:100:1000:4", "stage:1000:5000:4", "stage:5000:15000:4", "enum:5000", "blocks:5000:30:5000:0"], False, None)
-    yield "real/saureus_k25", {"kind": "fasta", "file": sa}, rd(sa), ["enum:25", "stage:25:150:4", "enum:25", "blocks:25:25:200:0"], False, None
+           ["stage:30:150:4", "stage:100:1000:4", "stage:1000:5000:4", "stage:5000:15000:4", "enum:5000", "blocks:5000:30:5000:0", "write:5000:30:5000:0:1"], False, None)
+    yield "real/saureus_k25", {"kind": "fasta", "file": sa}, rd(sa), ["enum:25", "stage:25:150:4", "enum:25", "blocks:25:25:200:0", "write:25:25:200:0:1"], False, None
     small_inv = dict(inv_min=2000, inv_max=9000)
     synth = [
         ("synth/strains4_100k", dict(L0=100_000, n=4, seed=7, **small_inv), ["enum:25", "stage:25:150:4", "enum:25", "dot:25"]),
         ("synth/strains4_100k_fine", dict(L0=100_000, n=4, seed=7, **small_inv),
-         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500", "blocks:500:30:500:0", "blocks:100:30:300:1"]),
+         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500", "blocks:500:30:500:0", "blocks:100:30:300:1", "write:500:30:500:0:1", "write:100:30:300:1:1"]),
         ("synth/strains3_400k_k16", dict(L0=400_000, n=3, seed=11, inv_min=5000, inv_max=20000), ["enum:16", "stage:16:120:4", "enum:31"]),
         ("synth/strains2_4600k", dict(L0=4_600_000, n=2, seed=1), ["enum:25", "stage:25:150:4"]),
         ("synth/strains8_4600k", dict(L0=4_600_000, n=8, seed=1), ["enum:25", "stage:25:150:4"]),

@@ -186,6 +186,10 @@ def test_cpp_class_surface_runs_on_the_gpu(tmp_path):
                    '  size_t calls = 0; size_t b = bf.PerformGraphSimplifications(5, 12, 4, [&](size_t, SyntenyFinderAMD::BlockFinder::State) { calls++; });\n'
                    '  { std::ofstream o(std::string(argv[1]) + ".1"); bf.SerializeCondensedGraph(5, o); }\n'
                    '  bool threw = false; try { bf.PerformGraphSimplifications(5, 12, 1, [](size_t, SyntenyFinderAMD::BlockFinder::State) { throw 7; }); } catch (int) { threw = true; }\n'
+                   '  std::vector<SyntenyFinderAMD::BlockInstance> blk; bf.GenerateSyntenyBlocks(5, 4, 8, blk);\n'
+                   '  { std::ofstream o(std::string(argv[1]) + ".blocks"); for (auto &x : blk) o << x.GetSignedBlockId() << " " << x.GetChrId() << " " << x.GetStart() << " " << x.GetEnd() << "\\n"; }\n'
+                   '  std::string t0, t1, t2; bf.PostProcess(true, blk, t0, t1, t2, {"seq0", "seq1"});\n'
+                   '  { std::ofstream o(std::string(argv[1]) + ".reports"); o << t0 << t1 << t2; }\n'
                    '  std::printf("bulges %%zu calls %%zu threw %%d\\n", b, calls, (int)threw); return 0; }\n'
                    % (len(seqs), "".join('  v[%d].s = "%s";\n' % (i, s.decode()) for i, s in enumerate(seqs))))
     exe = tmp_path / "main"
@@ -199,6 +203,15 @@ def test_cpp_class_surface_runs_on_the_gpu(tmp_path):
     for i, o in enumerate(dots):
         got = open(str(tmp_path / ("dot.%d" % i)), "rb").read()
         assert F_sha(got) == o["sha256"], "DOT text %d differs from the reference" % i
+    # GenerateSyntenyBlocks + PostProcess through the class = the same calls through the Python mirror (itself checked against the
+    # reference's blocks: / write: fixtures) on the same sequence of operations
+    py = _bf(seqs)
+    py.list_edges(5); py.simplify_stage(5, 12, 4); py.list_edges(5); py.simplify_stage(5, 12, 1)
+    blocks = py.generate_blocks(5, 4, 8)
+    want = "".join("%d %d %d %d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert open(str(tmp_path / "dot.blocks")).read() == want
+    _, texts = py.postprocess(["seq0", "seq1"], True)
+    assert open(str(tmp_path / "dot.reports"), "rb").read() == b"".join(texts)
 
 
 def test_config5_shape_matches_oracle():

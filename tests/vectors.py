@@ -59,6 +59,12 @@ def run_cmd(backend, cmd: str) -> bytes:
         return F.state_bytes(bulges, seqs, opos)
     if p[0] == "blocks":
         return F.blocks_bytes(backend.generate_blocks(int(p[1]), int(p[2]), int(p[3]), bool(int(p[4]))))
+    if p[0] == "write":                                  # N4: blocks after GlueStripes + the three report texts
+        k, tk, ms, sh, gl = (int(x) for x in p[1:6])
+        blocks = backend.generate_blocks(k, tk, ms, bool(sh))
+        names = ["seq%d" % i for i in range(len(backend.state()[0]))]      # W.write_fasta's descriptions (what the reference read)
+        out, texts = backend.postprocess(blocks, names, bool(gl)) if hasattr(backend, "_orig") else backend.postprocess(names, bool(gl))
+        return F.blocks_bytes(out) + b"".join(__import__("struct").pack("<Q", len(t)) + t for t in texts)
     if p[0] == "hash":
         k = int(p[1])
         return F.hash_bytes(backend.kmer_hashes(k), [len(x) for x in backend.state()[0]], k)
