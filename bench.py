@@ -181,6 +181,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg[dom],
+                         "algorithmic_model": "this design's per-kernel model (DESIGN.md 4: e.g. k_commit = 8 B x (D + k) per instance of the launch's "
+                                              "transactions), not SURVEY 8d's stage formula N x 24.125 + 12 x instances + iters x N x 4 = %.2f GB per stage"
+                                              % ((N * 24.125 + 12 * st["instances"] + st["iterations"] * N * 4) / 1e9),
+                         "stage_frac_of_peak_by_survey_formula": ((N * 24.125 + 12 * st["instances"] + st["iterations"] * N * 4) / 1e9) / (ms_step * 1e-3) / HBM_PEAK_GBS,
                          "all_kernels_ms_per_step": per},
         }
         if replicas is not None:

@@ -111,6 +111,9 @@ def cases(skipped):
         ("synth/strains3_400k_k16", dict(L0=400_000, n=3, seed=11, inv_min=5000, inv_max=20000), ["enum:16", "stage:16:120:4", "enum:31"]),
         ("synth/strains2_4600k", dict(L0=4_600_000, n=2, seed=1), ["enum:25", "stage:25:150:4"]),
         ("synth/strains8_4600k", dict(L0=4_600_000, n=8, seed=1), ["enum:25", "stage:25:150:4"]),
+        # BASELINE.json config 3 at full size: 8 strains, -s fine cascade, then the synteny stage and the reports (~10 min of reference time)
+        ("synth/strains8_4600k_fine", dict(L0=4_600_000, n=8, seed=1),
+         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500", "blocks:500:30:500:0", "write:500:30:500:0:1"]),
     ]
     for name, kw, cmds in synth:
         yield name, {"kind": "gen_strains", "args": kw}, (lambda kw=kw: W.gen_strains(**kw)), cmds, False, None
@@ -148,7 +151,7 @@ def main():
         order.append(name)
         if only and not any(name.startswith(p) for p in only):
             continue
-        if name == "synth/strains8_4600k" and "--big" not in sys.argv:
+        if name.startswith("synth/strains8_4600k") and "--big" not in sys.argv:
             continue
         if not only and name in byname and [o["cmd"] for o in byname[name]["outputs"]] == cmds:
             continue                                   # already present with the same command list

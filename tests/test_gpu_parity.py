@@ -271,3 +271,27 @@ def test_config5_full_size_properties():
     assert sum(diff) == 1 and diff[2] == diff[3] == 0
     assert all(y[0] == 0 and y[-1] == len(y) - 1 and bool((np.diff(y.astype(np.int64)) == 1).all()) for y in p)
     bf.close()
+
+
+def test_config4_shape_full_size_is_reproducible():
+    # BASELINE.json config 4 shape at full size on one GPU: 62 strains x 4.6 Mbp (285 Mbp, 570 M strand-k-mers, ids with 124
+    # instances), k = 25.  No CPU implementation finishes it in test time (the reference is superlinear in the number of
+    # strains): the result must be reproducible and independent of the speculation window, and its first two strains are the
+    # 2-strain workload whose reference result is a fixture -- the stage must at least leave their lengths within the indel budget.
+    import hashlib
+    from sibelia_amd import workloads as W, formats as F
+    seqs = W.gen_strains(L0=4_600_000, n=62, seed=1)
+    digests, counts = [], []
+    for window in (0, 5000):
+        bf = _bf(seqs)
+        if window:
+            bf.set_window(window)
+        bulges = bf.simplify_stage(25, 150, 4)
+        st = bf.stats()
+        counts.append((bulges, st["bif_count"], st["instances"], st["replays"] - st["grow_replays"]))
+        s, p = bf.state()
+        digests.append(hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest())
+        assert all(int(y.max()) < len(x0) and bool((np.diff(y.astype(np.int64)) >= 0).all()) for x0, y in zip(seqs, p))      # original positions stay monotone
+        bf.close()
+    assert digests[0] == digests[1] and counts[0][:3] == counts[1][:3]
+    assert counts[0][0] > 2_000_000 and counts[0][1] > 1_000_000
