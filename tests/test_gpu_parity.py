@@ -295,3 +295,13 @@ def test_config4_shape_full_size_is_reproducible():
         bf.close()
     assert digests[0] == digests[1] and counts[0][:3] == counts[1][:3]
     assert counts[0][0] > 2_000_000 and counts[0][1] > 1_000_000
+
+
+def test_config3_full_size_fine_cascade_matches_reference():
+    # BASELINE.json config 3 at full size: 8 strains x 4.6 Mbp through the whole `-s fine` cascade (30,150)(100,500)(500,1500),
+    # then the enumeration at the last k, the synteny blocks and the three reports -- every output sha256-identical to what the
+    # unmodified reference produced on this input (about 12 minutes there)
+    gold = [v for v in VECS if v["name"] == "synth/strains8_4600k_fine"]
+    if not gold:
+        pytest.skip("fixture synth/strains8_4600k_fine not generated")
+    V.replay(gold[0], _bf)
