@@ -186,6 +186,9 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	unsigned bits = 4;
 	while (bits < 30 && (n >> bits) > 700) bits++;
 	size_t maxpairs = n / 8 + 4096, maxmembers = n;              // capacities of the classification outputs; grown on demand
+	// test hooks: start with too few bucket bits / too small an output buffer so that the re-bucket and grow paths run
+	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));
+	if (const char *e = getenv("SBL_TEST_MAXPAIRS")) maxpairs = (size_t)std::max(1, atoi(e));
 	unsigned cnt[4] = {0, 0, 0, 0};
 	unsigned long long *members = k0;                            // the unsorted records are dead after the partition: their space holds the member list
 	for (int attempt = 0;; attempt++) {

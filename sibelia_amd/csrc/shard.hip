@@ -344,6 +344,8 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 	unsigned bits = 4;
 	while (bits < 30 && (nall >> bits) > 700) bits++;              // the same on every rank: buckets are sized by the WHOLE input
 	size_t maxpairs = nall / R / 8 + 4096;
+	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));      // test hooks, as in sbl_run_enumeration
+	if (const char *e = getenv("SBL_TEST_MAXPAIRS")) maxpairs = (size_t)std::max(1, atoi(e));
 	unsigned cnt[4] = {0, 0, 0, 0};
 	size_t nrecv = 0;
 	HIP_TRY(hipEventRecord(c->ev[0], s));

@@ -305,3 +305,20 @@ def test_config3_full_size_fine_cascade_matches_reference():
     if not gold:
         pytest.skip("fixture synth/strains8_4600k_fine not generated")
     V.replay(gold[0], _bf)
+
+
+def test_bucket_overflow_and_buffer_growth_paths(monkeypatch):
+    # the radix-bucketed table re-buckets with a longer prefix when a bucket holds more distinct k-mers than its LDS table, and
+    # grows its classification buffers on demand: force both (2 bucket bits for 1.2 M positions, room for 16 pairs)
+    from sibelia_amd import workloads as W
+    from sibelia_amd.dist import LocalShardedFinder
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=300_000, n=4, seed=17, inv_min=3000, inv_max=12000)
+    want = Oracle(seqs).enumerate(20)
+    monkeypatch.setenv("SBL_TEST_BUCKET_BITS", "2")
+    monkeypatch.setenv("SBL_TEST_MAXPAIRS", "16")
+    for make in (_bf, lambda s: LocalShardedFinder(s, [0, 0, 0])):
+        bf = make(seqs)
+        got = bf.enumerate(20)
+        assert got[0] == want[0] and (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        bf.close()
