@@ -133,6 +133,12 @@ sbl_status sbl_generate_blocks(sbl_ctx *ctx, uint32_t k, uint32_t trim_k, uint32
 sbl_status sbl_postprocess(sbl_ctx *ctx, int glue, const char *const *names, const sbl_block **blocks, uint64_t *n,
                            const char **blocks_coords, const char **genomes_permutations, const char **coverage_report);
 
+/* Replaces BlockFinder::SerializeGraph (src/serialization.cpp:112-138; defined for records of at least k + 1 characters -- the
+ * reference walks off the end of a shorter one): DOT text of the UNcondensed de Bruijn graph of the
+ * current state, one line per (k+1)-window, generated on the device (a debugging dump: main only reaches it with -q and never
+ * with production options).  Owned by the ctx, valid until the next call. */
+sbl_status sbl_serialize_graph(sbl_ctx *ctx, uint32_t k, const char **text, uint64_t *len);
+
 /* H0: the k-mer hash of the reference's hashing.h (SlidingWindow / KMerHashFunction, src/hashing.h:14-112; HASH_BASE 57,
  * arithmetic mod 2^64) for every k-mer of the current state: strand 0 then strand 1 (complemented characters, walk order),
  * chromosomes ascending.  The reference's production path never executes it; provided with a known-answer test.

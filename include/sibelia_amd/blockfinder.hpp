@@ -2,8 +2,7 @@
 //
 // Mirrors SyntenyFinder::BlockFinder's public section (reference src/blockfinder.h:28-45) for the hot path:
 // same constructors (a FASTARecord only needs GetSequence()), same method names, argument order and meaning:
-// PerformGraphSimplifications, GenerateSyntenyBlocks, SerializeCondensedGraph (SerializeGraph, a debugging dump of the
-// uncondensed graph that main never calls with production options, is not provided).
+// PerformGraphSimplifications, GenerateSyntenyBlocks, SerializeCondensedGraph, SerializeGraph.
 // Header-only; link with -lsibelia_amd.  Errors that the reference cannot produce (no device, OOM, input
 // beyond the 29-bit limits) are thrown as std::runtime_error, the only exception type the reference itself throws
 // (src/platform.cpp:40,79,118,126).
@@ -115,6 +114,14 @@ namespace SyntenyFinderAMD
 				out << e[i].start_vertex << " -> " << e[i].end_vertex << " " << buf << std::endl;
 			}
 			out << "}" << std::endl;
+		}
+
+		// serialization.cpp:112-138
+		void SerializeGraph(size_t k, std::ostream &out)
+		{
+			const char *t = nullptr; uint64_t n = 0;
+			Check(sbl_serialize_graph(ctx_, (uint32_t)k, &t, &n), "SerializeGraph");
+			out.write(t, (std::streamsize)n);
 		}
 
 		// rawSeq_ / originalPos_ (blockfinder.h:52-54) after the last stage

@@ -60,6 +60,7 @@ def lib():
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_postprocess.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_serialize_graph.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_force_long_k_path.argtypes = [C.c_void_p, C.c_int]
@@ -169,6 +170,15 @@ class Oracle:
         for i in range(3):
             self.L.orc_free(tx[i])
         return out, texts
+
+    def serialize_graph(self, k: int) -> bytes:
+        v, n = C.c_void_p(), C.c_uint64()
+        rc = self.L.orc_serialize_graph(self.h, k, C.byref(v), C.byref(n))
+        if rc:
+            raise ValueError("orc_serialize_graph failed: %d" % rc)
+        t = C.string_at(v, n.value)
+        self.L.orc_free(v)
+        return t
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         v, n = C.c_void_p(), C.c_uint64()

@@ -9,7 +9,7 @@
 // into flat binary files that make_golden.py turns into committed fixtures.
 //
 // usage: ref_dump <in.fasta> <out-prefix> <cmd>...
-//   cmd = state | hash:K | blocks:K:TRIMK:MINSIZE:SHARED | write:K:TRIMK:MINSIZE:SHARED:GLUE | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
+//   cmd = state | hash:K | blocks:K:TRIMK:MINSIZE:SHARED | write:K:TRIMK:MINSIZE:SHARED:GLUE | graph:K | enum:K | stage:K:D:ITER | dot:K      (output i goes to <out-prefix>.<i>.out)
 #include "common.h"
 #include "fasta.h"
 #include "dnasequence.h"
@@ -197,6 +197,11 @@ int main(int argc, char **argv)
 			}
 			fclose(f);
 			remove(tmp.c_str());
+		}
+		else if(sscanf(argv[a], "graph:%u", &k) == 1)           // BlockFinder::SerializeGraph (src/serialization.cpp:112-138): the uncondensed graph
+		{
+			std::ofstream out((prefix + buf).c_str());
+			finder.SerializeGraph(k, out);
 		}
 		else if(sscanf(argv[a], "dot:%u", &k) == 1)
 		{

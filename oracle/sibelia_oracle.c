@@ -998,3 +998,38 @@ int orc_kmer_hashes(orc_ctx *c, uint32_t k, uint64_t **out, uint64_t *nout)
 	return 0;
 }
 void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BlockFinder::SerializeGraph (src/serialization.cpp:112-138 with OutputEdge :15-24): the UNcondensed de Bruijn graph of the
+ * current rawSeq_ as DOT text -- per chromosome, strand 0 then 1, one line per (k+1)-window in walk order:
+ *   <k-mer> -> <next k-mer> [color="blue|red", label="(chr, pos)"];
+ * characters as a StrandIterator yields them (no sanitising; negative strand complemented).  malloc'd, orc_free. */
+int orc_serialize_graph(orc_ctx *c, uint32_t k, char **out, uint64_t *nout)
+{
+	size_t cap = 1 << 16, n = 0;
+	char *t = (char *)malloc(cap);
+	char buf[256];
+#define ORC_PUT(ptr, len) do { size_t l_ = (len); while (n + l_ + 1 > cap) { cap *= 2; t = (char *)realloc(t, cap); } memcpy(t + n, (ptr), l_); n += l_; } while (0)
+	ORC_PUT("digraph G\n{\nrankdir=LR\n", strlen("digraph G\n{\nrankdir=LR\n"));
+	for (uint32_t ch = 0; ch < c->nchr; ch++)
+		for (int strand = 0; strand < 2; strand++) {
+			uint64_t len = c->len[ch];
+			for (uint64_t pos = 0; pos + k + 1 <= len; pos++) {
+				for (int part = 0; part < 2; part++) {
+					for (uint32_t i = 0; i < k; i++) {
+						uint64_t p = pos + part + i;
+						char x = (char)(strand ? orc_translate(c->seq[ch][len - 1 - p]) : c->seq[ch][p]);
+						ORC_PUT(&x, 1);
+					}
+					if (part == 0) ORC_PUT(" -> ", 4);
+				}
+				int l = snprintf(buf, sizeof buf, " [color=\"%s\", label=\"(%i, %i)\"];\n", strand ? "red" : "blue", (int)ch, (int)pos);
+				ORC_PUT(buf, (size_t)l);
+			}
+		}
+	ORC_PUT("}\n", 2);
+#undef ORC_PUT
+	t[n] = 0;
+	*out = t; *nout = n;
+	return 0;
+}

@@ -77,6 +77,9 @@ void orc_rng_copy(orc_ctx *dst, const orc_ctx *src);
 int orc_postprocess(const orc_block *in, uint64_t n, uint32_t nchr, const char *const *names, const uint64_t *sizes, int glue,
                     orc_block **out_blocks, uint64_t *nout, char **texts /* 3 */, uint64_t *text_len /* 3 */);   /* a child index shares the parent's rand() stream */
 
+/* BlockFinder::SerializeGraph (src/serialization.cpp:112-138): DOT text of the uncondensed graph; malloc'd, orc_free. */
+int orc_serialize_graph(orc_ctx *c, uint32_t k, char **out, uint64_t *n);
+
 /* test hooks */
 void orc_force_long_k_path(orc_ctx *c, int on);      /* use the rank-doubling grouping even for k <= 32 */
 uint32_t orc_rand(orc_ctx *c);                       /* next value of the ctx's glibc rand() stream   */

@@ -23,7 +23,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
-           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess"]
+           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess", "sbl_serialize_graph"]
 
 
 class StageStats(C.Structure):
@@ -79,6 +79,7 @@ def load_library():
         L.sbl_generate_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_postprocess.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        L.sbl_serialize_graph.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_kmer_hashes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.sbl_comm_unique_id.argtypes = [C.c_void_p]
         L.sbl_comm_attach_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -196,6 +197,12 @@ class BlockFinder:
         t = [C.c_char_p() for _ in range(3)]
         self._check(self.L.sbl_postprocess(self.h, int(glue), nm, C.byref(b), C.byref(n), C.byref(t[0]), C.byref(t[1]), C.byref(t[2])), "sbl_postprocess")
         return _view(b.value, n.value, formats.BLOCK_DTYPE), [x.value for x in t]
+
+    def serialize_graph(self, k: int) -> bytes:
+        """BlockFinder::SerializeGraph (reference src/blockfinder.h:41): DOT text of the uncondensed graph."""
+        t, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.sbl_serialize_graph(self.h, k, C.byref(t), C.byref(n)), "sbl_serialize_graph")
+        return C.string_at(t, n.value)
 
     def kmer_hashes(self, k: int) -> np.ndarray:
         """H0: hashes of the reference's hashing.h for every k-mer, strand 0 then 1, chromosomes ascending, walk order."""

@@ -81,6 +81,49 @@ __global__ void __launch_bounds__(256) k_kmer_hashes(const uint8_t *__restrict__
 	out[i] = h;
 }
 
+// BlockFinder::SerializeGraph (reference src/serialization.cpp:112-138, OutputEdge :15-24): DOT text of the UNcondensed graph, one
+// line per (k+1)-window, generated on the device.  Line i of [strand-major within a chromosome] has a fixed part of 2k + 35 (+1 for
+// "blue") characters and the decimal digits of (chr, pos): lengths -> exclusive scan -> every thread writes its own line.
+__device__ __forceinline__ unsigned dec_digits(unsigned v) { unsigned d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+struct GraphLine { unsigned chr, strand, pos; };
+__device__ __forceinline__ GraphLine graph_line(unsigned long long i, const unsigned long long *__restrict__ lineoff, unsigned nchr)
+{
+	// lineoff[c] = lines before chromosome c (two strands each); order: chr, strand, pos
+	unsigned lo = 0, hi = nchr;
+	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (lineoff[mid] <= i) lo = mid; else hi = mid; }
+	const unsigned long long per = (lineoff[lo + 1] - lineoff[lo]) / 2, j = i - lineoff[lo];
+	GraphLine g; g.chr = lo; g.strand = j >= per; g.pos = (unsigned)(g.strand ? j - per : j);
+	return g;
+}
+__global__ void __launch_bounds__(256) k_graph_line_len(const unsigned long long *__restrict__ lineoff, unsigned nchr, unsigned k, unsigned long long nlines, unsigned *__restrict__ len)
+{
+	unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nlines) return;
+	const GraphLine g = graph_line(i, lineoff, nchr);
+	// "<k> -> <k> [color=\"red\", label=\"(c, p)\"];\n"
+	len[i] = 2 * k + 4 + 9 + (g.strand ? 3 : 4) + 11 + dec_digits(g.chr) + 2 + dec_digits(g.pos) + 5;
+}
+__global__ void __launch_bounds__(256) k_graph_lines(const uint8_t *__restrict__ ch, const unsigned *__restrict__ sepidx, const unsigned long long *__restrict__ lineoff, unsigned nchr,
+                                                     unsigned k, unsigned long long nlines, const unsigned long long *__restrict__ textoff, char *__restrict__ text)
+{
+	unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nlines) return;
+	const GraphLine g = graph_line(i, lineoff, nchr);
+	char *o = text + textoff[i];
+	const unsigned first = sepidx[g.chr] + 1, last = sepidx[g.chr + 1] - 1;
+	auto at = [&](unsigned p) -> char {
+		uint8_t x = g.strand ? ch[last - p] : ch[first + p];
+		if (g.strand) x = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x == 'a' ? 't' : x == 't' ? 'a' : x == 'c' ? 'g' : x == 'g' ? 'c' : x;
+		return (char)x;
+	};
+	auto put = [&](const char *s) { while (*s) *o++ = *s++; };
+	auto num = [&](unsigned v) { unsigned d = dec_digits(v); for (unsigned x = d; x-- > 0;) { o[x] = (char)('0' + v % 10); v /= 10; } o += d; };
+	for (unsigned t = 0; t < k; t++) *o++ = at(g.pos + t);
+	put(" -> ");
+	for (unsigned t = 0; t < k; t++) *o++ = at(g.pos + 1 + t);
+	put(" [color=\""); put(g.strand ? "red" : "blue"); put("\", label=\"("); num(g.chr); put(", "); num(g.pos); put(")\"];\n");
+}
+
 // ------------------------------------------------------------------------------------------- helpers
 static void drop_host_state(sbl_ctx *c) { c->host_state_valid = false; }
 
@@ -454,6 +497,50 @@ extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **se
 		if (seq) *seq = c->h_seq[chr].data();
 		if (orig_pos) *orig_pos = c->h_op[chr].data();
 		if (len) *len = c->h_seq[chr].size();
+	});
+}
+
+extern "C" sbl_status sbl_serialize_graph(sbl_ctx *c, uint32_t k, const char **text, uint64_t *len)
+{
+	return guarded(c, [&] {
+		SBL_CHECK(k >= 1, SBL_ERR_BAD_ARG, "k must be at least 1");
+		hipStream_t s = c->stream;
+		std::vector<unsigned long long> off(c->nchr + 1, 0);
+		for (uint32_t ch = 0; ch < c->nchr; ch++) {
+			size_t n = c->sepidx[ch + 1] - c->sepidx[ch] - 1;
+			off[ch + 1] = off[ch] + 2 * (n >= (size_t)k + 1 ? n - k : 0);       // (k+1)-windows on both strands
+		}
+		const unsigned long long nlines = off[c->nchr];
+		const std::string head = "digraph G\n{\nrankdir=LR\n", tail = "}\n";
+		c->graph_text = head;
+		if (nlines) {
+			SBL_CHECK(nlines < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many lines");
+			DevBuf d_off, d_len, d_toff, d_text;                         // freed below (a debugging dump: no workspace kept)
+			try {
+				d_off.ensure((size_t)(c->nchr + 1) * 8); d_len.ensure((size_t)(nlines + 1) * 4); d_toff.ensure((size_t)(nlines + 1) * 8);
+				HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (size_t)(c->nchr + 1) * 8, hipMemcpyHostToDevice, s));
+				HIP_TRY(hipMemsetAsync(d_len.p, 0, (size_t)(nlines + 1) * 4, s));
+				k_graph_line_len<<<nblocks(nlines, 256), 256, 0, s>>>(d_off.as<unsigned long long>(), c->nchr, k, nlines, d_len.as<unsigned>());
+				size_t tmp = 0;
+				HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, d_len.as<unsigned>(), d_toff.as<unsigned long long>(), 0ull, (size_t)nlines + 1, rocprim::plus<unsigned long long>(), s));
+				c->d_scantmp.ensure(tmp);
+				HIP_TRY(rocprim::exclusive_scan(c->d_scantmp.p, tmp, d_len.as<unsigned>(), d_toff.as<unsigned long long>(), 0ull, (size_t)nlines + 1, rocprim::plus<unsigned long long>(), s));
+				unsigned long long total = 0;
+				HIP_TRY(hipMemcpyAsync(&total, d_toff.as<unsigned long long>() + nlines, 8, hipMemcpyDeviceToHost, s));
+				HIP_TRY(hipStreamSynchronize(s));
+				d_text.ensure(total + 16);
+				k_graph_lines<<<nblocks(nlines, 256), 256, 0, s>>>(c->d_ch.as<uint8_t>(), c->d_sepidx.as<unsigned>(), d_off.as<unsigned long long>(), c->nchr, k, nlines,
+				                                                  d_toff.as<unsigned long long>(), d_text.as<char>());
+				HIP_TRY(hipGetLastError());
+				c->graph_text.resize(head.size() + total);
+				HIP_TRY(hipMemcpyAsync(&c->graph_text[head.size()], d_text.p, total, hipMemcpyDeviceToHost, s));
+				HIP_TRY(hipStreamSynchronize(s));
+			} catch (...) { d_off.release(); d_len.release(); d_toff.release(); d_text.release(); throw; }
+			d_off.release(); d_len.release(); d_toff.release(); d_text.release();
+		}
+		c->graph_text += tail;
+		if (text) *text = c->graph_text.data();
+		if (len) *len = c->graph_text.size();
 	});
 }
 

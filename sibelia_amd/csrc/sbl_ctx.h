@@ -61,6 +61,7 @@ struct sbl_ctx {
 	std::vector<sbl_edge> edges;
 	std::vector<uint64_t> h_hashes;
 	std::vector<sbl_block> blocks;
+	std::string graph_text;              // sbl_serialize_graph
 	std::string report[3];               // sbl_postprocess: blocks_coords.txt, genomes_permutations.txt, coverage_report.txt
 
 	// ---- multi-GPU enumeration (shard.hip): attached communicator + exchange buffers

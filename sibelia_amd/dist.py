@@ -107,6 +107,9 @@ class LocalShardedFinder:
     def postprocess(self, names=None, glue=True):
         return self.ranks[0].postprocess(names, glue)
 
+    def serialize_graph(self, k):
+        return self.ranks[0].serialize_graph(k)
+
     def kmer_hashes(self, k):
         return self.ranks[0].kmer_hashes(k)
 

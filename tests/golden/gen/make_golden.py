@@ -14,6 +14,8 @@ file whose sha256 (and for tiny cases whose bytes) are stored.  Output formats:
   dot:K           text of BlockFinder::SerializeCondensedGraph(K)
   blocks:K:T:M:S  N2: BlockFinder::GenerateSyntenyBlocks(K, trimK=T, minSize=M, sharedOnly=S): u64 n, n x (i32 id, u32 chr, u64 start, u64 end)
   write:K:T:M:S:G N4: GenerateSyntenyBlocks, GlueStripes if G, then the texts of blocks_coords.txt / genomes_permutations.txt / coverage_report.txt
+  graph:K         text of BlockFinder::SerializeGraph(K) (the uncondensed graph; only for inputs whose records all hold K + 1 characters: the
+                  reference's SlidingWindow walks off the end of a shorter one)
   hash:K          H0: SlidingWindow hashes (src/hashing.h) of every K-mer of the current rawSeq_, per (strand, chr): u64 n, n x u64
 """
 import base64, gzip, hashlib, json, os, shutil, struct, subprocess, sys, tempfile
@@ -57,7 +59,7 @@ def run_case(seqs, cmds, keep_bytes=False, timeout=None):
 HAND = {
     # SURVEY.md Appendix A.1 / A.2 (SNP bulge; indel + N + reverse complement)
     "snp_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
-               ["enum:5", "dot:5", "stage:5:12:4", "enum:5", "dot:5", "hash:5", "hash:1", "hash:40", "hash:41"]),
+               ["enum:5", "dot:5", "stage:5:12:4", "enum:5", "dot:5", "hash:5", "hash:1", "hash:40", "hash:41", "graph:5", "graph:39"]),
     "indel_N_rc_k5": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC",
                        "ACGTTGCAAGGCTTATCACGGATCCATGACCTGAATCGTTAGC",
                        "GCTAACGATTCAGGTCATGGATCCGTNAGCCTTGCAACGT"],
@@ -71,7 +73,7 @@ HAND = {
                       "TTGACCAGTGCGGTCAATGCTATAGGCTAAGC", "TTGACCAGTACGGTCAATGCCATAGGCTAAGC"],
                      ["enum:4", "stage:4:10:4", "dot:4"]),
     "ambig_codes_k4": (["ACGTNNACGTRYACGTKMACGT-ACGTXACGU", "NACGTTGCAACGTNACGTTGCAAN"],
-                       ["hash:4", "blocks:4:3:6:0", "dot:4", "stage:4:8:4", "dot:4", "stage:6:12:2", "dot:6", "hash:33", "blocks:6:4:8:0"]),
+                       ["hash:4", "graph:3", "blocks:4:3:6:0", "dot:4", "stage:4:8:4", "dot:4", "stage:6:12:2", "dot:6", "hash:33", "blocks:6:4:8:0"]),
     "single_base_iter1": (["ACGTTGCAAGGCTTACGGATCCATGACCTGAATCGTTAGC", "ACGTTGCAAGGCTAACGGATCCATGACCTGAATCGTTAGC"],
                           ["stage:5:12:1", "stage:5:3:4", "stage:2:4:4", "dot:2"]),
 }
@@ -107,7 +109,7 @@ def cases(skipped):
     synth = [
         ("synth/strains4_100k", dict(L0=100_000, n=4, seed=7, **small_inv), ["enum:25", "stage:25:150:4", "enum:25", "dot:25"]),
         ("synth/strains4_100k_fine", dict(L0=100_000, n=4, seed=7, **small_inv),
-         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500", "blocks:500:30:500:0", "blocks:100:30:300:1", "write:500:30:500:0:1", "write:100:30:300:1:1"]),
+         ["stage:30:150:4", "stage:100:500:4", "stage:500:1500:4", "enum:500", "blocks:500:30:500:0", "blocks:100:30:300:1", "write:500:30:500:0:1", "write:100:30:300:1:1", "graph:21"]),
         ("synth/strains3_400k_k16", dict(L0=400_000, n=3, seed=11, inv_min=5000, inv_max=20000), ["enum:16", "stage:16:120:4", "enum:31"]),
         ("synth/strains2_4600k", dict(L0=4_600_000, n=2, seed=1), ["enum:25", "stage:25:150:4"]),
         ("synth/strains8_4600k", dict(L0=4_600_000, n=8, seed=1), ["enum:25", "stage:25:150:4"]),

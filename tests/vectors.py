@@ -65,6 +65,8 @@ def run_cmd(backend, cmd: str) -> bytes:
         names = ["seq%d" % i for i in range(len(backend.state()[0]))]      # W.write_fasta's descriptions (what the reference read)
         out, texts = backend.postprocess(blocks, names, bool(gl)) if hasattr(backend, "_orig") else backend.postprocess(names, bool(gl))
         return F.blocks_bytes(out) + b"".join(__import__("struct").pack("<Q", len(t)) + t for t in texts)
+    if p[0] == "graph":
+        return backend.serialize_graph(int(p[1]))
     if p[0] == "hash":
         k = int(p[1])
         return F.hash_bytes(backend.kmer_hashes(k), [len(x) for x in backend.state()[0]], k)

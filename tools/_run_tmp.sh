@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2m
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "bucket_overflow" > gpurun_out/r2m/ovf.log 2>&1; tail -12 gpurun_out/r2m/ovf.log
+mkdir -p gpurun_out/r2n
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_shard.py -x -q -k "snp_k5 or short_chr or ambig or strains4_100k_fine" > gpurun_out/r2n/graph.log 2>&1; tail -6 gpurun_out/r2n/graph.log
