@@ -2045,10 +2045,13 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	window = (uint32_t)std::min<size_t>(window, std::max<size_t>(64, (24ull << 30) / be.arena_bytes));
 	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
 	be.window = window;
-	st->win.ensure((size_t)window * 4 + 16);
-	st->arena.ensure((size_t)window * be.arena_bytes);
-	st->claims.ensure((size_t)window * (CLAIM_CAP + 1) * 4);
-	st->live.ensure((size_t)window + 64);
+	// the driver widens the window up to 4x while rounds are capacity-bound (simplify_driver.h); an explicit sbl_set_window pins it
+	uint32_t window_max = c->window ? window : (uint32_t)std::min<size_t>((size_t)window * 4, std::max<size_t>(window, (48ull << 30) / be.arena_bytes));
+	window_max = std::max<uint32_t>(window, std::min<uint32_t>(window_max, be.nid_ ? be.nid_ : 1));
+	st->win.ensure((size_t)window_max * 4 + 16);
+	st->arena.ensure((size_t)window_max * be.arena_bytes);
+	st->claims.ensure((size_t)window_max * (CLAIM_CAP + 1) * 4);
+	st->live.ensure((size_t)window_max + 64);
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {
@@ -2062,7 +2065,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	HIP_TRY(hipEventRecord(c->ev[3], s));
 
 	// ---- SimplifyGraph
-	SimplifyReport rep = simplify_graph(be, max_iter, window, progress, user);
+	SimplifyReport rep = simplify_graph(be, max_iter, window, progress, user, window_max);
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 
 	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays

@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2n
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_shard.py -x -q -k "snp_k5 or short_chr or ambig or strains4_100k_fine" > gpurun_out/r2n/graph.log 2>&1; tail -6 gpurun_out/r2n/graph.log
+mkdir -p gpurun_out/r2o
+for cfg in "0.15 1.0 4" "0.15 0.5 4" "0.15 0.25 4" "0.1 0.5 4" "0.15 0.5 8" "0.08 1.0 8"; do
+set -- $cfg
+SBL_KEEP_BLOCKED=$1 SBL_WMIN=$2 SBL_WMAX=$3 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/r2o/b.log 2>&1; echo -n "keep $1 wmin $2 wmax $3: "; grep '^{' gpurun_out/r2o/b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), d['config']['rounds'], {k:round(v,1) for k,v in d['phase_ms'].items() if k in ('commit_ms','probe_ms','reserve_ms')})"
+done
