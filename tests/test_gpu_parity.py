@@ -24,15 +24,16 @@ def _bulges(v):
 # Low-complexity small cases with thousands of collapses on a few hundred bases are the dense-conflict regime: the ordered
 # rounds commit one or two transactions each there, and the driver hands the pending ids to the serial chain (k_chain).
 SUPPORTED = VECS
-# Beyond 8000 collapses (k = 3 .. 10 on a few hundred bases: ids with thousands of instances, every transaction in conflict
-# with every other) a case takes 13 - 100 s on the GPU (serial chain, one wave): six of the seven run below (HUGE_RUN).
-# small/078 -- k = 3, D = 144 on 1.4 kbp, ids grow to ~4500 instances -- takes > 10 min and is left out of the GPU suite;
-# its first stage and the other six vectors also run through the product's transaction code on the host
-# (tests/test_hostsim.py::test_transactions_match_reference_on_the_densest_vectors).
+# Beyond 8000 collapses (k = 3 .. 10 on a few hundred bases: ids whose instance lists grow to tens of thousands of entries, every
+# transaction in conflict with every other) a case takes 13 - 97 s on the GPU (serial chain, one wave, O(instances) bookkeeping per
+# collapse).  The three that finish in about half a minute run below (HUGE_RUN); small/171, small/236 and small/145 (43 / 62 / 94 s)
+# are replayed bit-exact by `tools/dense_vectors.py` (profiles/r02_dense_vectors.txt) but kept out of the suite for its running
+# time, small/078 -- k = 3, D = 144 -- takes more than 10 min.  All seven (078: its first stage) also run through the product's
+# transaction code on the host (tests/test_hostsim.py::test_transactions_match_reference_on_the_densest_vectors).
 DENSE = [v for v in VECS if v["name"].startswith("small/") and 400 <= _bulges(v) < 8000]
 HUGE = [v for v in VECS if v["name"].startswith("small/") and _bulges(v) >= 8000]
 FAST = [v for v in SUPPORTED if not v["name"].startswith(("real/", "synth/strains2", "synth/strains8")) and v not in DENSE and v not in HUGE]
-HUGE_RUN = [v for v in HUGE if v["name"] != "small/078"]
+HUGE_RUN = [v for v in HUGE if v["name"] in ("small/074", "small/197", "small/126")]
 BIG = [v for v in SUPPORTED if v["name"].startswith(("real/", "synth/strains2"))]
 
 
