@@ -233,18 +233,15 @@ __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWor
 #define VT_SLOTS 512u
 struct VerdictTable { unsigned key[VT_SLOTS]; unsigned mask[VT_SLOTS]; };
 
-__device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane, bool table_ready = false)
+// one instance's marks into the verdict table: 1 = some id is now reached by two instances with different endChars, -1 = the table
+// could fill up, 0 = nothing yet.  `distinct` counts the occupied slots.
+__device__ __forceinline__ int wave_verdict_instance(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane, unsigned i, unsigned &distinct)
 {
-	if (!table_ready) {                                                // (multi-wave callers clear the table before their own barrier)
-		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-		__syncthreads();
-	}
 	const unsigned D = g.D, k = g.k;
-	unsigned distinct = 0;                                             // occupied slots (homologous instances repeat the same ids)
 	bool found = false;
-	for (unsigned i = 0; i < w.n; i++) {
+	{
 		const unsigned len = w.wlen[i];
-		if (len < k + 1) continue;                                     // endChar == ' '
+		if (len < k + 1) return 0;                                     // endChar == ' '
 		const char ec = w.wck[i];
 		const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
 		const unsigned lim = len < D ? len : D, nm = w.wmn[i], start = w.wst[i];
@@ -277,6 +274,20 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 		}
 	}
 	return __any(found) ? 1 : 0;
+}
+
+__device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork &w, VerdictTable &vt, unsigned lane, bool table_ready = false)
+{
+	if (!table_ready) {                                                // (multi-wave callers clear the table before their own barrier)
+		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+		__syncthreads();
+	}
+	unsigned distinct = 0;                                             // occupied slots (homologous instances repeat the same ids)
+	for (unsigned i = 0; i < w.n; i++) {
+		const int r = wave_verdict_instance(g, w, vt, lane, i, distinct);
+		if (r) return r;
+	}
+	return 0;
 }
 
 // ---- first snapshot of a stage: a stream over the position-ordered marks ------------------------------------------------
@@ -567,12 +578,28 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }
 	__syncthreads();
 	wave_setup(g, t, w, true, lane, ok);
-	if (ok)
-		wave_scan_all(g, w, lane, 0, tid, 3, id, wv, PROBE_WAVES);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 	__syncthreads();
-	if (wv) return;
-	int verdict = ok ? wave_verdict(g, w, vt, lane, true) : 0;
+	// windows are scanned one at a time (the next one's burst in flight) and their marks go straight into the verdict table:
+	// an entry that IS live stops at the first id two instances with different endChars reach, without scanning the rest
+	int verdict = 0;
+	if (ok) {
+		unsigned distinct = 0;
+		ScanBurst nb;
+		scan_burst_load(g, w.sel[0], w.start[0] & 1u, 0, w.ws, lane, nb);
+		for (unsigned i = 0; i < w.n && verdict == 0; i++) {
+			ScanBurst b = nb;
+			if (i + 1 < w.n) scan_burst_load(g, w.sel[i + 1], w.start[i + 1] & 1u, 0, w.ws, lane, nb);
+			wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
+			__syncthreads();
+			if (w.mk_overflow) { verdict = -1; break; }                     // more marks than the LDS list holds: the generic path below decides
+			verdict = wave_verdict_instance(g, w, vt, lane, i, distinct);
+		}
+		if (verdict < 0) {                                                // undecided by the table: every window is needed
+			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
+			__syncthreads();
+		}
+	}
 	if (lane == 0) {
 		bool has = verdict > 0;
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
