@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	__shared__ VerdictTable vt;
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
-	const unsigned wi = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const unsigned wi = blockIdx.x, lane = threadIdx.x & 63u;
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
@@ -1504,7 +1504,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
-	const unsigned id = g.win[wi], stampv = g.round_bits | wi, tid = id + 1;
+	const unsigned id = g.win[wi], stampv = g.round_bits | wi;
 	if (!solo) {
 		const unsigned *cb = claims + (size_t)wi * (CLAIM_CAP + 1);
 		unsigned n = cb[0];
