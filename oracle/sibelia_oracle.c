@@ -687,9 +687,13 @@ static void replace_direct(orc_ctx *c, sit source, size_t dS, uint32_t target, s
 
 /* CollapseBulgeGreedily = EraseBifurcations + Replace + UpdateBifurcations
  * (src/bulgeremoval.cpp:284-327, :55-95, src/dnasequence.cpp:232-252, src/bulgeremoval.cpp:238-282) */
+/* analysis hook (tools/dependency_depth.py): ORC_TRACE=<file> logs, per RemoveBulges call that has bulge groups, the instances it
+ * starts from ("T id n" + n x "I slot strand") and every collapse ("C target-slot strand dT dS"); slots = element indices */
+static FILE *orc_trace;
 static void collapse(orc_ctx *c, uint32_t k, const proxy *startKMer, vdata src, vdata tgt)
 {
 	sit t = deref(c, startKMer[tgt.kmer]), s = deref(c, startKMer[src.kmer]);
+	if (orc_trace) fprintf(orc_trace, "C %u %d %zu %zu\n", t.e, t.d, tgt.dist, src.dist);
 	sit amer, bmer, sa, sb;
 	size_t i, nlb = 0, nlf = 0, anear = 0, bnear = 0;
 	uint32_t *lb = (uint32_t *)xrealloc(0, (size_t)k * 8), *lf = (uint32_t *)xrealloc(0, (size_t)k * 8);
@@ -807,6 +811,10 @@ static size_t remove_bulges(orc_ctx *c, uint32_t k, size_t D, uint32_t bifId)
 			if (vids[p].n > 1) groups[g++] = vids[p];        /* unordered_map iteration order, :203-215 */
 	}
 	if (!ngroups) goto done;
+	if (orc_trace) {
+		fprintf(orc_trace, "T %u %zu\n", bifId, n);
+		for (i = 0; i < n; i++) { sit a = deref(c, startKMer[i]); fprintf(orc_trace, "I %u %d\n", a.e, a.d); }
+	}
 
 	for (s = 0; s < ngroups; s++) {
 		size_t idI, idJ;
@@ -863,13 +871,17 @@ static uint64_t simplify_graph(orc_ctx *c, uint32_t k, uint32_t D, uint32_t max_
 {
 	uint64_t total = 0;
 	uint32_t iterations = 0, id;
+	const char *tr = getenv("ORC_TRACE");
+	orc_trace = tr ? fopen(tr, "w") : 0;
 	do {
 		iterations++;
+		if (orc_trace) fprintf(orc_trace, "ITER %u\n", iterations);
 		for (id = 0; id <= c->bif_count; id++) {
 			total += remove_bulges(c, k, D, id);
 			if (id == 0xFFFFFFFFu) break;
 		}
 	} while (total > 0 && iterations < max_iter);
+	if (orc_trace) { fclose(orc_trace); orc_trace = 0; }
 	return total;
 }
 
