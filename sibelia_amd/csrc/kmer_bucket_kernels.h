@@ -86,10 +86,14 @@ static __global__ void __launch_bounds__(256) k_bucket_bounds(const unsigned lon
 	boff[b] = (unsigned)lo;
 }
 
-#define KB_SLOTS 2048u                          // LDS table of a bucket: 2048 x (8 + 4 + 4) B = 32 KB
-#define KB_MAX_DISTINCT 1536u
+#ifndef KB_SLOTS
+#define KB_SLOTS 1024u                          // LDS table of a bucket: 1024 x (8 + 4 + 4) B = 16 KB (9 workgroups per CU)
+#endif
+#define KB_MAX_DISTINCT (KB_SLOTS * 25u / 32u)
 #define KB_THREADS 256
-// counters: [0] pairs [1] keys [2] members [3] overflow flag
+// counters: pairs, keys, members, overflow flag -- one 128-B line each: 65 536 workgroups reserve their output ranges with returning
+// atomics, and one address (or one line) takes only ~88 of those per microsecond
+enum { KB_CTR_PAIRS = 0, KB_CTR_KEYS = 32, KB_CTR_MEM = 64, KB_CTR_FLAG = 96, KB_CTR_WORDS = 128 };
 // B3: see the header comment.  Capacities (maxpairs, maxmembers) guard the writes; the host re-runs with larger buffers / more
 // bucket bits when a counter exceeds them or the overflow flag is set.
 static __global__ void __launch_bounds__(KB_THREADS) k_bucket_classify(const unsigned long long *__restrict__ skeys, const unsigned long long *__restrict__ svals,
@@ -123,19 +127,19 @@ static __global__ void __launch_bounds__(KB_THREADS) k_bucket_classify(const uns
 		}
 	}
 	__syncthreads();
-	if (s_used > KB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[3], 1u); return; }
+	if (s_used > KB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[KB_CTR_FLAG], 1u); return; }
 	// ---- classify the distinct k-mers of the bucket
 	for (unsigned sidx = threadIdx.x; sidx < KB_SLOTS; sidx += KB_THREADS) {
 		if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx])) continue;
 		const unsigned long long canon = kmer_unhash(tkey[sidx]);
 		const unsigned nk = rc_code(canon, k) == canon ? 1u : 2u;
 		const unsigned lp = atomicAdd(&s_pairs, 1u), lk = atomicAdd(&s_keys, nk);
-		taux[sidx] = lp | (lk << 12);
+		taux[sidx] = lp | (lk << 12);                       // lp < 2^11, lk < 2^12
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		s_bpairs = s_pairs ? atomicAdd(&counters[0], s_pairs) : 0u;
-		s_bkeys = s_keys ? atomicAdd(&counters[1], s_keys) : 0u;
+		s_bpairs = s_pairs ? atomicAdd(&counters[KB_CTR_PAIRS], s_pairs) : 0u;
+		s_bkeys = s_keys ? atomicAdd(&counters[KB_CTR_KEYS], s_keys) : 0u;
 	}
 	__syncthreads();
 	if (s_pairs == 0) return;
@@ -168,7 +172,7 @@ static __global__ void __launch_bounds__(KB_THREADS) k_bucket_classify(const uns
 	__syncthreads();
 	unsigned woff = 0, total = 0;
 	for (unsigned w = 0; w < KB_THREADS / 64; w++) { if (w < wv) woff += s_wsum[w]; total += s_wsum[w]; }
-	if (threadIdx.x == 0) s_bmem = total ? atomicAdd(&counters[2], total) : 0u;
+	if (threadIdx.x == 0) s_bmem = total ? atomicAdd(&counters[KB_CTR_MEM], total) : 0u;
 	__syncthreads();
 	unsigned at = s_bmem + woff + incl - cnt;
 	for (unsigned i = lo + threadIdx.x; i < hi; i += KB_THREADS) {

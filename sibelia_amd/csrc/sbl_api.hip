@@ -216,7 +216,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	c->cur_k = k;
 	sbl_pack(c);
 	for (int i = 0; i < 2; i++) { c->d_rec_keys[i].ensure(n * 8); c->d_rec_vals[i].ensure(n * 8); }
-	c->d_counters.ensure(64 * 4);
+	c->d_counters.ensure(256 * 4);
 	unsigned long long *k0 = c->d_rec_keys[0].as<unsigned long long>(), *k1 = c->d_rec_keys[1].as<unsigned long long>();
 	unsigned long long *v0 = c->d_rec_vals[0].as<unsigned long long>(), *v1 = c->d_rec_vals[1].as<unsigned long long>();
 
@@ -227,7 +227,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 
 	// buckets of ~350-700 records (an LDS table holds KB_MAX_DISTINCT distinct k-mers); more bits if a bucket overflows
 	unsigned bits = 4;
-	while (bits < 30 && (n >> bits) > 700) bits++;
+	while (bits < 30 && (n >> bits) > KB_SLOTS * 9 / 16) bits++;
 	size_t maxpairs = n / 8 + 4096, maxmembers = n;              // capacities of the classification outputs; grown on demand
 	// test hooks: start with too few bucket bits / too small an output buffer so that the re-bucket and grow paths run
 	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));
@@ -246,13 +246,17 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			k_bucket_bounds<<<nblocks(((size_t)1 << bits) + 1, 256), 256, 0, s>>>(k1, n, bits, c->d_boff.as<unsigned>());
 		}
 		c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
-		HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64 * 4, s));
+		HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, KB_CTR_WORDS * 4, s));
 		k_bucket_classify<<<(unsigned)((size_t)1 << bits), KB_THREADS, 0, s>>>(k1, v1, c->d_boff.as<unsigned>(), k, c->d_counters.as<unsigned>(),
 		                                                                      c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), (unsigned)maxpairs,
 		                                                                      members, (unsigned)maxmembers);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(cnt, c->d_counters.p, 16, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
+		{
+			unsigned all[KB_CTR_WORDS];
+			HIP_TRY(hipMemcpyAsync(all, c->d_counters.p, sizeof all, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			cnt[0] = all[KB_CTR_PAIRS]; cnt[1] = all[KB_CTR_KEYS]; cnt[2] = all[KB_CTR_MEM]; cnt[3] = all[KB_CTR_FLAG];
+		}
 		if (cnt[3] & 1u) continue;
 		if (cnt[0] > maxpairs || (size_t)cnt[1] > 2 * maxpairs) { maxpairs = std::max<size_t>(cnt[0], ((size_t)cnt[1] + 1) / 2) + 1024; continue; }
 		break;

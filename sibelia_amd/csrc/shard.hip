@@ -342,7 +342,7 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 	c->d_counters.ensure(256 * 4);
 	unsigned *ctr = c->d_counters.as<unsigned>();
 	unsigned bits = 4;
-	while (bits < 30 && (nall >> bits) > 700) bits++;              // the same on every rank: buckets are sized by the WHOLE input
+	while (bits < 30 && (nall >> bits) > KB_SLOTS * 9 / 16) bits++;              // the same on every rank: buckets are sized by the WHOLE input
 	size_t maxpairs = nall / R / 8 + 4096;
 	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));      // test hooks, as in sbl_run_enumeration
 	if (const char *e = getenv("SBL_TEST_MAXPAIRS")) maxpairs = (size_t)std::max(1, atoi(e));
@@ -402,12 +402,14 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		bool rebucket = false;
 		for (;;) {
 			c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
-			HIP_TRY(hipMemsetAsync(ctr, 0, 64 * 4, s));
+			HIP_TRY(hipMemsetAsync(ctr, 0, KB_CTR_WORDS * 4, s));
 			k_bucket_classify<<<(unsigned)nb, KB_THREADS, 0, s>>>(ok, ov, c->d_boff.as<unsigned>(), k, ctr, c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(),
 			                                                     (unsigned)maxpairs, members, (unsigned)nrecv);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipMemcpyAsync(cnt, ctr, 16, hipMemcpyDeviceToHost, s));
+			unsigned all[KB_CTR_WORDS];
+			HIP_TRY(hipMemcpyAsync(all, ctr, sizeof all, hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipStreamSynchronize(s));
+			cnt[0] = all[KB_CTR_PAIRS]; cnt[1] = all[KB_CTR_KEYS]; cnt[2] = all[KB_CTR_MEM]; cnt[3] = all[KB_CTR_FLAG];
 			if (cnt[3] & 1u) { rebucket = true; break; }
 			if (cnt[0] > maxpairs || (size_t)cnt[1] > 2 * maxpairs) { maxpairs = std::max<size_t>(cnt[0], ((size_t)cnt[1] + 1) / 2) + 1024; continue; }
 			break;
