@@ -33,8 +33,14 @@
 #define BT_INSERT_ALIGN 1u
 __host__ __device__ __forceinline__ uint32_t bt_insert_span(uint32_t m) { return (m + BT_INSERT_ALIGN - 1u) & ~(BT_INSERT_ALIGN - 1u); }
 
-enum { CTR_NE = 0, CTR_NN = 1, CTR_ERR = 2, CTR_BULGES = 3, CTR_VIOL = 4, CTR_NWIN = 5, CTR_LO = 6, CTR_COMMITTED = 7,
-       CTR_BIG = 8, CTR_PUSHED = 9, CTR_TXN = 10, CTR_COUNT = 16 };
+// Counter block.  Every counter has a 128-byte line of its own: thousands of workgroups per launch bump them (retired entries,
+// transactions, bulges) or reserve pool ranges through them with RETURNING atomics (element / node slots of a collapse), and all
+// atomics on one line queue up behind each other in the L2 (~11 ns each) -- on one shared line a collapse waited for everybody's
+// bookkeeping.  CTR_DETAIL .. +4: first violation (kind, resource, other, id, info), debugging only.
+enum { CTR_STRIDE = 32,
+       CTR_NE = 0 * CTR_STRIDE, CTR_NN = 1 * CTR_STRIDE, CTR_ERR = 2 * CTR_STRIDE, CTR_BULGES = 3 * CTR_STRIDE, CTR_VIOL = 4 * CTR_STRIDE,
+       CTR_NWIN = 5 * CTR_STRIDE, CTR_LO = 6 * CTR_STRIDE, CTR_COMMITTED = 7 * CTR_STRIDE, CTR_BIG = 8 * CTR_STRIDE, CTR_PUSHED = 9 * CTR_STRIDE,
+       CTR_TXN = 10 * CTR_STRIDE, CTR_DETAIL = 11 * CTR_STRIDE, CTR_COUNT = 12 * CTR_STRIDE };
 enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
 
 struct GraphView {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 	if (wm > tid) bad = true;
 	if (bad) {
 		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
-		if (atomicCAS(&g.ctr[11], 0u, other != BT_NONE ? 1u : 2u) == 0u) { g.ctr[12] = r; g.ctr[13] = other != BT_NONE ? other : wm - 1; g.ctr[14] = id; g.ctr[15] = mode; }
+		if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, other != BT_NONE ? 1u : 2u) == 0u) { g.ctr[CTR_DETAIL + 1] = r; g.ctr[CTR_DETAIL + 2] = other != BT_NONE ? other : wm - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = mode; }
 	}
 }
 
@@ -877,7 +877,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 				unsigned rm = g.rmax[c];
 				if (a > tid || rm > tid) {
 					atomicMin(&g.ctr[CTR_VIOL], id);
-					if (atomicCAS(&g.ctr[11], 0u, 4u) == 0u) { g.ctr[12] = c; g.ctr[13] = (a > rm ? a : rm) - 1; g.ctr[14] = id; g.ctr[15] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
+					if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 4u) == 0u) { g.ctr[CTR_DETAIL + 1] = c; g.ctr[CTR_DETAIL + 2] = (a > rm ? a : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
 				}
 			}
 		}
@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned
 	atomicMax(&g.wmax[r], tid);
 	if (bad) {
 		atomicMin(&g.ctr[CTR_VIOL], id);
-		if (atomicCAS(&g.ctr[11], 0u, 3u) == 0u) { g.ctr[12] = r; g.ctr[13] = (wm > rm ? wm : rm) - 1; g.ctr[14] = id; g.ctr[15] = (wm > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (ow != stampv ? 4u : 0u); }
+		if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 3u) == 0u) { g.ctr[CTR_DETAIL + 1] = r; g.ctr[CTR_DETAIL + 2] = (wm > rm ? wm : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (wm > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (ow != stampv ? 4u : 0u); }
 	}
 }
 // ErasePoint (bifurcationstorage.cpp:144-155) for one (strand, element) per lane; the lazy-erase chain head lives in LDS
@@ -1728,7 +1728,8 @@ struct DeviceBackend {
 		back(st->touch, st->ck_touch, (size_t)nid_ + 1);
 		back(st->nslot, st->ck_nslot, (size_t)ck_nn * 4); back(st->nnext, st->ck_nnext, (size_t)ck_nn * 4); back(st->ndead, st->ck_ndead, ck_nn);
 		unsigned v[2] = { ck_ne, ck_nn };
-		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_NE, &v[0], 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_NN, &v[1], 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	// segment ranking of the current list (shared with the copy-back): returns the list length, leaves flag / segidx / seg_head / dist[cur] filled
@@ -1832,9 +1833,10 @@ struct DeviceBackend {
 	}
 	void clear_counters()
 	{
-		unsigned v[CTR_COUNT - 2] = {0};
-		v[CTR_VIOL - 2] = BT_NONE;
-		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + 2, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+		// everything but the pool cursors (CTR_NE, CTR_NN)
+		const unsigned none = BT_NONE;
+		HIP_TRY(hipMemsetAsync(st->ctr.as<unsigned>() + CTR_ERR, 0, (size_t)(CTR_COUNT - CTR_ERR) * 4, c->stream));
+		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_VIOL, &none, 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)

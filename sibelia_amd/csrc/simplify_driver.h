@@ -103,7 +103,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					SimplifyCounters c = be.counters();
 					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",
 					                   rep.iterations, round, lo, limit, nwin, solo, c.v[CTR_COMMITTED], c.v[CTR_BULGES], c.v[CTR_BIG], (int)c.v[CTR_VIOL], c.v[CTR_ERR]);
-					if (trace && c.v[CTR_VIOL] != BT_NONE) fprintf(stderr, "[sbl] violation detail: kind %u resource %u other %u id %u info %u\n", c.v[11], c.v[12], c.v[13], c.v[14], c.v[15]);
+					if (trace && c.v[CTR_VIOL] != BT_NONE) fprintf(stderr, "[sbl] violation detail: kind %u resource %u other %u id %u info %u\n", c.v[CTR_DETAIL], c.v[CTR_DETAIL + 1], c.v[CTR_DETAIL + 2], c.v[CTR_DETAIL + 3], c.v[CTR_DETAIL + 4]);
 					if (c.v[CTR_ERR]) {
 						if (!be.grow(c.v[CTR_ERR])) throw SblError{SBL_ERR_INTERNAL, "bulge removal: unrecoverable capacity error"};
 						replay = true; rep.grow_replays++;
