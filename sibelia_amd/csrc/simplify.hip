@@ -604,10 +604,24 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 		bool has = verdict > 0;
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
-		if (!has) { g.need[id] = 0; g.touch[id] = 0; atomicAdd(&g.ctr[CTR_COMMITTED], 1u); }   // verdict taken now: clean until somebody touches it again
+		if (!has) { g.need[id] = 0; g.touch[id] = 0; }             // verdict taken now: clean until somebody touches it again (counted by k_count_retired)
 		else if (!t.err) g.need[id] = 2;
 		live[wi] = has ? 1 : 0;
 	}
+}
+
+// Entries the probe retired (live == 0): one atomic per 1024 entries instead of one per entry on a single counter -- late in an
+// iteration a launch retires up to 65 536 entries, and an address takes ~88 atomics per microsecond.
+__global__ void __launch_bounds__(256) k_count_retired(const uint8_t *__restrict__ live, unsigned nwin, unsigned *__restrict__ counter)
+{
+	unsigned base = blockIdx.x * 1024 + threadIdx.x * 4, c = 0;
+	for (unsigned i = 0; i < 4; i++) c += base + i < nwin && live[base + i] == 0;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+	__shared__ unsigned s[4];
+	if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) { unsigned t = s[0] + s[1] + s[2] + s[3]; if (t) atomicAdd(counter, t); }
 }
 
 // The lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window (and runs alone if it is the lowest).
@@ -1856,6 +1870,7 @@ struct DeviceBackend {
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		HIP_TRY(hipEventRecord(ev[4], c->stream));
 		k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
+		k_count_retired<<<(nwin + 1023) / 1024, 256, 0, c->stream>>>(st->live.as<uint8_t>(), nwin, g.ctr + CTR_COMMITTED);
 		HIP_TRY(hipEventRecord(ev[5], c->stream));
 		timed_probe = true;
 		HIP_TRY(hipGetLastError());
