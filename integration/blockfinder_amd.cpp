@@ -1,0 +1,89 @@
+// blockfinder_amd.cpp -- the reference-side binding of INTEGRATION.md as a real translation unit.
+//
+// Defines the PUBLIC members of the reference's own class SyntenyFinder::BlockFinder (declared in the reference's unmodified
+// src/blockfinder.h:28-45) on top of libsibelia_amd.so.  Linked INSTEAD of the reference's blockfinder.cpp, bulgeremoval.cpp,
+// edge.cpp, serialization.cpp and synteny.cpp, it turns the reference's program (src/sibelia.cpp: command line, FASTA reader,
+// post-processor, output writers -- all unchanged) into one whose BlockFinder runs on the MI355X.  oracle/build_dropin.sh
+// builds that program into oracle/_ref/ (it contains reference objects, so it is never committed);
+// tests/test_gpu_dropin.py runs it on the GPU box and compares every output file with what the unmodified reference wrote.
+//
+// The header is not touched: the device context of a BlockFinder lives in a side table keyed by `this` (a maintainer would add a
+// member `sbl_ctx * amd_` instead and release it in a destructor; the class has none, so the table entry lives as long as the
+// process, like the reference's own object inside main's auto_ptr).
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "blockfinder.h"                      // the reference's (-I <reference>/src)
+#include "sibelia_amd/blockfinder.hpp"        // the C ABI + a thin C++ wrapper (this repository's include/)
+
+namespace
+{
+	typedef SyntenyFinderAMD::BlockFinder Device;
+	std::mutex tableLock;
+	std::map<const SyntenyFinder::BlockFinder *, std::unique_ptr<Device> > table;
+
+	Device & Of(const SyntenyFinder::BlockFinder * self)
+	{
+		std::lock_guard<std::mutex> hold(tableLock);
+		return *table.at(self);
+	}
+
+	// boost::function<void(size_t, State)> of the reference -> std::function<void(size_t, State)> of the wrapper
+	Device::ProgressCallBack Adapt(SyntenyFinder::BlockFinder::ProgressCallBack f)
+	{
+		if (f.empty()) return Device::ProgressCallBack();
+		return [f](size_t progress, Device::State state) { f(progress, static_cast<SyntenyFinder::BlockFinder::State>(state)); };
+	}
+}
+
+namespace SyntenyFinder
+{
+	const char BlockFinder::SEPARATION_CHAR = '#';
+	const char BlockFinder::POS_FREE = 0;
+	const char BlockFinder::POS_OCCUPIED = 1;
+
+	BlockFinder::BlockFinder(const std::vector<FASTARecord> & chrList): iseq_(0), originalChrList_(&chrList)
+	{
+		Init(chrList);
+	}
+
+	// tempDir: the reference spills its suffix array there unless -r is given; nothing is spilled here
+	BlockFinder::BlockFinder(const std::vector<FASTARecord> & chrList, const std::string & tempDir): tempDir_(tempDir), iseq_(0), originalChrList_(&chrList)
+	{
+		Init(chrList);
+	}
+
+	void BlockFinder::Init(const std::vector<FASTARecord> & chrList)
+	{
+		std::unique_ptr<Device> device(new Device(chrList));          // sbl_create + sbl_load: throws std::runtime_error without an MI355X
+		std::lock_guard<std::mutex> hold(tableLock);
+		table[this] = std::move(device);
+	}
+
+	size_t BlockFinder::PerformGraphSimplifications(size_t k, size_t minBranchSize, size_t maxIterations, ProgressCallBack f)
+	{
+		return Of(this).PerformGraphSimplifications(k, minBranchSize, maxIterations, Adapt(f));
+	}
+
+	void BlockFinder::GenerateSyntenyBlocks(size_t k, size_t trimK, size_t minSize, std::vector<BlockInstance> & block, bool sharedOnly, ProgressCallBack f)
+	{
+		std::vector<SyntenyFinderAMD::BlockInstance> found;
+		Of(this).GenerateSyntenyBlocks(k, trimK, minSize, found, sharedOnly, Adapt(f));
+		block.clear();
+		for (size_t i = 0; i < found.size(); i++)
+		{
+			block.push_back(BlockInstance(found[i].id, &(*originalChrList_)[found[i].chr], found[i].start, found[i].end));
+		}
+	}
+
+	void BlockFinder::SerializeCondensedGraph(size_t k, std::ostream & out, ProgressCallBack f)
+	{
+		Of(this).SerializeCondensedGraph(k, out, Adapt(f));
+	}
+
+	void BlockFinder::SerializeGraph(size_t k, std::ostream & out)
+	{
+		Of(this).SerializeGraph(k, out);
+	}
+}

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Fixtures for tests/test_gpu_dropin.py: the UNMODIFIED reference program (oracle/_ref/sibelia_ref, built by
+oracle/build_dropin.sh from /root/reference) is run on the committed example inputs; the sha256 of every file it writes and of
+its standard output go to tests/golden/dropin_cases.json.  Run in the build container (needs /root/reference): CPU only."""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+REF = os.path.join(ROOT, "oracle", "_ref", "sibelia_ref")
+
+# name, input (tests/golden/data/<input>.fa.gz), arguments between the program name and "-o out <input>.fa"
+CASES = [
+    ("hpylori_loose_inram_sequences", "Helicobacter_pylori", ["-s", "loose", "-r", "-q"]),
+    ("hpylori_fine_allstages_graphs", "Helicobacter_pylori", ["-s", "fine", "--allstages", "-g", "-r", "-m", "2000"]),
+    ("hpylori_far_hierarchy", "Helicobacter_pylori", ["-s", "far", "-v", "-r"]),
+    ("saureus_loose_gff_sharedonly_tempfiles", "Staphylococcus_aureus_pair", ["-s", "loose", "--gff", "-a"]),
+    ("saureus_fine_nopostprocess_lastk", "Staphylococcus_aureus_pair", ["-s", "fine", "-r", "--nopostprocess", "--lastk", "200", "-m", "1000", "-i", "2"]),
+]
+
+
+def run_case(program, inp, args, workdir, env=None):
+    """-> (returncode, sha256 of stdout, {relative path: [size, sha256]})"""
+    fa = inp + ".fa"
+    with gzip.open(os.path.join(DATA, inp + ".fa.gz"), "rb") as f, open(os.path.join(workdir, fa), "wb") as g:
+        shutil.copyfileobj(f, g)
+    p = subprocess.run([program] + args + ["-o", "out", fa], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=3600)
+    files = {}
+    for d, _, names in os.walk(os.path.join(workdir, "out")):
+        for n in names:
+            path = os.path.join(d, n)
+            b = open(path, "rb").read()
+            files[os.path.relpath(path, os.path.join(workdir, "out"))] = [len(b), hashlib.sha256(b).hexdigest()]
+    return p.returncode, hashlib.sha256(p.stdout).hexdigest(), files, p.stdout, p.stderr
+
+
+if __name__ == "__main__":
+    if not os.path.exists(REF):
+        sys.exit("build oracle/_ref/sibelia_ref first: bash oracle/build_dropin.sh")
+    out = {"generator": "tests/golden/gen/make_dropin_golden.py", "program": "oracle/_ref/sibelia_ref (unmodified reference, oracle/build_dropin.sh)", "cases": []}
+    for name, inp, args in CASES:
+        with tempfile.TemporaryDirectory() as wd:
+            rc, so, files, stdout, stderr = run_case(REF, inp, args, wd)
+        print(name, "rc", rc, len(files), "files", file=sys.stderr)
+        out["cases"].append({"name": name, "input": inp, "args": args, "returncode": rc, "stdout_sha256": so, "stdout_bytes": len(stdout), "files": files})
+    with open(os.path.join(ROOT, "tests", "golden", "dropin_cases.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)

@@ -45,3 +45,22 @@ def test_fixture_is_what_the_reference_build_produces(v, tmp_path):
     for i, o in enumerate(v["outputs"]):
         b = open(str(tmp_path / ("o.%d.out" % i)), "rb").read()
         assert len(b) == o["size"] and hashlib.sha256(b).hexdigest() == o["sha256"], (v["name"], o["cmd"])
+
+
+def test_reference_program_over_the_library_fails_loudly_without_a_gpu(tmp_path):
+    """oracle/_ref/sibelia_dropin (tests/test_gpu_dropin.py) is the reference's main over libsibelia_amd.so: here, without a device,
+    it must stop with the library's error through the reference's own catch block -- no CPU path behind the binding."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_dropin.py runs the program for real")
+    dropin = os.path.join(ROOT, "oracle", "_ref", "sibelia_dropin")
+    if not os.path.exists(dropin):
+        if not os.path.isdir("/root/reference/src"):
+            pytest.skip("no oracle/_ref/sibelia_dropin and no /root/reference to build it from")
+        subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_dropin.sh")], check=True, capture_output=True)
+    fa = tmp_path / "two.fa"
+    fa.write_text(">a\n" + "ACGTTGCAAGGCTTAACCGGTTAGCATCGATCGGATCGATTAGC" * 40 + "\n>b\n" + "ACGTTGCAAGGCTTAACCGGTTAGCATCGATCGGATCGATTAGC" * 40 + "\n")
+    p = subprocess.run([dropin, "-s", "loose", "-r", "-o", str(tmp_path / "out"), str(fa)], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert "no usable HIP device" in (p.stdout + p.stderr)
+    assert not (tmp_path / "out" / "blocks_coords.txt").exists()
