@@ -74,15 +74,10 @@ def main():
     # in the same line under "replicas" (or as the headline with --replicas)
     if world > 1 and not a.replicas:
         a.shard_enum = True
+    os.environ.setdefault("SBL_COMM_TIMEOUT_S", "90")      # a rank that waits for a failed peer gives up (communicator aborted) instead of hanging the bench
     seqs = W.gen_strains(**D.rank_workload(0 if a.shard_enum else rank, a.strains, a.L0))
     N = W.strand_kmers(seqs, a.k)
     bf = BlockFinder(seqs, device=local)
-    if a.shard_enum:
-        if world > 1:
-            D.attach(bf, device=torch.device("cuda", local))
-        else:
-            from sibelia_amd.api import comm_unique_id
-            bf.attach_rccl(0, 1, comm_unique_id())
     if a.window:
         bf.set_window(a.window)
     bf.save_state()
@@ -90,6 +85,42 @@ def main():
     def step():
         bf.restore_state()
         return bf.PerformGraphSimplifications(a.k, a.D, a.iters)
+
+    # The sharded configuration is a collective over RCCL: attach + one trial stage are guarded, and the ranks agree on the outcome.
+    # If any rank failed, every rank falls back to the replicas configuration and the line says why ("sharded_error").
+    shard_error = None
+    if a.shard_enum:
+        try:
+            if world > 1:
+                D.attach(bf, device=torch.device("cuda", local))
+            else:
+                from sibelia_amd.api import comm_unique_id
+                bf.attach_rccl(0, 1, comm_unique_id())
+            if world > 1:
+                step()
+        except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+            shard_error = "rank %d: %s" % (rank, e)
+        if world > 1:
+            flag = torch.tensor([1 if shard_error else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                errs = [None] * world
+                dist.all_gather_object(errs, shard_error)
+                shard_error = "; ".join(e for e in errs if e) or "a peer rank failed"
+                try:
+                    bf.detach()
+                except Exception:      # noqa: BLE001
+                    pass
+                bf.close()
+                a.shard_enum = False
+                seqs = W.gen_strains(**D.rank_workload(rank, a.strains, a.L0))
+                N = W.strand_kmers(seqs, a.k)
+                bf = BlockFinder(seqs, device=local)
+                if a.window:
+                    bf.set_window(a.window)
+                bf.save_state()
+        elif shard_error:
+            raise SystemExit("sharded enumeration failed: " + shard_error)
 
     for _ in range(a.warmup):
         step()
@@ -189,6 +220,8 @@ def main():
         }
         if replicas is not None:
             out["replicas"] = replicas
+        if shard_error:
+            out["sharded_error"] = shard_error
         if world == 1:
             # PCIe-inclusive rate (never `value`): host buffers -> device (sbl_load: 1 B/base over PCIe; original positions and the
             # ambiguity scan are derived on the device) + one stage + the state back to the host (5 B/base)

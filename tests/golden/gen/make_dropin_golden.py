@@ -16,21 +16,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 REF = os.path.join(ROOT, "oracle", "_ref", "sibelia_ref")
 
-# name, input (tests/golden/data/<input>.fa.gz), arguments between the program name and "-o out <input>.fa"
+# name, input (tests/golden/data/<input>.fa.gz, or "synth:L0:n:seed" = sibelia_amd.workloads.gen_strains written as FASTA),
+# arguments between the program name and "-o out <input>.fa"
 CASES = [
     ("hpylori_loose_inram_sequences", "Helicobacter_pylori", ["-s", "loose", "-r", "-q"]),
     ("hpylori_fine_allstages_graphs", "Helicobacter_pylori", ["-s", "fine", "--allstages", "-g", "-r", "-m", "2000"]),
     ("hpylori_far_hierarchy", "Helicobacter_pylori", ["-s", "far", "-v", "-r"]),
     ("saureus_loose_gff_sharedonly_tempfiles", "Staphylococcus_aureus_pair", ["-s", "loose", "--gff", "-a"]),
+    # BASELINE.json config 3 (8 genomes x 4.6 Mbp, -s fine) through the reference's own main: ~12 min for the reference (--big)
+    ("synth8_4600k_fine_config3", "synth:4600000:8:1", ["-s", "fine", "-r"]),
     ("saureus_fine_nopostprocess_lastk", "Staphylococcus_aureus_pair", ["-s", "fine", "-r", "--nopostprocess", "--lastk", "200", "-m", "1000", "-i", "2"]),
 ]
 
 
 def run_case(program, inp, args, workdir, env=None):
     """-> (returncode, sha256 of stdout, {relative path: [size, sha256]})"""
-    fa = inp + ".fa"
-    with gzip.open(os.path.join(DATA, inp + ".fa.gz"), "rb") as f, open(os.path.join(workdir, fa), "wb") as g:
-        shutil.copyfileobj(f, g)
+    if inp.startswith("synth:"):
+        sys.path.insert(0, ROOT)
+        from sibelia_amd import workloads as W
+        _, L0, n, seed = inp.split(":")
+        fa = "synth.fa"
+        with open(os.path.join(workdir, fa), "wb") as g:
+            for i, s in enumerate(W.gen_strains(L0=int(L0), n=int(n), seed=int(seed))):
+                b = s if isinstance(s, bytes) else s.encode()
+                g.write(b">strain%d synthetic\n" % i)
+                for o in range(0, len(b), 80):
+                    g.write(b[o:o + 80] + b"\n")
+    else:
+        fa = inp + ".fa"
+        with gzip.open(os.path.join(DATA, inp + ".fa.gz"), "rb") as f, open(os.path.join(workdir, fa), "wb") as g:
+            shutil.copyfileobj(f, g)
     p = subprocess.run([program] + args + ["-o", "out", fa], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=3600)
     files = {}
     for d, _, names in os.walk(os.path.join(workdir, "out")):
@@ -45,10 +60,19 @@ if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("build oracle/_ref/sibelia_ref first: bash oracle/build_dropin.sh")
     out = {"generator": "tests/golden/gen/make_dropin_golden.py", "program": "oracle/_ref/sibelia_ref (unmodified reference, oracle/build_dropin.sh)", "cases": []}
+    path = os.path.join(ROOT, "tests", "golden", "dropin_cases.json")
+    old = {c["name"]: c for c in json.load(open(path))["cases"]} if os.path.exists(path) else {}
     for name, inp, args in CASES:
+        if inp.startswith("synth:") and "--big" not in sys.argv:      # keep what an earlier --big run wrote
+            if name in old:
+                out["cases"].append(old[name])
+            continue
+        if "--only-big" in sys.argv and not inp.startswith("synth:") and name in old:
+            out["cases"].append(old[name])
+            continue
         with tempfile.TemporaryDirectory() as wd:
             rc, so, files, stdout, stderr = run_case(REF, inp, args, wd)
         print(name, "rc", rc, len(files), "files", file=sys.stderr)
         out["cases"].append({"name": name, "input": inp, "args": args, "returncode": rc, "stdout_sha256": so, "stdout_bytes": len(stdout), "files": files})
-    with open(os.path.join(ROOT, "tests", "golden", "dropin_cases.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
