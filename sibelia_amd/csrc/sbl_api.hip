@@ -340,6 +340,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->child) { sbl_destroy(c->child); c->child = nullptr; }
+	if (c->tiny_out) { (void)hipHostFree(c->tiny_out); c->tiny_out = nullptr; }
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);

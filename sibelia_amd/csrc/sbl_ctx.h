@@ -27,6 +27,7 @@ struct sbl_ctx {
 	DevBuf d_orig_ch;
 	std::vector<uint32_t> orig_sepidx;
 	sbl_ctx *child = nullptr;            // index over block sequences (TrimBlocks), same device
+	void *tiny_out = nullptr;            // mapped host buffer of the small-block index (synteny.hip), hipHostFree'd with the context
 
 	// stage-boundary checkpoint (sbl_save_state / sbl_restore_state)
 	DevBuf d_save_ch, d_save_op;

@@ -14,6 +14,7 @@
 #include <numeric>
 
 #include "sbl_ctx.h"
+#include "kmer_kernels.h"       // rc_code, mask_is_bifurcation
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
@@ -26,6 +27,132 @@ __global__ void __launch_bounds__(256) k_gather_blocks(const uint8_t *__restrict
 		for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.len; i += (unsigned long long)gridDim.x * blockDim.x)
 			out[d.dst + i] = orig[d.src + i];
 	}
+}
+
+// ---- index over a SMALL block (TrimBlocks at small k: tens of thousands of candidate blocks of a few dozen bases) -------------
+// The general child index costs ~38 launches and ~10 host synchronisations whatever its size.  Blocks of at most TE_MAX_ELEM
+// elements in at most TE_MAX_REC sequences, trimK <= 32, are indexed by ONE workgroup in ONE launch instead: gather from the
+// original records, canonical codes, LDS table of the distinct k-mers with their merged neighbour masks, Bifurcation() test, id =
+// rank of the code among the bifurcation codes of both orientations, instance lists in element order -- the definitions of
+// kmer_bucket_kernels.h (k_kmer_records / k_bucket_classify / k_scatter_ids / k_scatter_members / k_make_instances) applied in LDS.
+// The result goes straight into mapped host memory.  A character other than A, C, G, T (the general path draws rand() for
+// those) makes the kernel decline (status 1) and the caller takes the general path.
+#define TE_MAX_ELEM 1024u
+#define TE_MAX_REC 16u
+#define TE_SLOTS 2048u
+#define TE_THREADS 256u
+struct TinyDesc { unsigned nrec, k; unsigned long long src[TE_MAX_REC]; unsigned len[TE_MAX_REC]; };
+struct TinyOut { unsigned status, bif_count, n[2], pad[4]; unsigned inst[2][TE_MAX_ELEM * 3]; };
+__global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate(const uint8_t *__restrict__ orig, TinyDesc d, TinyOut *__restrict__ out)
+{
+	__shared__ uint8_t ch[TE_MAX_ELEM + 8];
+	__shared__ unsigned short pslot[TE_MAX_ELEM];             // table slot of the k-mer starting at g | orientation flags << 12 ... see below
+	__shared__ uint8_t pfl[TE_MAX_ELEM];
+	__shared__ unsigned sep[TE_MAX_REC + 1];
+	__shared__ unsigned long long tkey[TE_SLOTS];
+	__shared__ unsigned tmask[TE_SLOTS];
+	__shared__ unsigned short taux[TE_SLOTS];
+	__shared__ unsigned long long keys[TE_SLOTS];
+	__shared__ unsigned short payload[TE_SLOTS], pairids[TE_SLOTS];
+	__shared__ unsigned s_bad, s_pairs, s_keys, s_wsum[2][TE_THREADS / 64];
+	const unsigned tid = threadIdx.x, k = d.k, lane = tid & 63u, wv = tid >> 6;
+	if (tid == 0) {
+		unsigned e = 0;
+		for (unsigned r = 0; r < d.nrec; r++) { sep[r] = e; e += d.len[r] + 1; }
+		sep[d.nrec] = e;
+		s_bad = 0; s_pairs = 0; s_keys = 0;
+	}
+	for (unsigned i = tid; i < TE_SLOTS; i += TE_THREADS) { tkey[i] = ~0ull; tmask[i] = 0; taux[i] = 0xFFFFu; }
+	__syncthreads();
+	const unsigned E = sep[d.nrec] + 1;
+	// ---- gather: '$' b0 '$' b1 '$' ...
+	for (unsigned e = tid; e < E; e += TE_THREADS) {
+		unsigned r = 0;
+		while (r + 1 <= d.nrec && sep[r + 1] <= e) r++;                                  // sep[r] <= e < sep[r + 1] (r == nrec: the last separator)
+		uint8_t c = '$';
+		if (r < d.nrec && e != sep[r]) {
+			c = orig[d.src[r] + (e - sep[r] - 1)];
+			if (c != 'A' && c != 'C' && c != 'G' && c != 'T') s_bad = 1;
+		}
+		ch[e] = c;
+	}
+	__syncthreads();
+	if (s_bad) { if (tid == 0) out->status = 1; return; }
+	auto base = [&](unsigned e) -> unsigned { unsigned x = (ch[e] >> 1) & 3u; return x ^ (x >> 1); };      // A:0 C:1 G:2 T:3 (k_pack2bit)
+	// ---- records: canonical code, neighbour masks in canonical orientation (k_kmer_records), merged per distinct k-mer in the LDS table
+	for (unsigned g = tid; g < E; g += TE_THREADS) {
+		unsigned short slot = 0xFFFFu;
+		uint8_t fl = 0;
+		bool valid = g + k < E;                                                          // the element after the window exists (the last one is '$')
+		for (unsigned i = 0; valid && i < k; i++) if (ch[g + i] == '$') valid = false;
+		if (valid) {
+			unsigned long long fwd = 0, rev = 0;
+			for (unsigned i = 0; i < k; i++) {
+				const unsigned long long b = base(g + i);
+				fwd = (fwd << 2) | b;
+				rev |= (3ull - b) << (2 * i);
+			}
+			const unsigned ps = ch[g - 1] == '$' ? 4u : base(g - 1), ns = ch[g + k] == '$' ? 4u : base(g + k);
+			unsigned m = 0;
+			if (fwd <= rev) { m |= (1u << ps) | (1u << (8 + ns)); fl |= 1u; }
+			if (rev <= fwd) { m |= (1u << (ns == 4 ? 4 : 3 - ns)) | (1u << (8 + (ps == 4 ? 4 : 3 - ps))); fl |= 2u; }
+			const unsigned long long canon = fwd < rev ? fwd : rev;
+			unsigned h = (unsigned)((canon * 0x9E3779B97F4A7C15ull) >> 53) & (TE_SLOTS - 1);
+			for (;;) {
+				unsigned long long old = atomicCAS(&tkey[h], ~0ull, canon);
+				if (old == ~0ull || old == canon) { atomicOr(&tmask[h], m); break; }
+				h = (h + 1) & (TE_SLOTS - 1);
+			}
+			slot = (unsigned short)h;
+		}
+		pslot[g] = slot; pfl[g] = fl;
+	}
+	__syncthreads();
+	// ---- Bifurcation() per distinct k-mer; the codes of both orientations (a palindrome once) are the keys of the ranking
+	for (unsigned h = tid; h < TE_SLOTS; h += TE_THREADS) {
+		if (tkey[h] == ~0ull || !mask_is_bifurcation(tmask[h])) continue;
+		const unsigned long long canon = tkey[h], r = rc_code(canon, k);
+		const unsigned nk = r == canon ? 1u : 2u;
+		const unsigned lp = atomicAdd(&s_pairs, 1u), lk = atomicAdd(&s_keys, nk);
+		keys[lk] = canon; payload[lk] = (unsigned short)(2 * lp);
+		if (nk == 2) { keys[lk + 1] = r; payload[lk + 1] = (unsigned short)(2 * lp + 1); }
+		taux[h] = (unsigned short)lp;
+	}
+	__syncthreads();
+	const unsigned nkeys = s_keys;
+	for (unsigned i = tid; i < nkeys; i += TE_THREADS) {                                 // id = rank of the code (the keys are distinct)
+		const unsigned long long mine = keys[i];
+		unsigned rank = 0;
+		for (unsigned j = 0; j < nkeys; j++) rank += keys[j] < mine;
+		const unsigned p = payload[i];
+		pairids[p] = (unsigned short)rank;
+		if (!(p & 1u) && rc_code(mine, k) == mine) pairids[p + 1] = (unsigned short)rank;
+	}
+	__syncthreads();
+	// ---- instance lists in element order: + strand element g, - strand element g + k - 1 (k_scatter_members / k_make_instances)
+	const unsigned per = (E + TE_THREADS - 1) / TE_THREADS, g0 = tid * per, g1 = g0 + per < E ? g0 + per : E;
+	unsigned cnt = 0;
+	for (unsigned g = g0; g < g1; g++) cnt += pslot[g] != 0xFFFFu && taux[pslot[g]] != 0xFFFFu;
+	unsigned incl = cnt;
+#pragma unroll
+	for (int dd = 1; dd < 64; dd <<= 1) { unsigned x = __shfl_up(incl, dd); if (lane >= (unsigned)dd) incl += x; }
+	if (lane == 63) s_wsum[0][wv] = incl;
+	__syncthreads();
+	unsigned off = incl - cnt, total = 0;
+	for (unsigned w = 0; w < TE_THREADS / 64; w++) { if (w < wv) off += s_wsum[0][w]; total += s_wsum[0][w]; }
+	for (unsigned g = g0; g < g1; g++) {
+		if (pslot[g] == 0xFFFFu) continue;
+		const unsigned lp = taux[pslot[g]];
+		if (lp == 0xFFFFu) continue;
+		const unsigned p = 2 * lp + ((pfl[g] & 1u) ? 0u : 1u);
+		unsigned r = 0;
+		while (sep[r + 1] <= g) r++;
+		out->inst[0][3 * off] = pairids[p]; out->inst[0][3 * off + 1] = r; out->inst[0][3 * off + 2] = g - sep[r] - 1;
+		const unsigned e1 = g + k - 1;
+		out->inst[1][3 * off] = pairids[p ^ 1u]; out->inst[1][3 * off + 1] = r; out->inst[1][3 * off + 2] = sep[r + 1] - 1 - e1;
+		off++;
+	}
+	if (tid == 0) { out->bif_count = nkeys; out->n[0] = total; out->n[1] = total; out->status = 0; }
 }
 
 namespace {
@@ -78,12 +205,48 @@ struct Synteny {
 		undo.clear();
 	}
 
+	// small blocks: one workgroup, one launch, result in mapped host memory (k_tiny_enumerate); false = not applicable, take the general path
+	TinyOut *tiny_out = nullptr, *tiny_out_dev = nullptr;
+	std::vector<sbl_inst> tiny_neg;
+	bool tiny_index(const std::vector<BEdge> &block, uint64_t L, uint32_t *bif_count, const sbl_inst **inst, uint64_t *ninst)
+	{
+		const uint32_t nrec = (uint32_t)block.size();
+		if (!tiny_out || trimK > 32 || nrec > TE_MAX_REC || L + nrec + 1 > TE_MAX_ELEM) return false;
+		TinyDesc d;
+		d.nrec = nrec; d.k = trimK;
+		for (uint32_t i = 0; i < nrec; i++) {
+			d.src[i] = (unsigned long long)c->orig_sepidx[block[i].chr] + 1 + block[i].origPos;
+			d.len[i] = (unsigned)block[i].origLen;
+		}
+		tiny_out->status = 2;
+		k_tiny_enumerate<<<1, TE_THREADS, 0, c->stream>>>(c->d_orig_ch.as<uint8_t>(), d, tiny_out_dev);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (tiny_out->status == 1) return false;                   // a non-ACGT character: the general path draws rand() for it
+		SBL_CHECK(tiny_out->status == 0, SBL_ERR_INTERNAL, "small-block index did not report");
+		const unsigned n = tiny_out->n[0];
+		// the negative list is reported per sequence in descending element order (sbl_enumerate: each chromosome's run reversed)
+		const sbl_inst *neg = reinterpret_cast<const sbl_inst *>(tiny_out->inst[1]);
+		tiny_neg.assign(neg, neg + n);
+		for (size_t a = 0; a < tiny_neg.size();) {
+			size_t b = a;
+			while (b < tiny_neg.size() && tiny_neg[b].chr == tiny_neg[a].chr) b++;
+			std::reverse(tiny_neg.begin() + a, tiny_neg.begin() + b);
+			a = b;
+		}
+		*bif_count = tiny_out->bif_count;
+		inst[0] = reinterpret_cast<const sbl_inst *>(tiny_out->inst[0]); inst[1] = tiny_neg.data();
+		ninst[0] = n; ninst[1] = n;
+		return true;
+	}
+
 	// a fresh index at trimK over the block sequences (IndexedSequence iseq(blockSeq, trimK, ""), synteny.cpp:44): on the GPU
 	void child_index(const std::vector<BEdge> &block, uint32_t *bif_count, const sbl_inst **inst, uint64_t *ninst)
 	{
 		const uint32_t nrec = (uint32_t)block.size();
 		uint64_t L = 0;
 		for (auto &b : block) L += b.origLen;
+		if (tiny_index(block, L, bif_count, inst, ninst)) return;
 		const size_t E = (size_t)L + nrec + 1, Epad = (E + 31) / 32 * 32 + 64;
 		hipStream_t s = child->stream;
 		child->d_ch.ensure(Epad);
@@ -213,6 +376,16 @@ extern "C" sbl_status sbl_generate_blocks(sbl_ctx *c, uint32_t k, uint32_t trim_
 			if (cs != SBL_OK) throw SblError{cs, "cannot create the trim context"};
 		}
 		sy.child = c->child;
+		if (!c->tiny_out && !getenv("SBL_NO_TINY_INDEX")) {          // mapped host buffer of the small-block index, owned by the context
+			void *h = nullptr;
+			HIP_TRY(hipHostMalloc(&h, sizeof(TinyOut), hipHostMallocMapped));
+			c->tiny_out = h;
+		}
+		if (c->tiny_out && !getenv("SBL_NO_TINY_INDEX")) {
+			void *dv = nullptr;
+			HIP_TRY(hipHostGetDevicePointer(&dv, c->tiny_out, 0));
+			sy.tiny_out = static_cast<TinyOut *>(c->tiny_out); sy.tiny_out_dev = static_cast<TinyOut *>(dv);
+		}
 		sy.occupied.resize(c->nchr); sy.local.resize(c->nchr);
 		for (uint32_t i = 0; i < c->nchr; i++) {
 			const size_t len = c->orig_sepidx[i + 1] - c->orig_sepidx[i] - 1;          // originalSize_

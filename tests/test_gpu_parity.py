@@ -323,3 +323,26 @@ def test_bucket_overflow_and_buffer_growth_paths(monkeypatch):
         got = bf.enumerate(20)
         assert got[0] == want[0] and (got[1] == want[1]).all() and (got[2] == want[2]).all()
         bf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,L0,k", [(11, 3, 20_000, 12), (12, 5, 8_000, 9), (13, 2, 40_000, 15), (14, 4, 6_000, 32), (15, 3, 5_000, 5)])
+def test_small_block_index_equals_the_general_child_index(seed, n, L0, k):
+    # GenerateSyntenyBlocks(k, k, k) on the raw graph (what -v / --allstages do): thousands of tiny candidate blocks, indexed by
+    # k_tiny_enumerate (one launch each); SBL_NO_TINY_INDEX=1 sends them through the general child enumeration; the oracle is third
+    import os
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=0.03, indel_every=300, inv_min=200, inv_max=800)
+    if seed == 12:      # non-ACGT characters inside candidate blocks: the small-block kernel must decline and leave rand() to the general path
+        seqs = [s[:1000] + b"N" + s[1001:3000] + b"RY" + s[3002:] for s in seqs]
+    a = _bf(seqs).generate_blocks(k, k, k)
+    os.environ["SBL_NO_TINY_INDEX"] = "1"
+    try:
+        b = _bf(seqs).generate_blocks(k, k, k)
+    finally:
+        del os.environ["SBL_NO_TINY_INDEX"]
+    c = Oracle(seqs).generate_blocks(k, k, k)
+    assert len(a) == len(b) == len(c) and len(a) > 0
+    for f in ("id", "chr", "start", "end"):
+        assert (a[f] == b[f]).all() and (a[f] == c[f]).all()
