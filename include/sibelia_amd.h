@@ -133,6 +133,12 @@ sbl_status sbl_generate_blocks(sbl_ctx *ctx, uint32_t k, uint32_t trim_k, uint32
 sbl_status sbl_postprocess(sbl_ctx *ctx, int glue, const char *const *names, const sbl_block **blocks, uint64_t *n,
                            const char **blocks_coords, const char **genomes_permutations, const char **coverage_report);
 
+/* Postprocessor::GlueStripes (src/postprocessor.cpp:37-154) on a caller's block list, in place (*n updated; never grows): the
+ * reference's main applies it to the blocks of every stage under -v / --allstages (src/sibelia.cpp:247-253).  Same merges in the same
+ * order as the reference, found by a worklist instead of one rescan per merge (88 k instances: 0.04 s instead of a minute).
+ * Host bookkeeping only: needs neither a context nor a device. */
+sbl_status sbl_glue_stripes(sbl_block *blocks, uint64_t *n, uint32_t nchr);
+
 /* Replaces BlockFinder::SerializeGraph (src/serialization.cpp:112-138; defined for records of at least k + 1 characters -- the
  * reference walks off the end of a shorter one): DOT text of the UNcondensed de Bruijn graph of the
  * current state, one line per (k+1)-window, generated on the device (a debugging dump: main only reaches it with -q and never

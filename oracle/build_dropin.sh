@@ -5,7 +5,8 @@
 #                                tests/golden/dropin_cases.json (tests/golden/gen/make_dropin_golden.py), CPU only
 #   oracle/_ref/sibelia_dropin   the same program with the five translation units that define BlockFinder's members
 #                                (blockfinder, bulgeremoval, edge, serialization, synteny) replaced by integration/blockfinder_amd.cpp
-#                                over libsibelia_amd.so -- what a maintainer gets by applying INTEGRATION.md.  Runs on the GPU box.
+#                                over libsibelia_amd.so, and Postprocessor::GlueStripes by integration/postprocessor_amd.cpp -- what a
+#                                maintainer gets by applying INTEGRATION.md.  Runs on the GPU box.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(dirname "$HERE")"
@@ -32,9 +33,15 @@ for f in $BF $REST; do
   g++ $CXXFLAGS -I"$SRC/include" -I"$OUT/include" -c "$SRC/$f.cpp" -o "$OUT/obj2/$f.o" & pids+=($!)
 done
 g++ $CXXFLAGS -I"$SRC" -I"$SRC/include" -I"$OUT/include" -I"$ROOT/include" -c "$ROOT/integration/blockfinder_amd.cpp" -o "$OUT/obj2/blockfinder_amd.o" & pids+=($!)
+g++ $CXXFLAGS -I"$SRC" -I"$SRC/include" -I"$OUT/include" -I"$ROOT/include" -c "$ROOT/integration/postprocessor_amd.cpp" -o "$OUT/obj2/postprocessor_amd.o" & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
+# integration/postprocessor_amd.cpp replaces ONE member of the reference's postprocessor.cpp: that definition becomes weak in a copy of the object
+GLUE=$(nm "$OUT/obj2/postprocessor.o" | awk '$2 == "T" && $3 ~ /Postprocessor11GlueStripes/ { print $3 }')
+[ -n "$GLUE" ] || { echo "Postprocessor::GlueStripes not found in postprocessor.o" >&2; exit 5; }
+objcopy --weaken-symbol="$GLUE" "$OUT/obj2/postprocessor.o" "$OUT/obj2/postprocessor_weak.o"
 objs() { for f in "$@"; do echo "$OUT/obj2/$f.o"; done; }
 g++ -O3 $(objs $BF $REST) "$OUT"/obj2/dss_*.o -o "$OUT/sibelia_ref"
-g++ -O3 $(objs $REST) "$OUT/obj2/blockfinder_amd.o" "$OUT"/obj2/dss_*.o -L"$ROOT/sibelia_amd/lib" -lsibelia_amd -Wl,-rpath,'$ORIGIN/../../sibelia_amd/lib' -o "$OUT/sibelia_dropin"
+REST_DROPIN=$(for f in $REST; do [ $f = postprocessor ] && echo postprocessor_weak || echo $f; done)
+g++ -O3 "$OUT/obj2/blockfinder_amd.o" "$OUT/obj2/postprocessor_amd.o" $(objs $REST_DROPIN) "$OUT"/obj2/dss_*.o -L"$ROOT/sibelia_amd/lib" -lsibelia_amd -Wl,-rpath,'$ORIGIN/../../sibelia_amd/lib' -o "$OUT/sibelia_dropin"
 rm -rf "$OUT/obj2"
 echo "built $OUT/sibelia_ref $OUT/sibelia_dropin"

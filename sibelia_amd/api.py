@@ -242,6 +242,19 @@ class BlockFinder:
 COMM_ID_BYTES = 128
 
 
+def glue_stripes(blocks: np.ndarray, nchr: int) -> np.ndarray:
+    """Postprocessor::GlueStripes (reference src/postprocessor.cpp:37-154) on a block array (formats.BLOCK_DTYPE); host bookkeeping only."""
+    L = load_library()
+    b = np.ascontiguousarray(blocks, dtype=formats.BLOCK_DTYPE).copy()
+    n = C.c_uint64(len(b))
+    L.sbl_glue_stripes.restype = C.c_int
+    L.sbl_glue_stripes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]
+    rc = L.sbl_glue_stripes(b.ctypes.data if len(b) else None, C.byref(n), int(nchr))
+    if rc:
+        raise SibeliaError("sbl_glue_stripes failed: %d" % rc)
+    return b[:n.value]
+
+
 def comm_unique_id() -> bytes:
     L = load_library()
     buf = C.create_string_buffer(COMM_ID_BYTES)

@@ -62,3 +62,43 @@ def test_cpp_class_surface_compiles_and_fails_loudly_without_a_gpu(tmp_path):
         assert r.returncode == 0 and r.stdout.startswith("bulges ")
     else:
         assert r.returncode == 3 and "no usable HIP device" in r.stdout
+
+
+def test_glue_stripes_worklist_equals_the_oracle_on_random_block_lists():
+    """sbl_glue_stripes is host bookkeeping (row N4): no device needed.  Random permutations built from runs of blocks that always
+    travel together -- what GlueStripes exists to merge -- against the oracle's restatement of the reference's rescan-per-merge loop."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    from sibelia_amd import formats as F
+    from sibelia_amd.api import glue_stripes
+    rng = np.random.default_rng(5)
+    shrunk = 0
+    for case in range(40):
+        nchr = int(rng.integers(1, 5))
+        nsyn = int(rng.integers(1, 30))                       # "true" blocks, each cut into 1..4 stripes that stay adjacent
+        stripes, nxt = [], 1
+        for _ in range(nsyn):
+            k = int(rng.integers(1, 5))
+            stripes.append(list(range(nxt, nxt + k)))
+            nxt += k
+        rows = []
+        for c in range(nchr):
+            pos = 0
+            for s in rng.permutation(nsyn)[: int(rng.integers(1, nsyn + 1))]:
+                ids = stripes[int(s)]
+                rev = bool(rng.integers(0, 2))
+                if rng.random() < 0.15 and len(ids) > 1:      # an occurrence that lacks a stripe: those two must not glue
+                    ids = ids[:-1]
+                for i in (reversed(ids) if rev else ids):
+                    ln = int(rng.integers(5, 50))
+                    rows.append((-i if rev else i, c, pos, pos + ln))
+                    pos += ln + int(rng.integers(0, 20))
+        blocks = np.array(rows, dtype=F.BLOCK_DTYPE)
+        seqs = [b"A" * 10_000] * nchr
+        want, _ = Oracle(seqs).postprocess(blocks, ["s%d" % i for i in range(nchr)], True)
+        got = glue_stripes(blocks, nchr)
+        assert len(got) == len(want), case
+        for f in ("id", "chr", "start", "end"):
+            assert (got[f] == want[f]).all(), (case, f)
+        shrunk += len(got) < len(blocks)
+    assert shrunk >= 20

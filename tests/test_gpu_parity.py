@@ -336,13 +336,29 @@ def test_small_block_index_equals_the_general_child_index(seed, n, L0, k):
     seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=0.03, indel_every=300, inv_min=200, inv_max=800)
     if seed == 12:      # non-ACGT characters inside candidate blocks: the small-block kernel must decline and leave rand() to the general path
         seqs = [s[:1000] + b"N" + s[1001:3000] + b"RY" + s[3002:] for s in seqs]
-    a = _bf(seqs).generate_blocks(k, k, k)
+    fa, fb, orc = _bf(seqs), _bf(seqs), Oracle(seqs)
+    a = fa.generate_blocks(k, k, k)
     os.environ["SBL_NO_TINY_INDEX"] = "1"
     try:
-        b = _bf(seqs).generate_blocks(k, k, k)
+        b = fb.generate_blocks(k, k, k)
     finally:
         del os.environ["SBL_NO_TINY_INDEX"]
-    c = Oracle(seqs).generate_blocks(k, k, k)
+    c = orc.generate_blocks(k, k, k)
     assert len(a) == len(b) == len(c) and len(a) > 0
     for f in ("id", "chr", "start", "end"):
         assert (a[f] == b[f]).all() and (a[f] == c[f]).all()
+    # GlueStripes on these thousands of instances: the worklist (product), the reference's rescan-per-merge procedure kept for
+    # this comparison (SBL_GLUE_RESCAN=1), and the oracle -- blocks and the three report texts
+    names = ["seq%d" % i for i in range(len(seqs))]
+    ga, ta = fa.postprocess(names, True)
+    ga = ga.copy()
+    os.environ["SBL_GLUE_RESCAN"] = "1"
+    try:
+        gb, tb = fb.postprocess(names, True)
+    finally:
+        del os.environ["SBL_GLUE_RESCAN"]
+    gc, tc = orc.postprocess(c, names, True)
+    assert len(ga) == len(gb) == len(gc) and len(ga) < len(a)
+    for f in ("id", "chr", "start", "end"):
+        assert (ga[f] == gb[f]).all() and (ga[f] == gc[f]).all()
+    assert list(ta) == list(tb) == list(tc)

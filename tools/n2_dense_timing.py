@@ -19,3 +19,6 @@ with tempfile.TemporaryDirectory() as d:
 t0 = time.time()
 b = bf.generate_blocks(k, k, k)
 print("GenerateSyntenyBlocks(%d, %d, %d): %.2f s, %d block instances" % (k, k, k, time.time() - t0, len(b)), flush=True)
+t0 = time.time()
+out, texts = bf.postprocess(None, True)
+print("PostProcess (GlueStripes + report texts): %.2f s, %d block instances left" % (time.time() - t0, len(out)), flush=True)
