@@ -99,6 +99,17 @@ namespace SyntenyFinderAMD
 			blocksCoords = t0; permutations = t1; coverageReport = t2;
 		}
 
+		// Postprocessor::GlueStripes (postprocessor.cpp:37-154) on any block list, e.g. the blocks of an earlier stage (sibelia.cpp:247-253)
+		static void GlueStripes(std::vector<BlockInstance> &block, size_t chrCount)
+		{
+			std::vector<sbl_block> flat(block.size());
+			for (size_t i = 0; i < block.size(); i++) { flat[i].id = block[i].id; flat[i].chr = (uint32_t)block[i].chr; flat[i].start = block[i].start; flat[i].end = block[i].end; }
+			uint64_t n = flat.size();
+			if (sbl_glue_stripes(flat.empty() ? nullptr : flat.data(), &n, (uint32_t)chrCount) != SBL_OK) throw std::runtime_error("sibelia_amd: GlueStripes: bad block list");
+			block.clear();
+			for (uint64_t i = 0; i < n; i++) block.push_back(BlockInstance{flat[i].id, flat[i].chr, (size_t)flat[i].start, (size_t)flat[i].end});
+		}
+
 		// serialization.cpp:88-110 (same text, byte for byte)
 		void SerializeCondensedGraph(size_t k, std::ostream &out, ProgressCallBack = ProgressCallBack())
 		{
