@@ -40,6 +40,18 @@ while time.time() - t0 < budget:
         tg += t2 - t1; tc += t3 - t2
         (sa, pa), (sb, pb) = bf.state(), orc.state()
         ok = ok and a == b and sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    if ok and not nshard and __import__("os").environ.get("N2"):      # N2=1: synteny blocks + GlueStripes + report texts after the stages (and before them: raw graph)
+        bk = int(rng.choice([stages[-1][0], max(4, stages[-1][0] // 2), 2 * stages[-1][0]]))
+        tk = int(min(bk, rng.choice([bk, max(3, bk // 2), 30])))
+        ms = int(rng.choice([bk, 50, 500]))
+        sh = bool(rng.random() < 0.2)
+        ga, gb = bf.generate_blocks(bk, tk, ms, sh), orc.generate_blocks(bk, tk, ms, sh)
+        ok = len(ga) == len(gb) and all((ga[f] == gb[f]).all() for f in ("id", "chr", "start", "end"))
+        names = ["s%d" % i for i in range(n)]
+        pa_, ta_ = bf.postprocess(names, True)
+        pb_, tb_ = orc.postprocess(gb, names, True)
+        ok = ok and len(pa_) == len(pb_) and all((pa_[f] == pb_[f]).all() for f in ("id", "chr", "start", "end")) and list(ta_) == list(tb_)
+        print("blocks(%d,%d,%d,%d) %d -> %d" % (bk, tk, ms, sh, len(ga), len(pa_)), end=" ")
     st = bf.stats()
     if nshard: st = st[0]
     done += 1
