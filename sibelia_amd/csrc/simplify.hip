@@ -1652,6 +1652,14 @@ __global__ void k_remap_seps(const unsigned *__restrict__ newidx, unsigned *__re
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) sepidx[i] = newidx[sepidx[i]];
 }
+// The separator that ends chromosome c carries the CURRENT length of c as its position: the next stage's DNASequence is built from the
+// simplified records and stamps it with record[chr].size() (dnasequence.cpp:96), and Replace clamps interpolated positions to the
+// position of the element after the rewritten span -- at a chromosome's end that is this separator.
+__global__ void k_sep_positions(const unsigned *__restrict__ sepidx, unsigned nchr, unsigned *__restrict__ op)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nchr) op[sepidx[i + 1]] = (sepidx[i + 1] - sepidx[i] - 1u) & BT_POS_MASK;
+}
 __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_t from, size_t to)
 {
 	size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2147,6 +2155,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	                                                 st->ch_out.as<uint8_t>(), st->op_out.as<unsigned>(), st->newidx.as<unsigned>());
 	k_fill_bytes<<<nblocks(Epad - Enew, 256), 256, 0, s>>>(st->ch_out.as<uint8_t>(), (uint8_t)'$', Enew, Epad);
 	k_remap_seps<<<nblocks(c->nchr + 1, 64), 64, 0, s>>>(st->newidx.as<unsigned>(), c->d_sepidx.as<unsigned>(), c->nchr + 1);
+	k_sep_positions<<<nblocks(c->nchr, 64), 64, 0, s>>>(c->d_sepidx.as<unsigned>(), c->nchr, st->op_out.as<unsigned>());
 	HIP_TRY(hipGetLastError());
 	std::swap(c->d_ch, st->ch_out);
 	std::swap(c->d_op, st->op_out);

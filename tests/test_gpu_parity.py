@@ -362,3 +362,19 @@ def test_small_block_index_equals_the_general_child_index(seed, n, L0, k):
     for f in ("id", "chr", "start", "end"):
         assert (ga[f] == gb[f]).all() and (ga[f] == gc[f]).all()
     assert list(ta) == list(tb) == list(tc)
+
+
+@pytest.mark.gpu
+def test_positions_clamp_at_a_chromosome_end_in_a_later_stage():
+    # Found by tools/stress.py (seed 110467): a collapse at the very end of a chromosome in the SECOND stage clamps the interpolated
+    # positions to the position of the closing separator, which the reference sets to the record's CURRENT length when it rebuilds
+    # the sequence for that stage (dnasequence.cpp:96) -- not to the original length.  The oracle agrees with the unmodified
+    # reference on this input (sha256 of both stages' states compared with oracle/_ref/ref_dump when the case was found).
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=13939, n=8, seed=110467, snp=0.03, indel_every=1000, inv_min=139, inv_max=696)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    for k, D in ((31, 124), (36, 174), (40, 250)):
+        assert bf.simplify_stage(k, D, 4) == orc.simplify_stage(k, D, 4)
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb)), (k, D)
