@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle stress (not part of the test suite): python tools/stress.py [seconds] [first_seed]"""
+"""Randomised GPU-vs-oracle stress (not part of the test suite): python tools/stress.py [seconds] [first_seed]
+Environment: SHARD=n (n virtual ranks), N2=1 (synteny blocks + GlueStripes + reports as well), STAGES=3 (three-stage cascades)."""
 import sys
 import time
 
@@ -23,6 +24,8 @@ while time.time() - t0 < budget:
     seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
                          inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
     stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
+    if __import__("os").environ.get("STAGES") == "3":                  # STAGES=3: every case is a three-stage cascade (state carried across copy-backs)
+        stages = [(k, D), (int(min(40, k + 5)), D + 50), (int(min(48, k + 10)), D + 100)]
     print("case", seed, "n", n, "L0", L0, "stages", stages, "snp", snp, end=" ", flush=True)
     nshard = int(__import__("os").environ.get("SHARD", "0"))          # SHARD=3: the same run through 3 virtual ranks (sharded enumeration)
     if nshard:
