@@ -49,7 +49,18 @@ def main():
     ap.add_argument("--shard-enum", action="store_true", help="one job on all ranks: hash-prefix sharded enumeration over RCCL (the default for --gpus > 1)")
     ap.add_argument("--replicas", action="store_true", help="--gpus > 1: make the replicas configuration (one independent job per GPU) the headline value")
     ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
+    ap.add_argument("--cpu-full", action="store_true", help="also time the unmodified reference on the FULL workload (8 x 4.6 Mbp: ~500 s, once)")
     a = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL), so that the
+    # multi-GPU line needs no wrapper (the driver's own launch sets WORLD_SIZE and lands below directly)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -161,6 +172,31 @@ def main():
                     "parallelism": "replicas (x%d): one independent job per GPU on its own strain set, no data-path collective" % world}
         bf2.close()
 
+    # ---- what was timed is what is checked (outside the timed region): the state the last step left on the device, downloaded
+    # once through the C ABI, serialised like the golden vectors (formats.state_bytes) and hashed; on the metric workload the
+    # reference's own result is a committed fixture (tests/golden/vectors.json: synth/strains8_4600k, generated by oracle/_ref)
+    verify = None
+    if rank == 0:
+        import hashlib, struct
+        t1 = time.perf_counter()
+        vs, vp = bf.state_views()
+        t_dl_first = time.perf_counter() - t1
+        h = hashlib.sha256(struct.pack("<QI", bulges, len(vs)))
+        for x, y in zip(vs, vp):
+            h.update(struct.pack("<Q", len(x))); h.update(x); h.update(y)
+        verify = {"state_sha256": h.hexdigest(), "download_first_ms": 1e3 * t_dl_first}
+        if (a.strains, a.L0, a.k, a.D, a.iters) == (8, 4_600_000, 25, 150, 4):
+            try:
+                fx = [v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "vectors.json")))["vectors"] if v["name"] == "synth/strains8_4600k"][0]
+                want = [o for o in fx["outputs"] if o["cmd"] == "stage:25:150:4"][0]
+                verify["reference_fixture"] = "tests/golden/vectors.json synth/strains8_4600k stage:25:150:4 (output of the unmodified reference, oracle/_ref)"
+                verify["matches_reference_fixture"] = bool(want["sha256"] == verify["state_sha256"] and want["bulges"] == bulges)
+            except Exception as e:      # noqa: BLE001
+                verify["matches_reference_fixture"] = None
+                verify["fixture_error"] = str(e)
+        else:
+            verify["matches_reference_fixture"] = None       # no reference fixture for a non-default workload
+
     if rank == 0:
         st = bf.stats()
         ms_step = 1000.0 * dt / a.steps
@@ -218,6 +254,13 @@ def main():
                          "stage_frac_of_peak_by_survey_formula": ((N * 24.125 + 12 * st["instances"] + st["iterations"] * N * 4) / 1e9) / (ms_step * 1e-3) / HBM_PEAK_GBS,
                          "all_kernels_ms_per_step": per},
         }
+        out["state_sha256"] = verify["state_sha256"]
+        out["matches_reference_fixture"] = verify["matches_reference_fixture"]
+        out["verify"] = verify
+        if world > 1:
+            out["rccl_ranks"] = world
+            out["exchange_ms"] = st["exchange_ms"]
+            out["exchange_bytes"] = st["exchange_bytes"]
         if replicas is not None:
             out["replicas"] = replicas
         if shard_error:
@@ -231,12 +274,22 @@ def main():
             t_load = time.perf_counter() - t1
             b2.PerformGraphSimplifications(a.k, a.D, a.iters)
             t_stage = time.perf_counter() - t1 - t_load
-            b2.state()
+            b2.state_views()
             t_all = time.perf_counter() - t1
             b2.close()
-            out["pcie_inclusive"] = {"value": N / t_all, "unit": "strand-k-mers/s", "load_ms": 1e3 * t_load, "stage_ms": 1e3 * t_stage,
-                                     "download_ms": 1e3 * (t_all - t_load - t_stage),
-                                     "note": "cold context: includes the first-call workspace allocations of the stage"}
+            # steady-state download on the warm context of the timed loop: one bulk device-to-host copy of ch[] + op[] (5 B/base)
+            # into the library's pinned staging buffer, chromosomes are slices of it (the first call also pins the buffer)
+            bf.restore_state()
+            bf.PerformGraphSimplifications(a.k, a.D, a.iters)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bf.state_views()
+            t_dl = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"value": N / (t_load + ms_step * 1e-3 + t_dl), "unit": "strand-k-mers/s", "load_ms": 1e3 * t_load, "stage_ms": ms_step,
+                                     "download_ms": 1e3 * t_dl,
+                                     "cold": {"value": N / t_all, "load_ms": 1e3 * t_load, "stage_ms": 1e3 * t_stage, "download_ms": 1e3 * (t_all - t_load - t_stage),
+                                              "note": "cold context: first-call workspace allocations of the stage and pinning of the staging buffer included"},
+                                     "note": "host buffers -> sbl_load (1 B/base up) + one warm stage + sbl_get_state (5 B/base down, pinned bulk copy)"}
         if not a.no_cpu_baseline and world == 1:
             # The reference's own CPU path beside the GPU number (north_star): oracle/_ref/ref_dump is the UNMODIFIED reference
             # compiled by oracle/build_ref.sh (it travels to the GPU box as a prebuilt binary).  The reference is single-threaded
@@ -267,6 +320,17 @@ def main():
                                                          "parallelism) on %d strains x %.2f Mbp from the same generator (%d strand-k-mers, %.1f s, %d bulges); on the full "
                                                          "8 x 4.6 Mbp input it takes 499.8 s = 0.147 M/s (BASELINE.md)"
                                                          % (a.k, a.D, a.iters, a.strains, a.cpu_sample_L0 / 1e6, Ns, cdt, ob)}
+                    if "cpu_baseline" in out and a.cpu_full:
+                        # the same binary on the FULL workload of `value`, once (~500 s): like-for-like on this host
+                        fa2 = os.path.join(d, "full.fa")
+                        W.write_fasta(fa2, seqs)
+                        r2 = subprocess.run([ref_dump, fa2, os.path.join(d, "f"), "stage:%d:%d:%d" % (a.k, a.D, a.iters)], capture_output=True, text=True)
+                        m2 = re.search(r"bulges=(\d+) seconds=([0-9.]+)", r2.stderr)
+                        if r2.returncode == 0 and m2:
+                            fb, fdt = int(m2.group(1)), float(m2.group(2))
+                            out["cpu_baseline"]["full"] = {"value": N / fdt, "unit": "strand-k-mers/s", "seconds": fdt, "bulges": fb, "bulges_equal_gpu": fb == bulges,
+                                                           "gpu_over_reference": (Ntot / (dt / a.steps)) / (N / fdt),
+                                                           "sample_over_full_rate": out["cpu_baseline"]["value"] / (N / fdt)}
             if "cpu_baseline" not in out:                 # no reference build on this box: the bit-exact port (oracle/) instead
                 o = Oracle(sample)
                 t1 = time.perf_counter()

@@ -128,7 +128,7 @@ sbl_status sbl_generate_blocks(sbl_ctx *ctx, uint32_t k, uint32_t trim_k, uint32
  * sbl_generate_blocks: Postprocessor::GlueStripes (src/postprocessor.cpp:37-154; skipped when glue == 0) and the texts of
  * blocks_coords.txt (OutputGenerator::ListBlocksIndices, src/outputgenerator.cpp:227-233), genomes_permutations.txt
  * (ListChromosomesAsPermutations, :203-219) and coverage_report.txt (GenerateReport, :162-201), byte for byte.
- * names: record descriptions (NULL: those of the last sbl_load_fasta).  Host-side bookkeeping and formatting only.
+ * names: record descriptions, EXACTLY sbl_nchr(ctx) pointers (NULL: those of the last sbl_load_fasta).  Host-side bookkeeping and formatting only.
  * Everything returned is owned by the ctx and valid until the next call. */
 sbl_status sbl_postprocess(sbl_ctx *ctx, int glue, const char *const *names, const sbl_block **blocks, uint64_t *n,
                            const char **blocks_coords, const char **genomes_permutations, const char **coverage_report);
@@ -163,9 +163,9 @@ const char *sbl_strerror(sbl_status s);
 /* ---- Multi-GPU (one context per GPU).  The reference is a single-threaded CPU program with no
  * counterpart; these entry points attach a communicator to a context, after which the enumeration inside
  * sbl_enumerate / sbl_simplify_stage / sbl_list_edges (k <= 32) shards the k-mer table by hash prefix:
- * every GPU scans a contiguous slice of base positions into a local pre-aggregating table, sends each distinct
- * canonical k-mer (16-B record) to its owner GPU in ONE all-to-all, owners classify, the bifurcation codes and
- * the resolved marks are all-gathered.  Simplification is globally ordered and runs replicated (bit-identical) on
+ * every GPU turns its contiguous slice of base positions into 16-B k-mer records (one per position, no local
+ * pre-aggregation), partitions them by hash prefix and sends every owner GPU its contiguous bucket range in ONE
+ * all-to-all; owners classify their buckets (LDS tables), the bifurcation codes and the member marks are all-gathered.  Simplification is globally ordered and runs replicated (bit-identical) on
  * every attached GPU.  The calls are collective: every attached context must make them with the same arguments.
  *   RCCL transport (one process or thread per GPU, xGMI): rank 0 calls sbl_comm_unique_id, the host distributes the
  *   128 bytes (MPI, torch.distributed, a file), every rank calls sbl_comm_attach_rccl.

@@ -90,6 +90,7 @@ namespace SyntenyFinderAMD
 		                 const std::vector<std::string> &descriptions = std::vector<std::string>())
 		{
 			std::vector<const char *> nm;
+			if (!descriptions.empty() && descriptions.size() != sbl_nchr(ctx_)) throw std::runtime_error("sibelia_amd: PostProcess: one description per record expected");
 			for (const std::string &d : descriptions) nm.push_back(d.c_str());
 			const sbl_block *b = nullptr; uint64_t n = 0;
 			const char *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;

@@ -174,6 +174,19 @@ class BlockFinder:
             pos.append(_view(p.value, n.value, np.dtype("<u4")))
         return seqs, pos
 
+    def state_views(self) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """The same state as zero-copy numpy views of the library's pinned staging buffer (one bulk device-to-host copy of
+        ch[] + op[], 5 B per base; chromosomes are slices of it).  Borrowed: valid until the next mutating call."""
+        seqs, pos = [], []
+        for c in range(self.L.sbl_nchr(self.h)):
+            s, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+            self._check(self.L.sbl_get_state(self.h, c, C.byref(s), C.byref(p), C.byref(n)), "sbl_get_state")
+            if not n.value:
+                seqs.append(np.zeros(0, np.uint8)); pos.append(np.zeros(0, "<u4")); continue
+            seqs.append(np.frombuffer((C.c_char * n.value).from_address(s.value), dtype=np.uint8, count=n.value))
+            pos.append(np.frombuffer((C.c_char * (4 * n.value)).from_address(p.value), dtype="<u4", count=n.value))
+        return seqs, pos
+
     def list_edges(self, k: int) -> np.ndarray:
         e, n = C.c_void_p(), C.c_uint64()
         self._check(self.L.sbl_list_edges(self.h, k, C.byref(e), C.byref(n)), "sbl_list_edges")
@@ -192,6 +205,8 @@ class BlockFinder:
         blocks_coords.txt, genomes_permutations.txt, coverage_report.txt (src/outputgenerator.cpp:162-233)."""
         nm = None
         if names is not None:
+            if len(names) != self.L.sbl_nchr(self.h):      # the C entry point reads one name per loaded record (include/sibelia_amd.h)
+                raise ValueError("postprocess: %d names for %d records" % (len(names), self.L.sbl_nchr(self.h)))
             nm = (C.c_char_p * len(names))(*[x.encode() for x in names])
         b, n = C.c_void_p(), C.c_uint64()
         t = [C.c_char_p() for _ in range(3)]

@@ -31,6 +31,7 @@
 // insertion takes exactly the slots it needs: low-complexity inputs make tens of thousands of 1-3 element insertions per
 // stage and would otherwise burn the element pool 32 slots at a time (grow + replay of the iteration, again and again).
 #define BT_INSERT_ALIGN 1u
+#define BT_LAZY_MIN 64u           // see BulgeWork::lazy
 __host__ __device__ __forceinline__ uint32_t bt_insert_span(uint32_t m) { return (m + BT_INSERT_ALIGN - 1u) & ~(BT_INSERT_ALIGN - 1u); }
 
 // Counter block.  Every counter has a 128-byte line of its own: thousands of workgroups per launch bump them (retired entries,
@@ -60,6 +61,7 @@ struct GraphView {
 	uint32_t nblk;
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
+	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
 };
 
 // ------------------------------------------------------------------------------------------- atomics (host + device)
@@ -369,6 +371,16 @@ struct BulgeWork {
 	uint32_t *wdel;              // elements this transaction has deleted inside each window (reach beyond the reserved range, simplify.hip)
 	unsigned long long *dirty_big; // ids with more than 256 instances: bit per window "saw the region of the last collapse" (simplify.hip)
 	bool lite;                   // verdict-only use: wel / wbf / wch are not materialised
+	// Lazy windows.  The reference walks an instance's window at the moment it needs it (FillVisit, the J walk, Overlap,
+	// MaxBifurcationMultiplicity: bulgeremoval.cpp:371-407).  The cache reproduces that either EAGERLY -- after a collapse every
+	// cached window that sees the rewritten region is rescanned at once (cheap for the usual dozen instances, and the set of
+	// those windows is what the reservation check of an ordered round needs) -- or LAZILY: a collapse only bumps `epoch`, and
+	// the loops ask for a window whose last scan is older (wep) right before they read it.  Ids with thousands of instances on a
+	// few hundred bases (dense regime) make nearly every cached window see every collapse: eager is O(instances) per collapse,
+	// lazy two window scans.  bt_rb_run returns 2 with the windows it needs in req[].
+	bool lazy;
+	uint32_t epoch, *wep;
+	uint32_t req[2], nreq;
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
@@ -415,7 +427,9 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc2(n);
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
-	w.wmk = lite ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0;
+	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
+	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
 	if (!w.wmk) { w.wmk = (uint64_t *)t.alloc(n * w.ws * 8); w.mks = w.ws; }
 	w.lite = lite;
@@ -434,6 +448,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.lb = (uint32_t *)t.alloc2(k * 8); w.lf = (uint32_t *)t.alloc2(k * 8);   // flank lists of a collapse: read back by other lanes, LDS when it fits
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
 		if (n > 256) w.dirty_big = (unsigned long long *)t.alloc(((n + 63) / 64) * 8);
+		if (n > lazy_min) { w.wep = (uint32_t *)t.alloc(n * 4); if (w.wep) for (uint32_t i = 0; i < n; i++) w.wep[i] = 0; }
 	}
 	if (t.err) return false;
 	if (!fill_list) return true;                    // the caller lists the positions itself (64 lanes, simplify.hip: wave_list_positions)
@@ -832,7 +847,9 @@ __host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w, int any_bulges
 	return true;
 }
 
-__host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
+// returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
+// the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards.
+__host__ __device__ inline int bt_rb_run(Txn &t, BulgeWork &w)
 {
 	const uint32_t D = t.g.D;
 	while (w.gi < w.ab.ngroups) {
@@ -844,11 +861,18 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true;
 			}
 			while (w.idJ < ge) {
-				const uint32_t kmerJ = w.ab.grp_mem[w.idJ++];
-				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) continue;
+				const uint32_t kmerJ = w.ab.grp_mem[w.idJ];
+				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) { w.idJ++; continue; }
+				if (w.lazy) {                                        // everything below reads the windows of I and J: as of NOW, like the reference's walks
+					uint32_t nr = 0;
+					if (w.wep[kmerI] != w.epoch) w.req[nr++] = kmerI;
+					if (w.wep[kmerJ] != w.epoch) w.req[nr++] = kmerJ;
+					if (nr) { w.nreq = nr; return 2; }
+				}
+				w.idJ++;
 				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
 				// after a collapse that rewrote I's own window
-				if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; if (t.err) return false; }
+				if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }
 				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.mks;
 				const uint32_t limJ = w.wlen[kmerJ] < D ? w.wlen[kmerJ] : D, nmJ = w.wmn[kmerJ];
 				for (uint32_t j = 0; j < nmJ; j++) {
@@ -861,7 +885,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 					if (lo < w.nvisit && (uint32_t)(w.visit[lo] >> 32) == nowBif) {
 						uint32_t dJ = step, dI = (uint32_t)w.visit[lo];
 						if (bt_overlap(t, w, kmerI, dI, kmerJ, dJ)) break;
-						if (t.err) return false;
+						if (t.err) return 0;
 						++w.ret;
 						uint32_t imlp = bt_max_mult(t, w, kmerI, dI);
 						uint32_t jmlp = bt_max_mult(t, w, kmerJ, dJ);
@@ -873,7 +897,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 							w.c_src = kmerJ; w.c_dS = dJ; w.c_tgt = kmerI; w.c_dT = dI;
 							w.need_fill = true;                      // FillVisit(I) again, on the rescanned window
 						}
-						return true;                                 // caller: collapse(c_src -> c_tgt), rescan, then call again (next J)
+						return 1;                                    // caller: collapse(c_src -> c_tgt), rescan (or bump epoch), then call again (next J)
 					}
 				}
 			}
@@ -883,7 +907,7 @@ __host__ __device__ inline bool bt_rb_run(Txn &t, BulgeWork &w)
 		if (w.gi < w.ab.ngroups) w.idI = w.ab.grp_off[w.gi];
 	}
 	if (!t.defer_cleanup) t.cleanup();           // (simplify.hip: Cleanup by all lanes once the loops are over)
-	return false;
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------- reservation footprint

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_fa_scatter(const uint8_t *__restrict__ 
 	const uint8_t c = orig >= 'a' && orig <= 'z' ? orig - 32 : orig;
 	bool ok = false;
 	switch (c) { case 'A': case 'C': case 'G': case 'T': case 'U': case 'R': case 'Y': case 'K': case 'M': case 'S': case 'W': case 'B': case 'D': case 'H': case 'N': case 'X': case '-': ok = true; }
-	if (!ok) { atomicMin(err, ((unsigned long long)l << 40) | ((unsigned long long)(i - a) << 16) | ((unsigned long long)orig << 8) | 2ull); return; }
+	if (!ok) { atomicMin(err, ((unsigned long long)l << 40) | ((unsigned long long)((i - a) < 0xFFFFFFull ? (i - a) : 0xFFFFFFull) << 16) | ((unsigned long long)orig << 8) | 2ull); return; }   // column clamped to its 24-bit field
 	ch[(size_t)elem0[l] + (i - a)] = c;
 }
 
@@ -287,6 +287,7 @@ extern "C" sbl_status sbl_load_fasta(sbl_ctx *c, const char *path)
 		unsigned long long first = ~0ull; std::string what;
 		if (herr != ~0ull) {
 			unsigned l = (unsigned)(herr >> 40);
+			SBL_CHECK(l < nlines, SBL_ERR_INTERNAL, "FASTA loader: corrupt error record");
 			// line number of line l = 1 + non-empty lines before it
 			unsigned before = 0;
 			HIP_TRY(hipMemcpy(&before, ne_before + l, 4, hipMemcpyDeviceToHost));

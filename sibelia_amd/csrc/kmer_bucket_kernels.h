@@ -89,8 +89,11 @@ static __global__ void __launch_bounds__(256) k_bucket_bounds(const unsigned lon
 #ifndef KB_SLOTS
 #define KB_SLOTS 1024u                          // LDS table of a bucket: 1024 x (8 + 4 + 4) B = 16 KB (9 workgroups per CU)
 #endif
-#define KB_MAX_DISTINCT (KB_SLOTS * 25u / 32u)
 #define KB_THREADS 256
+// Threads re-read the count before every record, so at most KB_MAX_DISTINCT + KB_THREADS slots are ever claimed: that sum must
+// leave the table room, or a probe for an absent key would spin in a full table.
+#define KB_MAX_DISTINCT (KB_SLOTS * 23u / 32u)
+static_assert(KB_MAX_DISTINCT + KB_THREADS < KB_SLOTS, "k_bucket_classify: the LDS table could fill up");
 // counters: pairs, keys, members, overflow flag -- one 128-B line each: 65 536 workgroups reserve their output ranges with returning
 // atomics, and one address (or one line) takes only ~88 of those per microsecond
 enum { KB_CTR_PAIRS = 0, KB_CTR_KEYS = 32, KB_CTR_MEM = 64, KB_CTR_FLAG = 96, KB_CTR_WORDS = 128 };
@@ -119,11 +122,12 @@ static __global__ void __launch_bounds__(KB_THREADS) k_bucket_classify(const uns
 		if (v == KB_INVALID) continue;
 		const unsigned long long key = skeys[i];
 		unsigned h = (unsigned)(key >> 44) & (KB_SLOTS - 1);            // bits above the bucket prefix (<= 40 bits)
-		for (;;) {
+		for (unsigned step = 0; step < KB_SLOTS; step++) {               // bounded: a full table ends in the overflow flag, never in a spin
 			unsigned long long old = atomicCAS(&tkey[h], KB_EMPTY_KEY, key);
 			if (old == KB_EMPTY_KEY) atomicAdd(&s_used, 1u);
 			if (old == KB_EMPTY_KEY || old == key) { atomicOr(&tmask[h], (unsigned)(v >> 32) & 0x1FFFu); break; }
 			h = (h + 1) & (KB_SLOTS - 1);
+			if (step + 1 == KB_SLOTS) atomicAdd(&s_used, KB_SLOTS);
 		}
 	}
 	__syncthreads();

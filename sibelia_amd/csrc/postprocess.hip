@@ -45,13 +45,10 @@ template <class T, class Less> std::vector<std::pair<size_t, size_t>> group_by(s
 // status of X only: a block that saw a Y instance as its follower enters it from the far end and now sees the merged block
 // reversed (-X) where it saw -Y, an injective relabelling that keeps "all followers equal" true or false, and count(X) = count(Y)
 // keeps the count test; nothing but Y itself ever saw X from its Y side.  So: chromosomes as linked lists, instance lists per id,
-// an ordered set of the ids that glue, and after each merge only X is examined again.  glue_stripes_by_rescan is the reference's
-// literal procedure, kept for the A/B test (SBL_GLUE_RESCAN=1).
-void glue_stripes_by_rescan(std::vector<sbl_block> &block, uint32_t nchr);
-
+// an ordered set of the ids that glue, and after each merge only X is examined again.  (The A/B test compares with the oracle's
+// restatement of the reference's procedure, oracle/output_oracle.cpp -- test infrastructure, not part of this library.)
 void glue_stripes(std::vector<sbl_block> &block, uint32_t nchr)
 {
-	if (getenv("SBL_GLUE_RESCAN")) { glue_stripes_by_rescan(block, nchr); return; }
 	const int sentinel = INT_MAX >> 1, NIL = -1;
 	std::vector<std::vector<sbl_block>> perm(nchr);
 	for (const sbl_block &b : block) perm[b.chr].push_back(b);
@@ -101,54 +98,6 @@ void glue_stripes(std::vector<sbl_block> &block, uint32_t nchr)
 	std::vector<int> ids;
 	for (uint32_t c = 0; c < nchr; c++)
 		for (int i = head[c]; i != NIL; i = next[i]) { block.push_back(node[i]); ids.push_back(iabs(node[i].id)); }
-	std::sort(ids.begin(), ids.end());
-	ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-	for (sbl_block &b : block) {
-		const int rank = (int)(std::lower_bound(ids.begin(), ids.end(), iabs(b.id)) - ids.begin()) + 1;
-		b.id = b.id > 0 ? rank : -rank;
-	}
-}
-
-void glue_stripes_by_rescan(std::vector<sbl_block> &block, uint32_t nchr)
-{
-	std::vector<std::vector<sbl_block>> perm(nchr);
-	for (const sbl_block &b : block) perm[b.chr].push_back(b);
-	for (auto &p : perm) std::sort(p.begin(), p.end(), [](const sbl_block &a, const sbl_block &b) { return a.start < b.start; });
-	const int sentinel = INT_MAX >> 1;
-	struct Stripe { int first, second; };
-	for (;;) {
-		// (block, what follows it when read in its own orientation)
-		std::vector<Stripe> stripe;
-		for (auto &p : perm)
-			for (size_t i = 0; i < p.size(); i++) {
-				const int bid = p[i].id;
-				if (bid > 0) stripe.push_back({bid, i + 1 < p.size() ? p[i + 1].id : sentinel});
-				else stripe.push_back({-bid, -(i > 0 ? p[i - 1].id : -sentinel)});
-			}
-		std::sort(stripe.begin(), stripe.end(), [](const Stripe &a, const Stripe &b) { return a.first < b.first; });
-		int glueBid = 0;
-		for (size_t now = 0, next = 0; now < stripe.size(); now = next) {
-			bool same = true;
-			for (; next < stripe.size() && stripe[next].first == stripe[now].first; next++)
-				if (stripe[next].second != stripe[now].second || stripe[next].second == sentinel || iabs(stripe[next].second) == stripe[next].first) same = false;
-			if (!same) continue;
-			// the follower must occur exactly as often as the block itself
-			const int follower = iabs(stripe[now].second);
-			auto lo = std::lower_bound(stripe.begin(), stripe.end(), follower, [](const Stripe &s, int v) { return s.first < v; });
-			auto hi = std::upper_bound(stripe.begin(), stripe.end(), follower, [](int v, const Stripe &s) { return v < s.first; });
-			if ((size_t)(hi - lo) == next - now) { glueBid = stripe[now].first; break; }
-		}
-		if (!glueBid) break;
-		for (auto &p : perm)
-			for (size_t i = 0; i < p.size(); i++) {
-				if (iabs(p[i].id) != glueBid) continue;
-				if (p[i].id > 0) { p[i].end = p[i + 1].end; p.erase(p.begin() + i + 1); }
-				else { --i; p[i].id = p[i + 1].id; p[i].end = p[i + 1].end; p.erase(p.begin() + i + 1); }
-			}
-	}
-	block.clear();
-	std::vector<int> ids;
-	for (auto &p : perm) for (const sbl_block &b : p) { block.push_back(b); ids.push_back(iabs(b.id)); }
 	std::sort(ids.begin(), ids.end());
 	ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
 	for (sbl_block &b : block) {

@@ -238,7 +238,8 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		SBL_CHECK(attempt < 8, SBL_ERR_INTERNAL, "k-mer bucket classification did not converge");
 		if (attempt == 0 || (cnt[3] & 1u)) {
 			if (attempt) {                                       // re-bucket with a longer prefix: the records have to be generated again (k0 was reused)
-				bits = std::min(bits + 2, 40u);
+				SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)");
+				bits = std::min(bits + 2, 28u);                  // grid = 2^bits workgroups, offsets (2^bits + 1) x 4 B: bounded
 				k_kmer_records<<<grid, KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, (size_t)0, ntiles, k0, v0);
 			}
 			device_sort_records(c, k0, k1, v0, v1, n, 0, bits);
@@ -341,6 +342,8 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	(void)hipSetDevice(c->device);
 	if (c->child) { sbl_destroy(c->child); c->child = nullptr; }
 	if (c->tiny_out) { (void)hipHostFree(c->tiny_out); c->tiny_out = nullptr; }
+	if (c->h_ch) (void)hipHostFree(c->h_ch);
+	if (c->h_opos) (void)hipHostFree(c->h_opos);
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);
@@ -485,23 +488,25 @@ extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **se
 	return guarded(c, [&] {
 		SBL_CHECK(chr < c->nchr, SBL_ERR_BAD_ARG, "chromosome index out of range");
 		if (!c->host_state_valid) {
-			std::vector<uint8_t> ch(c->nelem);
-			std::vector<uint32_t> op(c->nelem);
-			HIP_TRY(hipMemcpyAsync(ch.data(), c->d_ch.p, c->nelem, hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipMemcpyAsync(op.data(), c->d_op.p, c->nelem * 4, hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipStreamSynchronize(c->stream));
-			c->h_seq.assign(c->nchr, {}); c->h_op.assign(c->nchr, {});
-			for (uint32_t i = 0; i < c->nchr; i++) {
-				size_t a = c->sepidx[i] + 1, b = c->sepidx[i + 1];
-				c->h_seq[i].assign(ch.begin() + a, ch.begin() + b);
-				c->h_op[i].resize(b - a);
-				for (size_t j = a; j < b; j++) c->h_op[i][j - a] = op[j] & 0x1FFFFFFFu;
+			if (c->nelem > c->h_cap) {                               // pinned staging, grown with slack (stages change the length by a few per cent)
+				if (c->h_ch) (void)hipHostFree(c->h_ch);
+				if (c->h_opos) (void)hipHostFree(c->h_opos);
+				c->h_ch = nullptr; c->h_opos = nullptr; c->h_cap = 0;
+				const size_t cap = c->nelem + c->nelem / 8 + 4096;
+				HIP_TRY(hipHostMalloc((void **)&c->h_ch, cap));
+				HIP_TRY(hipHostMalloc((void **)&c->h_opos, cap * 4));
+				c->h_cap = cap;
 			}
+			// d_op never carries anything above the 29 position bits (the marks live in arrays of their own; the copy-back kernel masks)
+			HIP_TRY(hipMemcpyAsync(c->h_ch, c->d_ch.p, c->nelem, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipMemcpyAsync(c->h_opos, c->d_op.p, c->nelem * 4, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
 			c->host_state_valid = true;
 		}
-		if (seq) *seq = c->h_seq[chr].data();
-		if (orig_pos) *orig_pos = c->h_op[chr].data();
-		if (len) *len = c->h_seq[chr].size();
+		const size_t a = (size_t)c->sepidx[chr] + 1, b = c->sepidx[chr + 1];
+		if (seq) *seq = c->h_ch + a;
+		if (orig_pos) *orig_pos = c->h_opos + a;
+		if (len) *len = b - a;
 	});
 }
 

@@ -38,9 +38,12 @@ struct sbl_ctx {
 	bool saved = false;
 
 	// host mirrors for sbl_get_state
+	// (copy-back contract of the reference: blockfinder.cpp:85-95).  ONE pinned staging buffer for the whole element array, filled
+	// by two bulk device-to-host copies (1 + 4 B per element); the per-chromosome pointers handed out are slices of it.
 	bool host_state_valid = false;
-	std::vector<std::vector<uint8_t>> h_seq;
-	std::vector<std::vector<uint32_t>> h_op;
+	uint8_t *h_ch = nullptr;             // pinned [h_cap]
+	uint32_t *h_opos = nullptr;          // pinned [h_cap]
+	size_t h_cap = 0;
 
 	// ---- enumeration workspace
 	DevBuf d_pk, d_sp;                   // packed bases / separator bits

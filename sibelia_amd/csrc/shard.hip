@@ -4,15 +4,20 @@
 // reference src/vertexenumeration.cpp:263-364).  Here, with a communicator attached to the context, the k-mer
 // table is sharded by HASH PREFIX over the GPUs (north_star): one process (or host thread) per GPU, SPMD.
 //
-//   A  scan      every GPU slides over its contiguous slice of tiles (halo from the replicated packed sequence)
-//                into a LOCAL pre-aggregating table: one 16-B record per distinct canonical k-mer of the slice
-//   B  exchange  records are bucketed by owner = hash prefix and shipped in ONE all-to-all (RCCL send/recv group:
-//                7 peer messages per GPU, one per xGMI link)
-//   C  classify  the owner ORs the masks of its k-mers and emits the strand-specific codes of the bifurcations
-//   D  rank      the codes (8 B each, ~1.5 % of the k-mers) are all-gathered; every GPU radix-sorts the same
-//                list => identical id tables, and builds a bifurcation-only lookup table (L2 resident)
-//   E  resolve   every GPU resolves its slice against that table, compacts its marks and all-gathers them
-//                (8 B per instance); the dense mark arrays end up complete and identical on every GPU.
+//   A  records   every GPU runs k_kmer_records over its contiguous slice of tiles (halo from the replicated packed sequence):
+//                one 16-B record {mix64(canonical code), element | prev/next masks | orientation} per base POSITION of the
+//                slice -- no local pre-aggregation (round 1 had one; it cost more than it saved) -- and partitions them by
+//                the low `bits` bits of the key, the same hash prefix that buckets the single-GPU table
+//   B  exchange  bucket b belongs to rank (b * R) >> bits, so what goes to one owner is ONE contiguous range of the
+//                partitioned arrays: a single all-to-all of keys, then values (RCCL send/recv group: one message per peer
+//                and array, every xGMI link carries its own pair); 16 B x positions of the slice x (R - 1) / R per GPU
+//   C  classify  the owner partitions what it received again (R runs, each already bucket-sorted) and k_bucket_classify
+//                builds the per-bucket LDS tables: bifurcation codes + member positions of its buckets; an 8-B flag
+//                all-gather makes everybody re-bucket with a longer prefix if a bucket overflowed anywhere
+//   D  rank      the codes (8 B each, ~1.5 % of the k-mers) are all-gathered; every GPU radix-sorts the same list =>
+//                identical id tables; k_rank_own_keys: binary search of the owner's own codes = their ids
+//   E  marks     k_member_marks turns the owner's member positions into (element, id) marks, which are all-gathered
+//                (16 B per member position) and scattered: the dense mark arrays end up complete and identical everywhere.
 // Simplification (globally ordered) then runs replicated.  k > 32 (exact rank doubling) is not sharded.
 //
 // Transports: RCCL (dlopen'ed librccl: grouped ncclSend/ncclRecv + ncclAllGather on the context's stream) and a
@@ -418,7 +423,9 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		std::vector<unsigned long long> flag(1, rebucket ? 1 : 0), flags(R);
 		clk.time([&] { cm->allgather_host(c, flag.data(), 8, flags.data()); });
 		if (std::find(flags.begin(), flags.end(), 1ull) == flags.end()) break;
-		bits = std::min(bits + 2, 40u);
+		// (every rank sees the same flags and the same `bits`, so all of them stop here together)
+		SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)");
+		bits = std::min(bits + 2, 28u);
 	}
 	HIP_TRY(hipEventRecord(c->ev[1], s));
 	const unsigned npairs = cnt[0], mykeys = cnt[1], nmem = cnt[2];

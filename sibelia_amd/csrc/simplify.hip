@@ -1427,14 +1427,36 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		}
 		PH_ADD(1);
 		int any = wave_any_bulges(g, t, w, absh, lane);
-		if (lane == 0) flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0;
+		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
+		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
+		// an ordered round
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; }
 		__syncthreads();
 		PH_ADD(2);
 		while (flag) {
-			if (lane == 0) flag = bt_rb_run(t, w) && !t.err ? 1 : 0;
+			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
 			__syncthreads();
 			PH_ADD(3);
 			if (!flag) break;
+			if (flag == 2) {                                             // the loops need these windows as of now
+				const unsigned nr = w.nreq;
+				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
+				__syncthreads();
+				if (lane == 0) for (unsigned x = 0; x < nr; x++) w.wep[w.req[x]] = w.epoch;
+				__syncthreads();
+				PH_ADD(8);
+				continue;
+			}
+			if (w.lazy) {
+				wave_collapse(g, t, w, lane, stampv);
+				PH_ADD(5);
+				if (t.err) break;
+				wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane);
+				if (lane == 0) w.epoch++;                                // every cached window is stale until the loops ask for it
+				__syncthreads();
+				PH_ADD(6);
+				continue;
+			}
 			// which cached windows see the region about to be rewritten (target start .. end of its look-forward flank)?
 			// only those are rescanned afterwards -- normally just the target's own window
 			unsigned long long dirty[4] = {0, 0, 0, 0};                   // up to 256 windows in registers, more in the arena (w.dirty_big)
@@ -2104,10 +2126,19 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	// the driver widens the window up to 4x while rounds are capacity-bound (simplify_driver.h); an explicit sbl_set_window pins it
 	uint32_t window_max = c->window ? window : (uint32_t)std::min<size_t>((size_t)window * 4, std::max<size_t>(window, (48ull << 30) / be.arena_bytes));
 	window_max = std::max<uint32_t>(window, std::min<uint32_t>(window_max, be.nid_ ? be.nid_ : 1));
-	st->win.ensure((size_t)window_max * 4 + 16);
-	st->arena.ensure((size_t)window_max * be.arena_bytes);
-	st->claims.ensure((size_t)window_max * (CLAIM_CAP + 1) * 4);
-	st->live.ensure((size_t)window_max + 64);
+	auto round_buffers = [&](uint32_t w) {
+		st->win.ensure((size_t)w * 4 + 16);
+		st->arena.ensure((size_t)w * be.arena_bytes);
+		st->claims.ensure((size_t)w * (CLAIM_CAP + 1) * 4);
+		st->live.ensure((size_t)w + 64);
+	};
+	try { round_buffers(window_max); }
+	catch (const SblError &) {                                        // a smaller or partly occupied GPU: the pinned window always was enough
+		if (window_max == window) throw;
+		(void)hipGetLastError();
+		window_max = window;
+		round_buffers(window);
+	}
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {

@@ -67,6 +67,9 @@ __host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint
 }
 
 // the transaction proper, for a window entry that owns its whole neighbourhood
+// alone: nothing else is in flight (solo round / serial chain) -- the precondition of lazy windows in the kernels, where an ordered
+// round needs the set of windows a collapse dirtied for its reservation check; this one-thread form has no such check and takes
+// lazy windows whenever the id is large enough (g.lazy_min lets the tests force them everywhere)
 __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes,
                                               uint8_t *fast = nullptr, uint32_t fast_bytes = 0)
 {
@@ -87,15 +90,23 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	w.ret = 0;
 	bt_setup(t, w);
 	bt_scan_all(t, w);
-	bool more = !t.err && bt_rb_begin(t, w);
+	w.lazy = !t.err && w.wep != nullptr;
+	int more = !t.err && bt_rb_begin(t, w) ? 1 : 0;
 	// windows that see the region a collapse rewrites (target start .. end of its look-forward flank) are the only ones whose
 	// cache changes: like k_commit (simplify.hip), only those are rescanned -- normally just the target's own window
-	uint64_t *dirty = more ? (uint64_t *)t.alloc(((w.n + 63) / 64) * 8) : nullptr;
-	if (more && !dirty) more = false;
+	uint64_t *dirty = more && !w.lazy ? (uint64_t *)t.alloc(((w.n + 63) / 64) * 8) : nullptr;
+	if (more && !w.lazy && !dirty) more = 0;
 	while (more) {
 		more = bt_rb_run(t, w);
 		if (t.err) break;
-		if (more) {
+		if (more == 2) {                                               // lazy run: the loops need these windows as of now
+			for (uint32_t x = 0; x < w.nreq; x++) { bt_scan_instance(t, w, w.req[x]); w.wep[w.req[x]] = w.epoch; }
+			if (t.err) break;
+		} else if (more && w.lazy) {
+			bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT);
+			if (t.err) break;
+			w.epoch++;                                                 // every cached window is stale until somebody asks for it
+		} else if (more) {
 			const uint32_t tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
 			const uint32_t tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
 			for (uint32_t i = 0; i < w.n; i++) {

@@ -57,6 +57,48 @@ def gen_strains(L0: int = 4_600_000, n: int = 8, seed: int = 1, snp: float = 0.0
     return out
 
 
+def cascade_case(seed: int) -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """A small multi-strain input plus a 3- or 4-stage (k, D) cascade with growing k (the shape of the reference's parameter sets,
+    src/util.cpp:52-87): state -- sequences AND original positions -- is carried across copy-backs, so later stages see what
+    the earlier ones left (positions re-interpolated by collapses, closing separators stamped with the CURRENT record length,
+    dnasequence.cpp:96).  Every strain additionally gets a substitution and a short indel within reach of each record end, so
+    that collapses happen right at chromosome boundaries."""
+    rng = np.random.default_rng(7_000_003 * (seed + 1))
+    n = int(rng.integers(2, 9))
+    L0 = int(rng.integers(3_000, 24_000))
+    k = int(rng.choice([15, 16, 20, 25, 30, 31, 32]))
+    D = int(rng.integers(3 * k, 8 * k))
+    snp = float(rng.choice([0.005, 0.01, 0.03, 0.06]))
+    seqs = gen_strains(L0=L0, n=n, seed=500_000 + seed, snp=snp, indel_every=int(rng.choice([150, 400, 1000, 2000])),
+                       inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
+    out = []
+    for s in seqs:
+        g = bytearray(s)
+        for end in (0, 1):
+            reach = k + int(rng.integers(1, D))              # distance of the edit from the record end
+            if reach + 25 >= len(g):
+                continue
+            at = reach if end == 0 else len(g) - 1 - reach
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                continue
+            if kind == 1:
+                g[at] = b"ACGT"[(b"ACGT".index(g[at]) + int(rng.integers(1, 4))) % 4]
+            elif kind == 2:
+                ins = bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 12))))
+                g[at:at] = ins
+            else:
+                del g[at:at + int(rng.integers(1, 12))]
+        out.append(bytes(g))
+    nst = 3 if rng.random() < 0.5 else 4
+    stages, kk, dd = [], k, D
+    for _ in range(nst):
+        stages.append((kk, dd))
+        kk = int(min(kk + int(rng.integers(3, 9)), 40)) if rng.random() < 0.7 else int(min(2 * kk + int(rng.integers(0, 20)), 120))
+        dd = dd + int(rng.integers(20, 120)) if kk <= 40 else int(rng.integers(3 * kk, 6 * kk))
+    return out, stages
+
+
 def random_dna(total: int, nrec: int, seed: int) -> List[bytes]:
     """Uniform random ACGT split into nrec equal records (config 5 style input)."""
     rng = np.random.default_rng(seed)

@@ -96,6 +96,19 @@ def cases(skipped):
             if seed % 10 == 0:
                 cmds += ["write:%d:%d:%d:0:1" % (kb, max(2, min(kb, 5 + seed % 7)), kb + seed % 13)]
         yield "small/%03d" % seed, {"kind": "small_case", "seed": seed}, (lambda seqs=seqs: seqs), cmds, False, int(os.environ.get("GOLDEN_SMALL_TIMEOUT", "20"))
+    # three- and four-stage cascades on small strain sets (k 15-40 first, collapses at record ends, indels near record boundaries):
+    # the state carried across copy-backs -- positions re-interpolated by earlier collapses, closing separators restamped with
+    # the current record lengths (dnasequence.cpp:96) -- is what later stages read; every intermediate state is an output
+    for seed in range(48):
+        seqs, stages = W.cascade_case(seed)
+        cmds = ["stage:%d:%d:4" % st for st in stages] + ["dot:%d" % stages[-1][0]]
+        if seed % 4 == 0:
+            cmds += ["blocks:%d:%d:%d:0" % (stages[-1][0], min(stages[0][0], stages[-1][0]), 2 * stages[-1][0])]
+        yield "cascade/%03d" % seed, {"kind": "cascade_case", "seed": seed}, (lambda seqs=seqs: seqs), cmds, False, 120
+    # found by tools/stress.py in round 2 (a collapse at the very end of a chromosome in the SECOND stage): now a fixture of the reference
+    kw = dict(L0=13939, n=8, seed=110467, snp=0.03, indel_every=1000, inv_min=139, inv_max=696)
+    yield ("cascade/stress_110467", {"kind": "gen_strains", "args": kw}, (lambda kw=kw: W.gen_strains(**kw)),
+           ["stage:31:124:4", "stage:36:174:4", "stage:40:250:4", "dot:40"], False, 300)
     hp = "Helicobacter_pylori.fa.gz"
     sa = "Staphylococcus_aureus_pair.fa.gz"
     data = os.path.join(ROOT, "tests", "golden", "data")

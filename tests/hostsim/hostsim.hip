@@ -227,6 +227,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 		be.ctr[CTR_NE] = (uint32_t)ne0;
 		be.bind();
 		be.g.k = k; be.g.D = D; be.g.nid = bif_count;
+		if (const char *e = getenv("HOSTSIM_LAZY_MIN")) be.g.lazy_min = (uint32_t)atoi(e);      // 1: lazy windows for every transaction
 		// marking loop (reference src/indexedsequence.cpp:49-67): (chr,pos) ascending, front insertion
 		uint32_t nn = 0;
 		for (int s = 0; s < 2; s++) {

@@ -75,9 +75,9 @@ def _huge():
 
 
 HUGE = _huge()
-# small/078's second stage (k = 3, D = 144 on 1.4 kbp: ids grow to ~4500 instances, nearly every cached window sees every
-# collapse) takes ~9 min through the one-thread driver: its first stage runs here, the second one only on the GPU tools run
-SLOW_STAGES = {("small/078", "stage:3:144:3")}
+# (small/078's second stage -- k = 3, D = 144 on 1.4 kbp: ids grow to ~8000 instances and nearly every cached window sees every
+# collapse -- took ~9 min while every such window was rescanned after every collapse; large ids now rescan windows on demand.)
+SLOW_STAGES = set()
 
 
 @pytest.mark.parametrize("v", HUGE, ids=[v["name"] for v in HUGE])

@@ -34,6 +34,8 @@ def vector_input(v: dict) -> List[bytes]:
         seqs = [s.encode() for s in src["seqs"]]
     elif src["kind"] == "small_case":
         seqs = W.small_case(src["seed"])[0]
+    elif src["kind"] == "cascade_case":
+        seqs = W.cascade_case(src["seed"])[0]
     elif src["kind"] == "fasta":
         seqs = W.read_fasta(os.path.join(GOLDEN, "data", src["file"]))[1]
     elif src["kind"] == "gen_strains":
