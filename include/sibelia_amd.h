@@ -180,6 +180,14 @@ void sbl_group_destroy(sbl_group *group);
 sbl_status sbl_comm_attach_local(sbl_ctx *ctx, sbl_group *group, uint32_t rank);
 sbl_status sbl_comm_detach(sbl_ctx *ctx);
 
+/* The layout arithmetic of the sharded table, device-free (what the pipeline itself uses; for tests and for a host that wants to
+ * size its buffers): tiles scanned by `rank`, first bucket of every owner (owner(b) = (b * nranks) >> bits), and -- given the
+ * all-gathered count matrix count[p * nranks + q] = records p holds for owner q, and where the owners' ranges start in this
+ * rank's partitioned arrays -- the byte counts / offsets of the one all-to-all. */
+sbl_status sbl_shard_layout(uint32_t nranks, uint32_t rank, uint32_t bits, uint64_t ntiles, uint32_t *first_bucket /* nranks + 1 */, uint64_t *tile_range /* 2 */);
+sbl_status sbl_shard_exchange_plan(uint32_t nranks, uint32_t rank, const uint64_t *count, const uint32_t *send_at /* nranks + 1 */, uint64_t record_bytes,
+                                   uint64_t *sbytes, uint64_t *soff, uint64_t *rbytes, uint64_t *roff, uint64_t *nrecv);
+
 /* Tuning knob (0 = default): number of bifurcation ids speculatively committed per ordered round. */
 sbl_status sbl_set_window(sbl_ctx *ctx, uint32_t window);
 

@@ -23,7 +23,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
-           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess", "sbl_serialize_graph"]
+           "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess", "sbl_serialize_graph",
+           "sbl_shard_layout", "sbl_shard_exchange_plan", "sbl_glue_stripes", "sbl_comm_unique_id", "sbl_comm_attach_rccl", "sbl_comm_attach_local", "sbl_comm_detach"]
 
 
 class StageStats(C.Structure):
@@ -255,6 +256,34 @@ class BlockFinder:
 
 
 COMM_ID_BYTES = 128
+
+
+def shard_layout(nranks: int, rank: int, bits: int, ntiles: int) -> Tuple[np.ndarray, Tuple[int, int]]:
+    """Device-free layout arithmetic of the sharded k-mer table (csrc/shard.hip uses the same entry point): first bucket of
+    every owner (nranks + 1 values; owner(b) = (b * nranks) >> bits) and the tile range this rank scans."""
+    L = load_library()
+    fb = (C.c_uint32 * (nranks + 1))()
+    tr = (C.c_uint64 * 2)()
+    L.sbl_shard_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+    rc = L.sbl_shard_layout(nranks, rank, bits, ntiles, fb, tr)
+    if rc:
+        raise SibeliaError("sbl_shard_layout: " + L.sbl_strerror(rc).decode())
+    return np.array(fb, dtype=np.uint32), (int(tr[0]), int(tr[1]))
+
+
+def shard_exchange_plan(nranks: int, rank: int, count: np.ndarray, send_at: np.ndarray, record_bytes: int = 8):
+    """Byte counts / offsets of the one all-to-all: count[p, q] = records rank p holds for owner q (all-gathered), send_at = where
+    the owners' ranges start in this rank's partitioned arrays.  Returns (sbytes, soff, rbytes, roff, nrecv)."""
+    L = load_library()
+    cnt = np.ascontiguousarray(count, dtype=np.uint64).reshape(nranks, nranks)
+    sa = np.ascontiguousarray(send_at, dtype=np.uint32)
+    out = [np.zeros(nranks, dtype=np.uint64) for _ in range(4)]
+    nrecv = C.c_uint64()
+    L.sbl_shard_exchange_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 4 + [C.c_void_p]
+    rc = L.sbl_shard_exchange_plan(nranks, rank, cnt.ctypes.data, sa.ctypes.data, record_bytes, *[o.ctypes.data for o in out], C.byref(nrecv))
+    if rc:
+        raise SibeliaError("sbl_shard_exchange_plan: " + L.sbl_strerror(rc).decode())
+    return out[0], out[1], out[2], out[3], int(nrecv.value)
 
 
 def glue_stripes(blocks: np.ndarray, nchr: int) -> np.ndarray:

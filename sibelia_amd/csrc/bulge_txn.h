@@ -381,6 +381,11 @@ struct BulgeWork {
 	bool lazy;
 	uint32_t epoch, *wep;
 	uint32_t req[2], nreq;
+	// The J loop of a group skips members that are no longer valid or share I's endChar (bulgeremoval.cpp:383-386): one look per
+	// member and per I, i.e. quadratic in the group size -- tens of millions of looks on the dense vectors.  With jscan set
+	// bt_rb_run hands that search to the caller (returns 3: move idJ to the next candidate of [idJ, group end), or to the end;
+	// then set jready), which the kernels do with 64 lanes x 4 members per step.
+	bool jscan, jready;
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
@@ -427,7 +432,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc2(n);
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
@@ -847,8 +852,21 @@ __host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w, int any_bulges
 	return true;
 }
 
+// the search bt_rb_run asks for with return code 3, one thread
+__host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
+{
+	const uint32_t ge = w.ab.grp_off[w.gi + 1], kmerI = w.ab.grp_mem[w.idI];
+	while (w.idJ < ge) {
+		const uint32_t kmerJ = w.ab.grp_mem[w.idJ];
+		if (bt_pvalid(t, w.start[kmerJ]) && w.endc[kmerI] != w.endc[kmerJ]) break;
+		w.idJ++;
+	}
+	w.jready = true;
+}
+
 // returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
-// the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards.
+// the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards,
+// 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search).
 __host__ __device__ inline int bt_rb_run(Txn &t, BulgeWork &w)
 {
 	const uint32_t D = t.g.D;
@@ -858,18 +876,19 @@ __host__ __device__ inline int bt_rb_run(Txn &t, BulgeWork &w)
 			const uint32_t kmerI = w.ab.grp_mem[w.idI];
 			if (!w.inI) {
 				if (!bt_pvalid(t, w.start[kmerI])) { w.idI++; continue; }
-				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true;
+				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true; w.jready = false;
 			}
 			while (w.idJ < ge) {
+				if (w.jscan && !w.jready && ge - w.idJ > 8) return 3;  // the caller finds the next candidate J (see jscan); short tails are walked here
 				const uint32_t kmerJ = w.ab.grp_mem[w.idJ];
-				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) { w.idJ++; continue; }
+				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) { w.idJ++; w.jready = false; continue; }
 				if (w.lazy) {                                        // everything below reads the windows of I and J: as of NOW, like the reference's walks
 					uint32_t nr = 0;
 					if (w.wep[kmerI] != w.epoch) w.req[nr++] = kmerI;
 					if (w.wep[kmerJ] != w.epoch) w.req[nr++] = kmerJ;
 					if (nr) { w.nreq = nr; return 2; }
 				}
-				w.idJ++;
+				w.idJ++; w.jready = false;
 				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
 				// after a collapse that rewrote I's own window
 				if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }

@@ -316,6 +316,36 @@ size_t allgatherv(sbl_ctx *c, Clock &clk, const char *send, size_t sbytes, DevBu
 }
 }
 
+// ---- the layout of the sharded table and of its one exchange, as plain arithmetic (no device, no communicator): what the
+// pipeline below uses, exported so that the tables can be checked for any number of ranks without GPUs (tests/test_shard_plan.py)
+//   tiles     rank r scans tiles [ntiles * r / R, ntiles * (r + 1) / R)
+//   buckets   owner p holds buckets [ceil(p * 2^bits / R), ceil((p + 1) * 2^bits / R)), i.e. owner(b) = (b * R) >> bits
+extern "C" sbl_status sbl_shard_layout(uint32_t nranks, uint32_t rank, uint32_t bits, uint64_t ntiles, uint32_t *first_bucket /* nranks + 1 */, uint64_t *tile_range /* 2 */)
+{
+	if (!nranks || rank >= nranks || bits > 30 || !first_bucket || !tile_range) return SBL_ERR_BAD_ARG;
+	const unsigned long long nb = 1ull << bits;
+	for (uint32_t p = 0; p <= nranks; p++) first_bucket[p] = (uint32_t)(((unsigned long long)p * nb + nranks - 1) / nranks);
+	tile_range[0] = ntiles * rank / nranks; tile_range[1] = ntiles * (rank + 1) / nranks;
+	return SBL_OK;
+}
+//   exchange  count[p * R + q] = records rank p holds for owner q (all-gathered).  Rank `rank` sends owner q the records
+//             [send_at[q], send_at[q + 1]) of its partitioned arrays and stores what p sends it behind what the ranks before p sent
+extern "C" sbl_status sbl_shard_exchange_plan(uint32_t nranks, uint32_t rank, const uint64_t *count /* nranks x nranks */, const uint32_t *send_at /* nranks + 1 */,
+                                              uint64_t record_bytes, uint64_t *sbytes, uint64_t *soff, uint64_t *rbytes, uint64_t *roff, uint64_t *nrecv)
+{
+	if (!nranks || rank >= nranks || !count || !send_at || !sbytes || !soff || !rbytes || !roff || !nrecv) return SBL_ERR_BAD_ARG;
+	uint64_t got = 0;
+	for (uint32_t p = 0; p < nranks; p++) {
+		if (count[(size_t)rank * nranks + p] != (uint64_t)send_at[p + 1] - send_at[p]) return SBL_ERR_BAD_ARG;      // my own row must be what I partitioned
+		sbytes[p] = count[(size_t)rank * nranks + p] * record_bytes; soff[p] = (uint64_t)send_at[p] * record_bytes;
+		const uint64_t m = count[(size_t)p * nranks + rank];
+		rbytes[p] = m * record_bytes; roff[p] = got * record_bytes;
+		got += m;
+	}
+	*nrecv = got;
+	return SBL_OK;
+}
+
 static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);
 void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
@@ -339,7 +369,10 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 	c->stats.exchange_bytes = 0;
 	const size_t E = c->nelem, nwords = (E + 31) / 32;
 	const size_t ntiles = (nwords + KM_TILE_WORDS - 1) / KM_TILE_WORDS;
-	const size_t t0 = ntiles * r / R, t1 = ntiles * (r + 1) / R;
+	std::vector<unsigned> fb(R + 1);
+	uint64_t trange[2];
+	SBL_CHECK(sbl_shard_layout(R, r, 4, ntiles, fb.data(), trange) == SBL_OK, SBL_ERR_INTERNAL, "shard layout");
+	const size_t t0 = trange[0], t1 = trange[1];
 	const size_t nall = ntiles * (size_t)(KM_TILE_WORDS * 32), nmine = (t1 - t0) * (size_t)(KM_TILE_WORDS * 32);
 	SBL_CHECK(nall < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many positions for 32-bit record indices");
 	c->cur_k = k;
@@ -360,8 +393,8 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		// ---- A: records of my slice, partitioned by hash prefix
 		for (int i = 0; i < 2; i++) { c->d_rec_keys[i].ensure(nmine * 8 + 16); c->d_rec_vals[i].ensure(nmine * 8 + 16); }
 		c->d_boff.ensure((nb + 1) * 4 + 64);
-		std::vector<unsigned> fb(R + 1), send_at(R + 1, 0);
-		for (uint32_t p = 0; p <= R; p++) fb[p] = (unsigned)(((unsigned long long)p * nb + R - 1) / R);      // first bucket of owner p
+		std::vector<unsigned> send_at(R + 1, 0);
+		SBL_CHECK(sbl_shard_layout(R, r, bits, ntiles, fb.data(), trange) == SBL_OK, SBL_ERR_INTERNAL, "shard layout");      // first bucket of every owner
 		if (nmine) {
 			k_kmer_records<<<(unsigned)std::min<size_t>(t1 - t0, 256 * 16), KM_THREADS, 0, s>>>(c->d_pk.as<unsigned long long>(), c->d_sp.as<unsigned>(), nwords, E, k, t0, t1,
 			                                                                                  c->d_rec_keys[0].as<unsigned long long>(), c->d_rec_vals[0].as<unsigned long long>());
@@ -381,13 +414,13 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		for (uint32_t p = 0; p < R; p++) scount[p] = send_at[p + 1] - send_at[p];
 		clk.time([&] { cm->allgather_host(c, scount.data(), R * 8, allcount.data()); });
 		std::vector<size_t> sb(R), so(R), rb(R), ro(R);
-		nrecv = 0;
-		for (uint32_t p = 0; p < R; p++) {
-			sb[p] = (size_t)scount[p] * 8; so[p] = (size_t)send_at[p] * 8;
-			const size_t m = allcount[(size_t)p * R + r];
-			rb[p] = m * 8; ro[p] = nrecv * 8;
-			nrecv += m;
-			if (p != r) c->stats.exchange_bytes += 2 * sb[p];
+		{
+			static_assert(sizeof(size_t) == sizeof(uint64_t), "64-bit host");
+			uint64_t got = 0;
+			SBL_CHECK(sbl_shard_exchange_plan(R, r, (const uint64_t *)allcount.data(), send_at.data(), 8, (uint64_t *)sb.data(), (uint64_t *)so.data(),
+			                                  (uint64_t *)rb.data(), (uint64_t *)ro.data(), &got) == SBL_OK, SBL_ERR_INTERNAL, "exchange plan: the gathered counts contradict my own");
+			nrecv = (size_t)got;
+			for (uint32_t p = 0; p < R; p++) if (p != r) c->stats.exchange_bytes += 2 * sb[p];
 		}
 		SBL_CHECK(nrecv < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many records for one owner");
 		c->d_recv.ensure(nrecv * 8 + 16); c->d_send.ensure(nrecv * 8 + 16);      // received keys / values

@@ -1235,6 +1235,55 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 	__syncthreads();
 }
 
+// ---- the caller side of BulgeWork::jscan: next member of [idJ, group end) that is still valid and whose endChar differs from I's
+// (bt_rb_next_j with 64 lanes x 4 members per step: member -> instance -> node -> dead flag is three dependent look-ups)
+__device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, unsigned lane)
+{
+	const unsigned ge = w.ab.grp_off[w.gi + 1];
+	const char ecI = w.endc[w.ab.grp_mem[w.idI]];
+	unsigned j0 = w.idJ, found = ge;
+	__syncthreads();                                                       // (everybody has read idJ before lane 0 moves it)
+	while (j0 < ge && found == ge) {
+		unsigned m[4], st[4]; char ec[4]; bool in[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { const unsigned idx = j0 + 64u * u + lane; in[u] = idx < ge; m[u] = in[u] ? w.ab.grp_mem[idx] : 0u; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) { st[u] = in[u] ? w.start[m[u]] : 0u; ec[u] = in[u] ? w.endc[m[u]] : ecI; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const bool cand = in[u] && ec[u] != ecI && !g.ndead[st[u] >> 1];
+			const unsigned long long b = __ballot(cand);
+			if (b && found == ge) found = j0 + 64u * u + (unsigned)__builtin_ctzll(b);
+		}
+		j0 += 256;
+	}
+	if (lane == 0) { w.idJ = found; w.jready = true; }
+	__syncthreads();
+}
+
+// ---- marks-only window scan, one LANE per instance (64 instances in flight): what AnyBulges needs of a window -- mark at step 0,
+// character at step k, length, the marked steps -- and nothing else (bt_scan_instance with lite set, minus the element cache).
+// For ids with many instances: a lane walks its window with dependent loads, but 64 windows advance together, where the
+// wave-cooperative scan spends a memory round trip or more on every single window.  Also writes the endChar.
+__device__ __forceinline__ void lane_scan_marks(const GraphView &g, const BulgeWork &w, unsigned i)
+{
+	const unsigned packed = w.start[i], dir = packed & 1u, k = g.k, ws = w.ws;
+	unsigned e = w.sel[i], nm = 0, s = 0;
+	char ck = ' ';
+	unsigned long long *mk = reinterpret_cast<unsigned long long *>(w.wmk) + (size_t)i * w.mks;
+	for (; s < ws; s++) {
+		const uint8_t c = g.ch[e];
+		const unsigned b = g.bif[dir][e];
+		if (s == 0) w.wst[i] = b;
+		if (s == k) ck = dir ? bt_comp((char)c) : (char)c;
+		if (c == BT_SEP) break;
+		if (s && b != BT_NONE) { if (nm < w.mks) mk[nm] = ((unsigned long long)s << 32) | b; nm++; }
+		e = dir ? g.pv[e] : g.nx[e];
+	}
+	w.wlen[i] = s; w.wmn[i] = nm; w.wck[i] = ck;
+	w.endc[i] = s >= k + 1 ? ck : ' ';                                 // bt_end_chars
+}
+
 // ---- AnyBulges with 64 lanes (writer pass) --------------------------------------------------------------------
 // bt_any_bulges looks every mark of every window up in the Boost-ordered map; for homologous instances nearly all of
 // those look-ups change nothing (the id has an entry with the same endChar).  Here the lanes classify 64 marks at a time
@@ -1245,20 +1294,23 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 struct ABShared { unsigned *skey, *sval; unsigned bits, distinct; int mode; unsigned batch[64]; };   // mode 0: serial fallback, 1: wave path
 
 #define AB_COUNT_SLOTS 512u
-__device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane)
+// count_slots: size of the distinct-id counting set (a power of two >= AB_COUNT_SLOTS; the dense kernel has room for more)
+__device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane, bool endc_ready = false,
+                                               const unsigned count_slots = AB_COUNT_SLOTS, unsigned *count_tab = nullptr /* caller's own table of count_slots words */)
 {
 	const unsigned D = g.D, n = w.n;
+	const unsigned cshift = 32u - (unsigned)__builtin_ctz(count_slots);
 	unsigned mark = 0;
 	if (lane == 0) {
-		bt_end_chars(t, w);
+		if (!endc_ready) bt_end_chars(t, w);
 		mark = t.fscr_used;
-		sh.skey = (unsigned *)t.falloc(AB_COUNT_SLOTS * 4);
+		sh.skey = count_tab ? count_tab : (unsigned *)t.falloc(count_slots * 4);
 		sh.mode = sh.skey ? 1 : 0;
 	}
 	__syncthreads();
 	if (sh.mode) {
 		// ---- pass 1: number of distinct ids that can get an entry
-		for (unsigned i = lane; i < AB_COUNT_SLOTS; i += 64) sh.skey[i] = BT_NONE;
+		for (unsigned i = lane; i < count_slots; i += 64) sh.skey[i] = BT_NONE;
 		__syncthreads();
 		unsigned distinct = 0;
 		bool full = false;
@@ -1273,14 +1325,14 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 				bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
 				unsigned long long ms = __ballot(stop);
 				unsigned upto = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
-				if (distinct + upto > (AB_COUNT_SLOTS * 3) / 4) { full = true; break; }
+				if (distinct + upto > (count_slots * 3) / 4) { full = true; break; }
 				bool fresh = false;
 				if (lane < upto) {
-					unsigned h = (b * 2654435761u) >> 23;
+					unsigned h = (b * 2654435761u) >> cshift;
 					for (;;) {
 						unsigned old = atomicCAS(&sh.skey[h], BT_NONE, b);
 						if (old == BT_NONE || old == b) { fresh = old == BT_NONE; break; }
-						h = (h + 1) & (AB_COUNT_SLOTS - 1);
+						h = (h + 1) & (count_slots - 1);
 					}
 				}
 				distinct += (unsigned)__popcll(__ballot(fresh));
@@ -1430,7 +1482,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
-		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; }
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy; }
 		__syncthreads();
 		PH_ADD(2);
 		while (flag) {
@@ -1438,6 +1490,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			__syncthreads();
 			PH_ADD(3);
 			if (!flag) break;
+			if (flag == 3) { wave_next_j(g, w, lane); continue; }       // large group: the search for the next J, 256 members per step
 			if (flag == 2) {                                             // the loops need these windows as of now
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
@@ -1607,6 +1660,110 @@ __global__ void __launch_bounds__(64) k_chain(GraphView g, uint8_t *arena, unsig
 		unsigned stop = lane == 0 ? (g.ctr[CTR_ERR] != 0 || g.ctr[CTR_VIOL] != BT_NONE || g.big[id] != 0) : 0u;   // big: did not even fit the big arena
 		if (__shfl((int)stop, 0)) break;
 	}
+}
+
+// ---- tiny / dense inputs: the whole SimplifyGraph in ONE launch -----------------------------------------------------------------
+// for iteration: for id ascending: RemoveBulges(id) (reference src/blockfinder.cpp:29-43), literally: one wave walks the ids in order
+// with nothing else in flight -- no snapshot, no probe, no reservation, no stamps, no checkpoint.  This is for inputs whose whole
+// graph is a few thousand elements (the host chooses it by size, sbl_simplify_run): there the ordered rounds have nothing to run in
+// parallel -- low-complexity sequence at k = 3 .. 10 makes every element a bifurcation, ids have thousands of instances, and every
+// transaction conflicts with every other -- and what counts is the cost of ONE RemoveBulges call:
+//   * one ListPositions and one pass over the windows per call (the round machinery examines a pending id three times: probe,
+//     verdict pass, writer pass), marks only, one LANE per instance (lane_scan_marks);
+//   * lazy windows (BulgeWork::lazy): FillVisit / Overlap / MaxBifurcationMultiplicity read the windows of I and J only, scanned
+//     with 64 lanes when the loops ask for them, as the reference walks them when it needs them; a collapse costs two window scans,
+//     not a pass over thousands of cached windows;
+//   * the J search of large bulge groups with 64 lanes (wave_next_j).
+// Capacity errors (element / node pool, arena) stop the kernel; the host then reruns the stage through the ordered rounds, which
+// can grow their pools and replay.
+#define DENSE_FAST_BYTES 40960u
+#define DENSE_COUNT_SLOTS 4096u             // distinct ids of one AnyBulges map counted in LDS (16 KB of the scratch)
+#define DENSE_LANE_SCAN_MIN 24u             // instances from which the marks-only scan runs one lane per instance
+__device__ __forceinline__ void dense_remove_bulges(const GraphView &g, Txn &t, BulgeWork &w, int &flag, ABShared &absh, uint8_t *fast, unsigned id,
+                                                    uint8_t *arena, unsigned arena_bytes)
+{
+	const unsigned lane = threadIdx.x;
+	unsigned *count_tab = reinterpret_cast<unsigned *>(fast);              // the first 16 KB of the scratch: AnyBulges' counting set
+	if (lane == 0) {
+		t.init(g, id, 0, 0, arena, arena_bytes);                           // mode 0: nothing to validate against
+		t.chain = true; t.defer_push = true; t.ext_stamps = true; w.ret = 0;
+		t.fscr = fast + DENSE_COUNT_SLOTS * 4; t.fscr_cap = DENSE_FAST_BYTES - DENSE_COUNT_SLOTS * 4;
+		t.tc_cap = 4096; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true;
+	}
+	__syncthreads();
+	wave_setup(g, t, w, false, lane, flag);
+	if (flag) {
+		if (lane == 0) w.epoch = 1;                                        // wep[] = 0: no window has been scanned in full yet
+		__syncthreads();
+		if (w.n >= DENSE_LANE_SCAN_MIN) {
+			for (unsigned i0 = 0; i0 < w.n; i0 += 64) if (i0 + lane < w.n) lane_scan_marks(g, w, i0 + lane);
+		} else {
+			wave_scan_all(g, w, lane, BT_NONE, 0, 0, id);
+			__syncthreads();
+			for (unsigned i = lane; i < w.n; i += 64) w.wep[i] = 1;
+			if (lane == 0) bt_end_chars(t, w);
+		}
+		__syncthreads();
+		int any = wave_any_bulges(g, t, w, absh, lane, true, DENSE_COUNT_SLOTS, count_tab);
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = true; w.jscan = true; }
+		__syncthreads();
+		while (flag) {
+			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
+			__syncthreads();
+			if (!flag) break;
+			if (flag == 3) { wave_next_j(g, w, lane); continue; }
+			if (flag == 2) {
+				const unsigned nr = w.nreq;
+				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, BT_NONE, 0, 0, id);
+				__syncthreads();
+				if (lane == 0) for (unsigned x = 0; x < nr; x++) w.wep[w.req[x]] = w.epoch;
+				__syncthreads();
+				continue;
+			}
+			wave_collapse(g, t, w, lane, BT_NONE);
+			if (t.err) break;
+			if (lane == 0) w.epoch++;
+			__syncthreads();
+		}
+	}
+	// ---- Cleanup (bifurcationstorage.cpp:33-41)
+	__syncthreads();
+	if (!t.err && t.tc_n) {
+		if (t.tc_n <= t.tc_cap) {
+			for (unsigned x = lane; x < t.tc_n; x += 64) { unsigned v = g.nidst[t.tc_list[x]]; atomicSub(&g.lsize[v & 1u][v >> 1], 1u); }
+		} else if (lane == 0) t.cleanup();
+	}
+	if (lane == 0) {
+		if (t.err) atomicOr(&g.ctr[CTR_ERR], t.err);
+		if (w.n >= 2) { atomicAdd(&g.ctr[CTR_BULGES], w.ret); atomicAdd(&g.ctr[CTR_TXN], 1u); }
+	}
+}
+
+// out: [0] iterations run, [1] ids examined in the last iteration (progress)
+__global__ void __launch_bounds__(64) k_dense_stage(GraphView g, uint8_t *arena, unsigned arena_bytes, unsigned max_iter, unsigned *out)
+{
+	__shared__ Txn t;
+	__shared__ BulgeWork w;
+	__shared__ int flag;
+	__shared__ ABShared absh;
+	__shared__ __attribute__((aligned(16))) uint8_t fast[DENSE_FAST_BYTES];
+	const unsigned lane = threadIdx.x;
+	unsigned iter = 0, total = 0;
+	bool stop = false;
+	do {
+		iter++;
+		for (unsigned id = 0; id < g.nid && !stop; id++) {
+			if (g.lsize[0][id] + g.lsize[1][id] < 2) continue;              // ListPositions < 2: nothing to do (bulgeremoval.cpp:336-337)
+			__syncthreads();
+			dense_remove_bulges(g, t, w, flag, absh, fast, id, arena, arena_bytes);
+			__syncthreads();
+			__threadfence();                                               // list sizes / marks changed through atomics: later plain loads must see them
+			stop = __shfl((int)(lane == 0 ? *(volatile unsigned *)&g.ctr[CTR_ERR] : 0u), 0) != 0;
+		}
+		__threadfence();
+		total = (unsigned)__shfl((int)(lane == 0 ? *(volatile unsigned *)&g.ctr[CTR_BULGES] : 0u), 0);
+	} while (!stop && total > 0 && iter < max_iter);                        // `total` is cumulative (blockfinder.cpp:43)
+	if (lane == 0) out[0] = iter;
 }
 
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
@@ -2013,7 +2170,17 @@ static void scan_u32(sbl_ctx *c, SimplifyState *st, unsigned *in, unsigned *out,
 	HIP_TRY(rocprim::exclusive_scan(st->scantmp.p, tmp, in, out, 0u, n, rocprim::plus<unsigned>(), c->stream));
 }
 
+// Inputs up to this many elements take the one-launch path (k_dense_stage) first; SBL_NO_DENSE_PATH=1 / SBL_DENSE_MAX_ELEMS=n: test switches
+#define DENSE_MAX_ELEMS (1u << 16)
+static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense);
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
+{
+	// the stage's input (d_ch / d_op) is only replaced by the copy-back at the very end, so a one-launch attempt that ran out of
+	// pool or arena space is simply followed by the general path from the same input
+	if (simplify_run_impl(c, k, D, max_iter, progress, user, bulges, true)) return;
+	(void)simplify_run_impl(c, k, D, max_iter, progress, user, bulges, false);
+}
+static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense)
 {
 	hipStream_t s = c->stream;
 	if (!c->simp) { c->simp = new SimplifyState(); HIP_TRY(hipHostMalloc((void **)&c->simp->h_ctr, CTR_COUNT * 4)); }
@@ -2044,7 +2211,12 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	sbl_compact_marks(c, 1);
 	size_t n0 = c->nmarks[0], n1 = c->nmarks[1], ninst = n0 + n1;
 	c->stats.instances = ninst;
-	size_t cap_n = 4 * ninst + (1u << 20);
+	size_t dense_max = DENSE_MAX_ELEMS;
+	if (const char *e = getenv("SBL_DENSE_MAX_ELEMS")) dense_max = (size_t)atoll(e);
+	const bool dense = allow_dense && E <= dense_max && be.nid_ > 0 && getenv("SBL_NO_DENSE_PATH") == nullptr;
+	// (the one-launch path cannot grow a pool and replay: low-complexity input makes hundreds of nodes per collapse, and 16 M nodes are 270 MB)
+	size_t cap_n = dense ? std::max<size_t>(4 * ninst + (1u << 20), 16u << 20) : 4 * ninst + (1u << 20);
+	if (dense) if (const char *e = getenv("SBL_TEST_DENSE_NODE_SLACK")) cap_n = ninst + (size_t)atoll(e);      // test hook: provoke the fall-back
 	SBL_CHECK(cap_n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
 	be.cap_n = (uint32_t)cap_n;
 	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nidst.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);
@@ -2132,7 +2304,7 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		st->claims.ensure((size_t)w * (CLAIM_CAP + 1) * 4);
 		st->live.ensure((size_t)w + 64);
 	};
-	try { round_buffers(window_max); }
+	try { if (!dense) round_buffers(window_max); }
 	catch (const SblError &) {                                        // a smaller or partly occupied GPU: the pinned window always was enough
 		if (window_max == window) throw;
 		(void)hipGetLastError();
@@ -2152,7 +2324,36 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	HIP_TRY(hipEventRecord(c->ev[3], s));
 
 	// ---- SimplifyGraph
-	SimplifyReport rep = simplify_graph(be, max_iter, window, progress, user, window_max);
+	SimplifyReport rep;
+	if (dense) {
+		// tiny input: for iteration, for id, RemoveBulges(id) in one launch (k_dense_stage)
+		be.g.lazy_min = 1;                                            // every id keeps full-size mark lists and takes lazy windows
+		st->big_arena.ensure(be.big_arena_bytes);
+		unsigned *d_out = st->ctr.as<unsigned>() + CTR_DETAIL;        // (the violation-detail words are unused here)
+		HIP_TRY(hipEventRecord(be.ev[2], s));
+		k_dense_stage<<<1, 64, 0, s>>>(be.g, st->big_arena.as<uint8_t>(), be.big_arena_bytes, max_iter, d_out);
+		HIP_TRY(hipEventRecord(be.ev[3], s));
+		HIP_TRY(hipGetLastError());
+		be.read_ctr();
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, be.ev[2], be.ev[3]));
+		be.commit_ms = ms;
+		if (st->h_ctr[CTR_ERR]) {
+			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] one-launch path: capacity error %u, falling back to the ordered rounds\n", st->h_ctr[CTR_ERR]);
+			return false;
+		}
+		rep.iterations = st->h_ctr[CTR_DETAIL]; rep.bulges = st->h_ctr[CTR_BULGES]; rep.transactions = rep.executed = st->h_ctr[CTR_TXN];
+		rep.chain_transactions = rep.transactions;
+		if (progress) {                                               // the reference's callback sequence (blockfinder.cpp:23-48), delivered after the launch
+			progress(0, SBL_PROGRESS_START, user);
+			const uint64_t threshold = ((uint64_t)be.nid_ * max_iter) / 50, processed = (uint64_t)rep.iterations * ((uint64_t)be.nid_ + 1);
+			const uint64_t due = threshold ? processed / threshold : processed;
+			uint64_t tp = 0;
+			for (uint64_t i = 0; i < due; i++) { tp = std::min<uint64_t>(tp + 1, 50); progress((size_t)tp, SBL_PROGRESS_RUN, user); }
+			progress(50, SBL_PROGRESS_END, user);
+		}
+	} else
+		rep = simplify_graph(be, max_iter, window, progress, user, window_max);
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 
 	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays
@@ -2220,4 +2421,5 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 		fprintf(stderr, "[sbl] longest transaction: %llu cycles, %llu instances, %llu collapses\n", mx[0], mx[1] >> 32, mx[1] & 0xFFFFFFFFull);
 	}
 	*bulges = rep.bulges;
+	return true;
 }

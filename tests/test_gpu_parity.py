@@ -21,20 +21,17 @@ def _bulges(v):
     return sum(o.get("bulges", 0) for o in v["outputs"])
 
 
-# Low-complexity small cases with thousands of collapses on a few hundred bases are the dense-conflict regime: the ordered
-# rounds commit one or two transactions each there, and the driver hands the pending ids to the serial chain (k_chain).
+# Low-complexity small cases with thousands of collapses on a few hundred bases are the dense-conflict regime: every element is a
+# bifurcation, ids have thousands of instances, every transaction conflicts with every other.  Inputs of this size take the
+# one-launch path (k_dense_stage: for iteration, for id, RemoveBulges(id) on one wave with lazy windows); ALL vectors run below.
+# The same vectors up to 8000 collapses also run through the ordered rounds + serial chain (SBL_NO_DENSE_PATH=1), which is what a
+# larger input of the same kind gets.
 SUPPORTED = VECS
-# Beyond 8000 collapses (k = 3 .. 10 on a few hundred bases: ids whose instance lists grow to tens of thousands of entries, every
-# transaction in conflict with every other) a case takes 13 - 97 s on the GPU (serial chain, one wave, O(instances) bookkeeping per
-# collapse).  The three that finish in about half a minute run below (HUGE_RUN); small/171, small/236 and small/145 (43 / 62 / 94 s)
-# are replayed bit-exact by `tools/dense_vectors.py` (profiles/r02_dense_vectors.txt) but kept out of the suite for its running
-# time, small/078 -- k = 3, D = 144 -- takes more than 10 min.  All seven (078: its first stage) also run through the product's
-# transaction code on the host (tests/test_hostsim.py::test_transactions_match_reference_on_the_densest_vectors).
 DENSE = [v for v in VECS if v["name"].startswith("small/") and 400 <= _bulges(v) < 8000]
 HUGE = [v for v in VECS if v["name"].startswith("small/") and _bulges(v) >= 8000]
 FAST = [v for v in SUPPORTED if not v["name"].startswith(("real/", "synth/strains2", "synth/strains8")) and v not in DENSE and v not in HUGE]
-HUGE_RUN = [v for v in HUGE if v["name"] in ("small/074", "small/197", "small/126")]
 BIG = [v for v in SUPPORTED if v["name"].startswith(("real/", "synth/strains2"))]
+assert len(FAST) + len(DENSE) + len(HUGE) + len(BIG) + 2 == len(VECS)      # (+ the two 8-strain vectors, replayed by their own tests below): nothing is left out
 
 
 def _bf(seqs):
@@ -57,9 +54,40 @@ def test_hip_matches_reference_dense_conflicts(v):
     V.replay(v, _bf)
 
 
-@pytest.mark.parametrize("v", HUGE_RUN, ids=[v["name"] for v in HUGE_RUN])
+@pytest.mark.parametrize("v", HUGE, ids=[v["name"] for v in HUGE])
 def test_hip_matches_reference_densest(v):
+    """every golden vector of the dense regime, small/078's second stage (k = 3, D = 144) included, inside a time bound that a
+    return of the old cliff (13 - 94 s, > 10 min for 078) would break"""
+    import time
+    t0 = time.time()
     V.replay(v, _bf)
+    assert time.time() - t0 < 30.0, "dense vector took %.1f s" % (time.time() - t0)
+
+
+@pytest.mark.parametrize("v", DENSE[::3], ids=[v["name"] for v in DENSE[::3]])
+def test_dense_vectors_through_the_ordered_rounds(v, monkeypatch):
+    """the general path (ordered rounds, serial chain with lazy windows) on every third dense vector: what an input of the same kind
+    above the one-launch size limit runs through"""
+    monkeypatch.setenv("SBL_NO_DENSE_PATH", "1")
+    V.replay(v, _bf)
+
+
+def test_one_launch_path_falls_back_when_a_pool_runs_out(monkeypatch):
+    """k_dense_stage cannot grow a pool and replay: with a node pool that is too small it must stop, and the stage must come out of
+    the ordered rounds (which can) with the reference's result all the same"""
+    v = [x for x in VECS if x["name"] == "small/074"][0]
+    monkeypatch.setenv("SBL_TEST_DENSE_NODE_SLACK", "2000")
+    seqs = V.vector_input(v)
+    bf = _bf(seqs)
+    try:
+        outs = [o for o in v["outputs"]]
+        for o in outs[:2]:                                   # enum + the first stage (8000 collapses need far more than 2000 new nodes)
+            got = V.run_cmd(bf, o["cmd"])
+            assert V.F.sha256(got) == o["sha256"], o["cmd"]
+        st = bf.stats()
+        assert st["rounds"] > 0, "the stage was expected to come out of the ordered rounds"
+    finally:
+        bf.close()
 
 
 @pytest.mark.parametrize("window", [1, 7, 100000])
