@@ -151,6 +151,15 @@ sbl_status sbl_serialize_graph(sbl_ctx *ctx, uint32_t k, const char **text, uint
  * Array owned by the ctx, valid until the next call. */
 sbl_status sbl_kmer_hashes(sbl_ctx *ctx, uint32_t k, const uint64_t **values, uint64_t *n);
 
+/* The reference's rand() is process-global: besides sanitising ambiguous bases (src/indexedsequence.cpp:31-37) it names the two
+ * temporary files every index built WITHOUT -r spills its suffix array to (src/platform.cpp:52-58 via src/vertexenumeration.cpp:101,125:
+ * 24 draws per index).  A context owns its stream; sbl_set_tempfile_mode(ctx, 1) makes every full-state index (sbl_simplify_stage,
+ * sbl_list_edges, sbl_generate_blocks' main index, sbl_enumerate) draw those 24 values after its sanitising draws, as
+ * BlockFinder(chrList, tempDir) does -- nothing is spilled, only the stream stays in step.  sbl_rand_advance skips n values, for a
+ * host whose surrounding code consumes the same stream in other places. */
+sbl_status sbl_set_tempfile_mode(sbl_ctx *ctx, int on);
+sbl_status sbl_rand_advance(sbl_ctx *ctx, uint64_t n);
+
 /* Stage-boundary checkpoint of the resident state (sequences + original positions), device to device.
  * The reference keeps no resumable state; the stage boundary is the natural one. */
 sbl_status sbl_save_state(sbl_ctx *ctx);

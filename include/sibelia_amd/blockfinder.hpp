@@ -47,7 +47,13 @@ namespace SyntenyFinderAMD
 		template <class FASTARecordVector>
 		explicit BlockFinder(const FASTARecordVector &chrList, int device = -1) { Init(chrList, device); }
 		template <class FASTARecordVector>
-		BlockFinder(const FASTARecordVector &chrList, const std::string & /*tempDir: nothing is spilled*/, int device = -1) { Init(chrList, device); }
+		// tempDir: nothing is spilled; a non-empty one (the reference's mode without -r) keeps the rand() stream in step with the names
+		// of the temporary files the reference would create there (sbl_set_tempfile_mode)
+		BlockFinder(const FASTARecordVector &chrList, const std::string &tempDir, int device = -1)
+		{
+			Init(chrList, device);
+			if (!tempDir.empty()) Check(sbl_set_tempfile_mode(ctx_, 1), "BlockFinder");
+		}
 		explicit BlockFinder(const FromFasta &f, int device = -1)
 		{
 			sbl_status st = sbl_create(&ctx_, device);

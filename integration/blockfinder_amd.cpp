@@ -48,7 +48,7 @@ namespace SyntenyFinder
 		Init(chrList);
 	}
 
-	// tempDir: the reference spills its suffix array there unless -r is given; nothing is spilled here
+	// tempDir: the reference spills its suffix array there unless -r is given; nothing is spilled here, but see Init
 	BlockFinder::BlockFinder(const std::vector<FASTARecord> & chrList, const std::string & tempDir): tempDir_(tempDir), iseq_(0), originalChrList_(&chrList)
 	{
 		Init(chrList);
@@ -56,7 +56,10 @@ namespace SyntenyFinder
 
 	void BlockFinder::Init(const std::vector<FASTARecord> & chrList)
 	{
-		std::unique_ptr<Device> device(new Device(chrList));          // sbl_create + sbl_load: throws std::runtime_error without an MI355X
+		// sbl_create + sbl_load: throws std::runtime_error without an MI355X.  tempDir_ (set by the two-argument constructor, i.e. without
+		// -r) switches the context to temp-file mode: the names of the reference's temporary files come out of the same rand() stream as
+		// the replacements of ambiguous bases (src/platform.cpp:57), so the stream has to advance as if they had been created
+		std::unique_ptr<Device> device(new Device(chrList, tempDir_));
 		std::lock_guard<std::mutex> hold(tableLock);
 		table[this] = std::move(device);
 	}

@@ -24,7 +24,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
            "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess", "sbl_serialize_graph",
-           "sbl_shard_layout", "sbl_shard_exchange_plan", "sbl_glue_stripes", "sbl_comm_unique_id", "sbl_comm_attach_rccl", "sbl_comm_attach_local", "sbl_comm_detach"]
+           "sbl_set_tempfile_mode", "sbl_rand_advance", "sbl_shard_layout", "sbl_shard_exchange_plan", "sbl_glue_stripes", "sbl_comm_unique_id", "sbl_comm_attach_rccl", "sbl_comm_attach_local", "sbl_comm_detach"]
 
 
 class StageStats(C.Structure):
@@ -236,6 +236,15 @@ class BlockFinder:
 
     def restore_state(self) -> None:
         self._check(self.L.sbl_restore_state(self.h), "sbl_restore_state")
+
+    def set_tempfile_mode(self, on: bool = True) -> None:
+        """BlockFinder(chrList, tempDir) of the reference: keep the rand() stream in step with its temp-file names (include/sibelia_amd.h)."""
+        self.L.sbl_set_tempfile_mode.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.L.sbl_set_tempfile_mode(self.h, int(on)), "sbl_set_tempfile_mode")
+
+    def rand_advance(self, n: int) -> None:
+        self.L.sbl_rand_advance.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(self.L.sbl_rand_advance(self.h, int(n)), "sbl_rand_advance")
 
     def set_window(self, w: int) -> None:
         self.L.sbl_set_window(self.h, w)

@@ -151,17 +151,23 @@ static void sanitise_revert(sbl_ctx *c)
 	HIP_TRY(hipStreamSynchronize(c->stream));
 }
 void sbl_sanitise_commit(sbl_ctx *c) { c->amb_elem.clear(); c->amb_orig.clear(); }
+// Without -r the reference builds its suffix array through two temporary files per IndexedSequence (CalculateLCP's lcpFile, then
+// CreateFileWithSA's posFile: src/vertexenumeration.cpp:125,101), and TempFile draws each name from the SAME process-global rand()
+// that sanitises ambiguous bases: "Sib_" + 12 x ('a' + rand() % 26) (src/platform.cpp:52-58) -- 24 draws right after the sanitising
+// draws of every index built with a temp directory (the stage, SerializeCondensedGraph, GenerateSyntenyBlocks' main index; TrimBlocks'
+// indices are built in RAM, src/synteny.cpp:44).  Nothing is spilled here; in temp-file mode the context only keeps its stream in
+// step, so that inputs with several ambiguous bases come out as the reference's temp-file mode produces them.
+static void tempfile_draws(sbl_ctx *c) { if (c->tempfile_mode) for (int i = 0; i < 24; i++) (void)c->rng.next(); }
 // sbl_enumerate / sbl_list_edges look at a sanitised COPY (a fresh IndexedSequence, reference src/indexedsequence.cpp:28-37):
 // the replacement is applied to the resident state for the duration of the call and taken back on every way out --
 // also when the enumeration throws (OOM, TOO_LARGE, a failed collective), together with the rand() stream.
 struct SanitiseScope {
 	sbl_ctx *c; bool applied; GlibcRand rng0; bool ok = false;
-	explicit SanitiseScope(sbl_ctx *cx) : c(cx), rng0(cx->rng) { applied = sanitise_apply(cx); }
+	explicit SanitiseScope(sbl_ctx *cx) : c(cx), rng0(cx->rng) { applied = sanitise_apply(cx); tempfile_draws(cx); }
 	void done() { ok = true; }
 	~SanitiseScope()
 	{
-		if (!applied) return;
-		try { sanitise_revert(c); } catch (...) { }
+		if (applied) { try { sanitise_revert(c); } catch (...) { } }
 		if (!ok) c->rng = rng0;
 	}
 };
@@ -476,11 +482,21 @@ extern "C" sbl_status sbl_simplify_stage(sbl_ctx *c, uint32_t k, uint32_t min_br
 	return guarded(c, [&] {
 		SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
 		if (sanitise_apply(c)) sbl_sanitise_commit(c);       // the sanitised copy flows back through the copy-back (src/blockfinder.cpp:85-95)
+		tempfile_draws(c);
 		uint64_t b = 0;
 		sbl_simplify_run(c, k, min_branch_size, max_iterations, progress, user, &b);
 		drop_host_state(c);
 		if (bulges) *bulges = b;
 	});
+}
+
+extern "C" sbl_status sbl_set_tempfile_mode(sbl_ctx *c, int on)
+{
+	return guarded(c, [&] { c->tempfile_mode = on != 0; });
+}
+extern "C" sbl_status sbl_rand_advance(sbl_ctx *c, uint64_t n)
+{
+	return guarded(c, [&] { for (uint64_t i = 0; i < n; i++) (void)c->rng.next(); });
 }
 
 extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **seq, const uint32_t **orig_pos, uint64_t *len)

@@ -7,6 +7,7 @@ struct sbl_ctx {
 	hipStream_t stream = nullptr;
 	std::string err;
 	GlibcRand rng;
+	bool tempfile_mode = false;          // sbl_set_tempfile_mode: draw the reference's TempFile names from the stream (see sbl_api.hip)
 
 	// ---- state carried between stages (rawSeq_ / originalPos_, reference src/blockfinder.h:52-54),
 	//      resident in HBM as the element array '$' c0 '$' c1 '$' ... '$'

@@ -43,7 +43,9 @@ __global__ void __launch_bounds__(256) k_gather_blocks(const uint8_t *__restrict
 #define TE_THREADS 256u
 struct TinyDesc { unsigned nrec, k; unsigned long long src[TE_MAX_REC]; unsigned len[TE_MAX_REC]; };
 struct TinyOut { unsigned status, bif_count, n[2], pad[4]; unsigned inst[2][TE_MAX_ELEM * 3]; };
-__global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate(const uint8_t *__restrict__ orig, TinyDesc d, TinyOut *__restrict__ out)
+// head: status, bif_count, instances per strand; inst0 / inst1: (id, sequence, position) triples of the + / - strand
+__device__ __forceinline__ void tiny_enumerate_body(const uint8_t *__restrict__ orig, const TinyDesc &d, unsigned *__restrict__ head,
+                                                    unsigned *__restrict__ inst0, unsigned *__restrict__ inst1)
 {
 	__shared__ uint8_t ch[TE_MAX_ELEM + 8];
 	__shared__ unsigned short pslot[TE_MAX_ELEM];             // table slot of the k-mer starting at g | orientation flags << 12 ... see below
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate(const uint8_t *__
 		ch[e] = c;
 	}
 	__syncthreads();
-	if (s_bad) { if (tid == 0) out->status = 1; return; }
+	if (s_bad) { if (tid == 0) head[0] = 1; return; }
 	auto base = [&](unsigned e) -> unsigned { unsigned x = (ch[e] >> 1) & 3u; return x ^ (x >> 1); };      // A:0 C:1 G:2 T:3 (k_pack2bit)
 	// ---- records: canonical code, neighbour masks in canonical orientation (k_kmer_records), merged per distinct k-mer in the LDS table
 	for (unsigned g = tid; g < E; g += TE_THREADS) {
@@ -147,12 +149,34 @@ __global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate(const uint8_t *__
 		const unsigned p = 2 * lp + ((pfl[g] & 1u) ? 0u : 1u);
 		unsigned r = 0;
 		while (sep[r + 1] <= g) r++;
-		out->inst[0][3 * off] = pairids[p]; out->inst[0][3 * off + 1] = r; out->inst[0][3 * off + 2] = g - sep[r] - 1;
+		inst0[3 * off] = pairids[p]; inst0[3 * off + 1] = r; inst0[3 * off + 2] = g - sep[r] - 1;
 		const unsigned e1 = g + k - 1;
-		out->inst[1][3 * off] = pairids[p ^ 1u]; out->inst[1][3 * off + 1] = r; out->inst[1][3 * off + 2] = sep[r + 1] - 1 - e1;
+		inst1[3 * off] = pairids[p ^ 1u]; inst1[3 * off + 1] = r; inst1[3 * off + 2] = sep[r + 1] - 1 - e1;
 		off++;
 	}
-	if (tid == 0) { out->bif_count = nkeys; out->n[0] = total; out->n[1] = total; out->status = 0; }
+	if (tid == 0) { head[1] = nkeys; head[2] = total; head[0] = 0; }
+}
+__global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate(const uint8_t *__restrict__ orig, TinyDesc d, TinyOut *__restrict__ out)
+{
+	__shared__ unsigned head[4];
+	tiny_enumerate_body(orig, d, head, out->inst[0], out->inst[1]);
+	__syncthreads();
+	if (threadIdx.x == 0) { if (head[0] == 0) { out->bif_count = head[1]; out->n[0] = head[2]; out->n[1] = head[2]; } out->status = head[0]; }
+}
+// The same for MANY candidate blocks in one launch, one workgroup each: TrimBlocks is called once per candidate block, and on a raw
+// graph at small k (-v / --allstages call GenerateSyntenyBlocks(k, k, k) before every stage) that is tens of thousands of blocks of a
+// few dozen bases -- one launch and one host synchronisation each cost more than the index itself.  The caller speculates the
+// blocks of a whole chunk of groups (sbl_generate_blocks) and reads all results back with one copy.
+struct TinyBatchDesc { TinyDesc d; unsigned long long out_off; unsigned cap, pad; };      // instances at pool[out_off ..): + strand, then (3 * cap words on) - strand
+__global__ void __launch_bounds__(TE_THREADS) k_tiny_enumerate_batch(const uint8_t *__restrict__ orig, const TinyBatchDesc *__restrict__ desc, unsigned *__restrict__ heads,
+                                                                     unsigned *__restrict__ pool)
+{
+	__shared__ TinyDesc d;
+	__shared__ unsigned long long s_off;
+	__shared__ unsigned s_cap;
+	if (threadIdx.x == 0) { d = desc[blockIdx.x].d; s_off = desc[blockIdx.x].out_off; s_cap = desc[blockIdx.x].cap; heads[4 * blockIdx.x] = 2u; }
+	__syncthreads();
+	tiny_enumerate_body(orig, d, heads + 4 * (size_t)blockIdx.x, pool + s_off, pool + s_off + 3ull * s_cap);
 }
 
 namespace {
@@ -224,9 +248,60 @@ struct Synteny {
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (tiny_out->status == 1) return false;                   // a non-ACGT character: the general path draws rand() for it
 		SBL_CHECK(tiny_out->status == 0, SBL_ERR_INTERNAL, "small-block index did not report");
-		const unsigned n = tiny_out->n[0];
-		// the negative list is reported per sequence in descending element order (sbl_enumerate: each chromosome's run reversed)
-		const sbl_inst *neg = reinterpret_cast<const sbl_inst *>(tiny_out->inst[1]);
+		const unsigned head[4] = { 0u, tiny_out->bif_count, tiny_out->n[0], 0u };
+		tiny_result(head, tiny_out->inst[0], tiny_out->inst[1], bif_count, inst, ninst);
+		return true;
+	}
+
+	// ---- speculated small-block indices of a chunk of groups (k_tiny_enumerate_batch), see sbl_generate_blocks
+	DevBuf d_bdesc, d_bheads, d_bpool;
+	std::vector<TinyBatchDesc> bdesc;
+	std::vector<unsigned> bheads, bpool;
+	const unsigned *pre_head = nullptr, *pre_inst = nullptr; unsigned pre_cap = 0;      // index speculated for the NEXT child_index call (one use)
+	bool tiny_eligible(const std::vector<BEdge> &block) const
+	{
+		if (!tiny_out || trimK > 32 || block.empty() || block.size() > TE_MAX_REC) return false;
+		uint64_t L = 0;
+		for (auto &b : block) L += b.origLen;
+		return L + block.size() + 1 <= TE_MAX_ELEM;
+	}
+	// queue the index of `block`; returns its slot in the batch
+	unsigned batch_add(const std::vector<BEdge> &block)
+	{
+		TinyBatchDesc bd;
+		memset(&bd, 0, sizeof bd);
+		bd.d.nrec = (unsigned)block.size(); bd.d.k = trimK;
+		unsigned E = 1;
+		for (size_t i = 0; i < block.size(); i++) {
+			bd.d.src[i] = (unsigned long long)c->orig_sepidx[block[i].chr] + 1 + block[i].origPos;
+			bd.d.len[i] = (unsigned)block[i].origLen;
+			E += (unsigned)block[i].origLen + 1;
+		}
+		bd.cap = E;
+		bd.out_off = bdesc.empty() ? 0 : bdesc.back().out_off + 6ull * bdesc.back().cap;
+		bdesc.push_back(bd);
+		return (unsigned)bdesc.size() - 1;
+	}
+	void batch_run()
+	{
+		if (bdesc.empty()) return;
+		const size_t nb = bdesc.size(), words = (size_t)(bdesc.back().out_off + 6ull * bdesc.back().cap);
+		d_bdesc.ensure(nb * sizeof(TinyBatchDesc)); d_bheads.ensure(nb * 16); d_bpool.ensure(words * 4 + 16);
+		HIP_TRY(hipMemcpyAsync(d_bdesc.p, bdesc.data(), nb * sizeof(TinyBatchDesc), hipMemcpyHostToDevice, c->stream));
+		k_tiny_enumerate_batch<<<(unsigned)nb, TE_THREADS, 0, c->stream>>>(c->d_orig_ch.as<uint8_t>(), d_bdesc.as<TinyBatchDesc>(), d_bheads.as<unsigned>(), d_bpool.as<unsigned>());
+		HIP_TRY(hipGetLastError());
+		bheads.resize(nb * 4); bpool.resize(words);
+		HIP_TRY(hipMemcpyAsync(bheads.data(), d_bheads.p, nb * 16, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpyAsync(bpool.data(), d_bpool.p, words * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	void batch_release() { d_bdesc.release(); d_bheads.release(); d_bpool.release(); }
+	~Synteny() { batch_release(); }
+	// the negative list is reported per sequence in descending element order (sbl_enumerate: each chromosome's run reversed)
+	void tiny_result(const unsigned *head, const unsigned *inst0, const unsigned *inst1, uint32_t *bif_count, const sbl_inst **inst, uint64_t *ninst)
+	{
+		const unsigned n = head[2];
+		const sbl_inst *neg = reinterpret_cast<const sbl_inst *>(inst1);
 		tiny_neg.assign(neg, neg + n);
 		for (size_t a = 0; a < tiny_neg.size();) {
 			size_t b = a;
@@ -234,10 +309,9 @@ struct Synteny {
 			std::reverse(tiny_neg.begin() + a, tiny_neg.begin() + b);
 			a = b;
 		}
-		*bif_count = tiny_out->bif_count;
-		inst[0] = reinterpret_cast<const sbl_inst *>(tiny_out->inst[0]); inst[1] = tiny_neg.data();
+		*bif_count = head[1];
+		inst[0] = reinterpret_cast<const sbl_inst *>(inst0); inst[1] = tiny_neg.data();
 		ninst[0] = n; ninst[1] = n;
-		return true;
 	}
 
 	// a fresh index at trimK over the block sequences (IndexedSequence iseq(blockSeq, trimK, ""), synteny.cpp:44): on the GPU
@@ -246,6 +320,12 @@ struct Synteny {
 		const uint32_t nrec = (uint32_t)block.size();
 		uint64_t L = 0;
 		for (auto &b : block) L += b.origLen;
+		if (pre_head) {                                          // speculated with the rest of its chunk, and the speculation held
+			const unsigned *h = pre_head, *i0 = pre_inst; const unsigned cap = pre_cap;
+			pre_head = nullptr;
+			if (h[0] == 0) { tiny_result(h, i0, i0 + 3ull * cap, bif_count, inst, ninst); return; }
+			// (status 1: a non-ACGT character -- the general path below draws rand() for it, now, in the reference's order)
+		}
 		if (tiny_index(block, L, bif_count, inst, ninst)) return;
 		const size_t E = (size_t)L + nrec + 1, Epad = (E + 31) / 32 * 32 + 64;
 		hipStream_t s = child->stream;
@@ -404,12 +484,46 @@ extern "C" sbl_status sbl_generate_blocks(sbl_ctx *c, uint32_t k, uint32_t trim_
 		int blockCount = 1;
 		std::vector<BEdge> now;
 		std::vector<uint32_t> occur(c->nchr);
-		for (const auto &g : group) {
+		// Groups are resolved strictly in order (a block occupies its positions for every later group), but a group's candidate block
+		// only depends on the earlier ones where they overlap it -- rarely.  So the candidate blocks of a whole CHUNK of groups are
+		// computed against the occupancy at the start of the chunk and their small-block indices built in ONE launch; a group whose
+		// candidate block comes out the same when its turn comes (it is recomputed: a byte scan) uses that index, any other group
+		// and every further trim iteration takes the one-block path as before.
+		const bool speculate = sy.tiny_out != nullptr && getenv("SBL_NO_TINY_BATCH") == nullptr;
+		const size_t CHUNK = 8192;
+		struct Spec { std::vector<BEdge> now; int slot; };
+		std::vector<Spec> spec;
+		for (size_t gi = 0; gi < group.size(); gi++) {
+			const auto &g = group[gi];
 			BEdge *first = edge.data() + g.first, *last = edge.data() + g.second;
-			std::sort(first, last, [](const BEdge &a, const BEdge &b) { return a.dir < b.dir; });      // CompareEdgesByDirection
+			if (gi % CHUNK == 0) {                                      // speculation pass over the next chunk
+				const size_t gend = std::min(group.size(), gi + CHUNK);
+				spec.assign(gend - gi, Spec{{}, -1});
+				sy.bdesc.clear();
+				for (size_t gj = gi; gj < gend; gj++) {
+					BEdge *f = edge.data() + group[gj].first, *l = edge.data() + group[gj].second;
+					std::sort(f, l, [](const BEdge &a, const BEdge &b) { return a.dir < b.dir; });      // CompareEdgesByDirection (once per group, here)
+					if (!speculate || l - f < 2 || f->dir != 0) continue;
+					Spec &sp = spec[gj - gi];
+					sy.resolve_overlap(f, l, sp.now);
+					if (sy.tiny_eligible(sp.now)) sp.slot = (int)sy.batch_add(sp.now);
+				}
+				sy.batch_run();
+			}
 			if (last - first < 2 || first->dir != 0) continue;          // fewer than two edges, or none on the positive strand (sorted: it would be first)
 			sy.resolve_overlap(first, last, now);
+			{
+				const Spec &sp = spec[gi % CHUNK];
+				bool same = sp.slot >= 0 && sp.now.size() == now.size();
+				for (size_t i = 0; same && i < now.size(); i++)
+					same = sp.now[i].chr == now[i].chr && sp.now[i].origPos == now[i].origPos && sp.now[i].origLen == now[i].origLen && sp.now[i].dir == now[i].dir;
+				if (same) {
+					const TinyBatchDesc &bd = sy.bdesc[sp.slot];
+					sy.pre_head = sy.bheads.data() + 4 * (size_t)sp.slot; sy.pre_inst = sy.bpool.data() + bd.out_off; sy.pre_cap = bd.cap;
+				}
+			}
 			while (sy.trim_blocks(now)) { }
+			sy.pre_head = nullptr;                                      // (an empty candidate block makes no index)
 			std::fill(occur.begin(), occur.end(), 0u);
 			for (const BEdge &e : now) occur[e.chr]++;
 			if (now.size() > 1 && (!shared_only || (size_t)std::count(occur.begin(), occur.end(), 1u) == c->nchr)) {
@@ -421,6 +535,7 @@ extern "C" sbl_status sbl_generate_blocks(sbl_ctx *c, uint32_t k, uint32_t trim_
 				blockCount++;
 			}
 		}
+		sy.batch_release();
 		std::sort(c->blocks.begin(), c->blocks.end(), [](const sbl_block &a, const sbl_block &b) { return std::make_pair(a.chr, a.start) < std::make_pair(b.chr, b.start); });
 		if (blocks) *blocks = c->blocks.data();
 		if (n) *n = c->blocks.size();

@@ -25,19 +25,35 @@ CASES = [
     ("saureus_loose_gff_sharedonly_tempfiles", "Staphylococcus_aureus_pair", ["-s", "loose", "--gff", "-a"]),
     # BASELINE.json config 3 (8 genomes x 4.6 Mbp, -s fine) through the reference's own main: ~12 min for the reference (--big)
     ("synth8_4600k_fine_config3", "synth:4600000:8:1", ["-s", "fine", "-r"]),
+    # several ambiguous bases per record: WITHOUT -r the reference names its temporary files from the same rand() stream that replaces
+    # them (src/platform.cpp:57), so the two modes produce different sequences from the second index on -- both must be reproduced
+    ("ambig_fine_tempfiles_allstages", "ambig:60000:4:77:9", ["-s", "fine", "--allstages", "-g", "-m", "500"]),
+    ("ambig_fine_inram_allstages", "ambig:60000:4:77:9", ["-s", "fine", "--allstages", "-g", "-m", "500", "-r"]),
     ("saureus_fine_nopostprocess_lastk", "Staphylococcus_aureus_pair", ["-s", "fine", "-r", "--nopostprocess", "--lastk", "200", "-m", "1000", "-i", "2"]),
 ]
 
 
 def run_case(program, inp, args, workdir, env=None):
     """-> (returncode, sha256 of stdout, {relative path: [size, sha256]})"""
-    if inp.startswith("synth:"):
+    if inp.startswith(("synth:", "ambig:")):
         sys.path.insert(0, ROOT)
         from sibelia_amd import workloads as W
-        _, L0, n, seed = inp.split(":")
+        kind, L0, n, seed = inp.split(":")[:4]
+        strains = W.gen_strains(L0=int(L0), n=int(n), seed=int(seed), inv_min=max(50, int(L0) // 100), inv_max=max(200, int(L0) // 20)) if kind == "ambig" \
+            else W.gen_strains(L0=int(L0), n=int(n), seed=int(seed))
+        if kind == "ambig":                                   # `count` ambiguity codes per strain at deterministic places
+            import numpy as np
+            rng = np.random.default_rng(int(seed) + 1)
+            out_s = []
+            for s in strains:
+                g = bytearray(s)
+                for pos in rng.choice(len(g), int(inp.split(":")[4]), replace=False):
+                    g[int(pos)] = b"NRYKMSWBDHX"[int(rng.integers(0, 11))]
+                out_s.append(bytes(g))
+            strains = out_s
         fa = "synth.fa"
         with open(os.path.join(workdir, fa), "wb") as g:
-            for i, s in enumerate(W.gen_strains(L0=int(L0), n=int(n), seed=int(seed))):
+            for i, s in enumerate(strains):
                 b = s if isinstance(s, bytes) else s.encode()
                 g.write(b">strain%d synthetic\n" % i)
                 for o in range(0, len(b), 80):
