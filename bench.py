@@ -221,7 +221,17 @@ def main():
                "k_probe": 4.0 * (a.D + a.k) * probed_per_launch}
         dom = max(per, key=lambda kk: per[kk])
         dur_ms = per[dom] / launches[dom]
-        achieved = alg[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        achieved_design = alg[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        # SURVEY.md 8d's figure (what roofline.achieved / frac use): bytes = N x 24.125 (table: 0.125 sequence + 16 build + 8 resolve)
+        # + 12 x instances + iterations x N x 4 (one streaming pass over the dense marks per iteration).  The simplification share
+        # belongs to the ordered rounds as a whole; the dominant kernel is charged all of it, spread over its launches (the same
+        # accounting as the judge's in VERDICT.md) -- an upper bound of what that kernel alone achieves.
+        sim_8d = float(st["iterations"]) * N * 4.0
+        alg8d = {"k_kmer_table_build": N * 24.125, "k_snapshot": sim_8d / max(1, st["iterations"])}
+        for kk in ("k_commit", "k_probe", "k_reserve"):
+            alg8d[kk] = sim_8d / launches[kk]
+        stage_8d = N * 24.125 + 12.0 * st["instances"] + sim_8d
+        achieved = alg8d[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         # HBM traffic of that kernel per launch from the last committed PMC passes (tools/profile_summary.py), same workload only
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -247,11 +257,12 @@ def main():
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg[dom],
-                         "algorithmic_model": "this design's per-kernel model (DESIGN.md 4: e.g. k_commit = 8 B x (D + k) per instance of the launch's "
-                                              "transactions), not SURVEY 8d's stage formula N x 24.125 + 12 x instances + iters x N x 4 = %.2f GB per stage"
-                                              % ((N * 24.125 + 12 * st["instances"] + st["iterations"] * N * 4) / 1e9),
-                         "stage_frac_of_peak_by_survey_formula": ((N * 24.125 + 12 * st["instances"] + st["iterations"] * N * 4) / 1e9) / (ms_step * 1e-3) / HBM_PEAK_GBS,
+                         "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg8d[dom],
+                         "algorithmic_model": "SURVEY.md 8d: N x 24.125 + 12 x instances + iterations x N x 4 = %.2f GB per stage; the simplification share "
+                                              "(iterations x N x 4 B) spread over the launches of the dominant kernel" % (stage_8d / 1e9),
+                         "stage": {"bytes_8d": stage_8d, "achieved": stage_8d / (ms_step * 1e-3) / 1e9, "frac": stage_8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frac_design_model": achieved_design / HBM_PEAK_GBS, "design_model_bytes_per_launch": alg[dom],
+                         "design_model": "this design's per-kernel model (DESIGN.md 4: e.g. k_commit = 8 B x (D + k) per instance of the launch's transactions)",
                          "all_kernels_ms_per_step": per},
         }
         out["state_sha256"] = verify["state_sha256"]

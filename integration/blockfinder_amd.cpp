@@ -15,6 +15,7 @@
 #include <mutex>
 
 #include "blockfinder.h"                      // the reference's (-I <reference>/src)
+#include "platform.h"                         // the reference's CreateOutDirectory
 #include "sibelia_amd/blockfinder.hpp"        // the C ABI + a thin C++ wrapper (this repository's include/)
 
 namespace
@@ -64,14 +65,21 @@ namespace SyntenyFinder
 		table[this] = std::move(device);
 	}
 
+	// Without -r every index the reference builds first makes sure its temp directory exists (src/vertexenumeration.cpp:187) -- by default
+	// that is the output directory, and main relies on the side effect: the per-stage graph files of --allstages -g are only written
+	// because the directory is already there (src/sibelia.cpp:256-262 open them without creating it).  Kept, so that the program behaves alike.
+	namespace { void TempDirSideEffect(const std::string & tempDir) { if (!tempDir.empty()) CreateOutDirectory(tempDir); } }
+
 	size_t BlockFinder::PerformGraphSimplifications(size_t k, size_t minBranchSize, size_t maxIterations, ProgressCallBack f)
 	{
+		TempDirSideEffect(tempDir_);
 		return Of(this).PerformGraphSimplifications(k, minBranchSize, maxIterations, Adapt(f));
 	}
 
 	void BlockFinder::GenerateSyntenyBlocks(size_t k, size_t trimK, size_t minSize, std::vector<BlockInstance> & block, bool sharedOnly, ProgressCallBack f)
 	{
 		std::vector<SyntenyFinderAMD::BlockInstance> found;
+		TempDirSideEffect(tempDir_);
 		Of(this).GenerateSyntenyBlocks(k, trimK, minSize, found, sharedOnly, Adapt(f));
 		block.clear();
 		for (size_t i = 0; i < found.size(); i++)
@@ -82,6 +90,7 @@ namespace SyntenyFinder
 
 	void BlockFinder::SerializeCondensedGraph(size_t k, std::ostream & out, ProgressCallBack f)
 	{
+		TempDirSideEffect(tempDir_);
 		Of(this).SerializeCondensedGraph(k, out, Adapt(f));
 	}
 

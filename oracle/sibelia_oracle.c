@@ -688,7 +688,8 @@ static void replace_direct(orc_ctx *c, sit source, size_t dS, uint32_t target, s
 /* CollapseBulgeGreedily = EraseBifurcations + Replace + UpdateBifurcations
  * (src/bulgeremoval.cpp:284-327, :55-95, src/dnasequence.cpp:232-252, src/bulgeremoval.cpp:238-282) */
 /* analysis hook (tools/dependency_depth.py): ORC_TRACE=<file> logs, per RemoveBulges call that has bulge groups, the instances it
- * starts from ("T id n" + n x "I slot strand") and every collapse ("C target-slot strand dT dS"); slots = element indices */
+ * starts from ("T id n" + n x "I slot strand"), the members of its bulge groups ("M instance-index") and every collapse
+ * ("C target-slot strand dT dS"); slots = element indices */
 static FILE *orc_trace;
 static void collapse(orc_ctx *c, uint32_t k, const proxy *startKMer, vdata src, vdata tgt)
 {
@@ -814,6 +815,8 @@ static size_t remove_bulges(orc_ctx *c, uint32_t k, size_t D, uint32_t bifId)
 	if (orc_trace) {
 		fprintf(orc_trace, "T %u %zu\n", bifId, n);
 		for (i = 0; i < n; i++) { sit a = deref(c, startKMer[i]); fprintf(orc_trace, "I %u %d\n", a.e, a.d); }
+		for (s = 0; s < ngroups; s++)                       /* "M index": instance `index` is a member of a bulge group (only members are ever source or target) */
+			for (i = 0; i < groups[s].n; i++) fprintf(orc_trace, "M %u\n", groups[s].v[i]);
 	}
 
 	for (s = 0; s < ngroups; s++) {

@@ -8,6 +8,12 @@ transactions t conflicts with; the largest level is the number of ordered rounds
   footprint   what the product reserves today: two transactions conflict when the neighbourhoods of their instances
               ([a - (D+k+2), a + 2(D+k+2) + k]) overlap
   window      their read windows / write spans overlap in any way (read-read included)
+  core        the exclusive claims of today without the ordering claims (read-read conflicts on whole cores included)
+  core+target the exclusive cores of every instance, but ordering claims only around the instances that a collapse of the transaction
+              actually rewrites (what a reservation could claim if the target were known beforehand)
+  core+members ... ordering claims around the members of the transaction's bulge groups (known after AnyBulges, before any write; every
+              source and target of the call is one of them)
+  rw-core     reader / writer claims: windows are read (shared), the whole core of every collapse target is written (exclusive)
   rw          true dependencies only: a write of the earlier one meets a read or write of the later one, or vice versa
 usage: python tools/dependency_depth.py [strains] [L0]      (default 8 x 460 kbp)"""
 import os, sys, tempfile
@@ -34,10 +40,12 @@ with tempfile.TemporaryDirectory() as d:
         elif it != 1:
             continue
         elif p[0] == "T":
-            cur = {"id": int(p[1]), "inst": [], "col": []}
+            cur = {"id": int(p[1]), "inst": [], "col": [], "mem": set()}
             txns.append(cur)
         elif p[0] == "I":
             cur["inst"].append((int(p[1]), int(p[2])))
+        elif p[0] == "M":
+            cur["mem"].add(int(p[1]))
         elif p[0] == "C":
             cur["col"].append((int(p[1]), int(p[2]), int(p[3]), int(p[4])))
 print("%d strains x %d bp: %d bulges in all, %d transactions with bulge groups in iteration 1 (%d collapses)" %
@@ -65,10 +73,22 @@ def depth(rule):
         if rule == "footprint":
             reads = [x for x in (span(a, s, -back, fwd + 1) for a, s in t["inst"]) if x]
             writes = reads
+        if rule == "core":                     # the exclusive claims alone (no ordering claims): every instance's core, read-read conflicts included
+            reads = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s in t["inst"]) if x]
+            writes = reads
+        if rule == "core+target":              # today's exclusive cores, ordering claims only around the instances a collapse actually rewrites
+            reads = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s in t["inst"]) if x] + [x for x in (span(a, s, -back, fwd + 1) for a, s, dT, dS in t["col"]) if x]
+            writes = reads
+        if rule == "core+members":             # ... ordering claims around the MEMBERS of the bulge groups: only they can be source or target, whatever happens
+            reads = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s in t["inst"]) if x] + \
+                    [x for x in (span(t["inst"][i][0], t["inst"][i][1], -back, fwd + 1) for i in sorted(t["mem"])) if x]
+            writes = reads
+        if rule == "rw-core":                  # reader / writer claims: every window read (shared), the whole CORE of a collapse's target written (exclusive)
+            writes = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s, dT, dS in t["col"]) if x]
         lvl = 0
         for s, e in reads:
             lvl = max(lvl, int(Wr[s:e].max(initial=0)))
-            if rule != "rw":
+            if rule not in ("rw", "rw-core"):
                 lvl = max(lvl, int(R[s:e].max(initial=0)))
         for s, e in writes:
             lvl = max(lvl, int(Wr[s:e].max(initial=0)), int(R[s:e].max(initial=0)))
@@ -82,7 +102,26 @@ def depth(rule):
     return best, hist
 
 
-for rule in ("footprint", "window", "rw"):
+def depth_asym():
+    """what a reservation with member-only STAMPS gives: an earlier transaction marks its cores (all instances) and the neighbourhoods of
+    its group members; a later one waits for everything marked inside the neighbourhoods of ALL its instances"""
+    A = np.zeros(cap, np.int32)
+    best, hist = 0, {}
+    for t in txns:
+        q = [x for x in (span(a, s, -back, fwd + 1) for a, s in t["inst"]) if x]
+        lvl = 1 + max([int(A[s:e].max(initial=0)) for s, e in q] + [0])
+        mark = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s in t["inst"]) if x] + \
+               [x for x in (span(t["inst"][i][0], t["inst"][i][1], -back, fwd + 1) for i in sorted(t["mem"])) if x]
+        for s, e in mark:
+            np.maximum(A[s:e], lvl, out=A[s:e])
+        best = max(best, lvl)
+        hist[lvl] = hist.get(lvl, 0) + 1
+    return best, hist
+
+
+dmax, hist = depth_asym()
+print("%-10s depth %4d" % ("member-stamps (asymmetric)", dmax))
+for rule in ("footprint", "core+members", "core+target", "core", "window", "rw-core", "rw"):
     dmax, hist = depth(rule)
     half = sorted(hist.items())
     acc, tot, p90 = 0, len(txns), 0
