@@ -121,6 +121,23 @@ def depth_asym():
 
 dmax, hist = depth_asym()
 print("%-10s depth %4d" % ("member-stamps (asymmetric)", dmax))
+
+
+def depth_asym_targets():
+    """the same with stamps only around the instances a collapse actually rewrites (a plan phase would have to name them)"""
+    A = np.zeros(cap, np.int32)
+    best = 0
+    for t in txns:
+        q = [x for x in (span(a, s, -back, fwd + 1) for a, s in t["inst"]) if x]
+        lvl = 1 + max([int(A[s:e].max(initial=0)) for s, e in q] + [0])
+        mark = [x for x in (span(a, s, 0, D + 2 * k + 4) for a, s in t["inst"]) if x] + [x for x in (span(a, s, -back, fwd + 1) for a, s, dT, dS in t["col"]) if x]
+        for s, e in mark:
+            np.maximum(A[s:e], lvl, out=A[s:e])
+        best = max(best, lvl)
+    return best
+
+
+print("%-10s depth %4d" % ("target-stamps (asymmetric)", depth_asym_targets()))
 for rule in ("footprint", "core+members", "core+target", "core", "window", "rw-core", "rw"):
     dmax, hist = depth(rule)
     half = sorted(hist.items())
