@@ -27,30 +27,30 @@ __global__ void __launch_bounds__(256) k_init_links(unsigned *__restrict__ nx, u
 // BifurcationStorage (front insertion while scanning (chr,pos) ascending, reference src/indexedsequence.cpp:51-67
 // + src/bifurcationstorage.cpp:122): + list = elements descending; - list = chromosomes descending, elements ascending.
 __global__ void __launch_bounds__(256) k_instance_keys(const unsigned *__restrict__ elem, const unsigned *__restrict__ id, unsigned n, unsigned strand,
-                                                       const unsigned *__restrict__ sepidx, unsigned nchr, unsigned E,
+                                                       const unsigned *__restrict__ sepidx, unsigned nchr, unsigned E, unsigned ordbits,
                                                        unsigned long long *__restrict__ keys, unsigned *__restrict__ midx)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	midx[i] = i;                                    // payload of the sort: index into the positional (compact) mark arrays
 	unsigned e = elem[i], ord;
-	if (strand == 0) ord = 0xFFFFFFFFu - e;
+	if (strand == 0) ord = E - 1u - e;              // (< E: the order field takes ordbits = bits of 2 E, the key id_bits + ordbits -- fewer radix passes than 64)
 	else { unsigned c = chr_of(sepidx, nchr, e); ord = (E - sepidx[c + 1]) + (e - sepidx[c]); }
-	keys[i] = ((unsigned long long)id[i] << 32) | ord;
+	keys[i] = ((unsigned long long)id[i] << ordbits) | ord;
 }
 
 __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *__restrict__ skeys, const unsigned *__restrict__ smidx, const unsigned *__restrict__ melem, unsigned n,
-                                                     unsigned node_base, unsigned strand, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext, unsigned *__restrict__ nidst,
+                                                     unsigned node_base, unsigned strand, unsigned ordbits, unsigned *__restrict__ nslot, unsigned *__restrict__ nnext, unsigned *__restrict__ nidst,
                                                      uint8_t *__restrict__ ndead, unsigned *__restrict__ head, unsigned *__restrict__ lsize,
                                                      unsigned *__restrict__ nodeof, unsigned *__restrict__ nmark)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const unsigned j = smidx[i];
-	unsigned id = (unsigned)(skeys[i] >> 32), nd = node_base + i, e = melem[j];
+	unsigned id = (unsigned)(skeys[i] >> ordbits), nd = node_base + i, e = melem[j];
 	nmark[nd] = j;                                  // where the instance sits in the positional mark arrays (k_snapshot_first)
-	bool last = i + 1 >= n || (unsigned)(skeys[i + 1] >> 32) != id;
-	bool first = i == 0 || (unsigned)(skeys[i - 1] >> 32) != id;
+	bool last = i + 1 >= n || (unsigned)(skeys[i + 1] >> ordbits) != id;
+	bool first = i == 0 || (unsigned)(skeys[i - 1] >> ordbits) != id;
 	nslot[nd] = e; ndead[nd] = 0; nidst[nd] = (id << 1) | strand;
 	nnext[nd] = last ? SBL_NONE : nd + 1;
 	nodeof[e] = nd;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 // ---- wave-cooperative window scan ---------------------------------------------------------------------------
 // Fills instance i's window cache (bulge_txn.h: BulgeWork) with 64 lanes: the same values bt_scan_instance
 // writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
-__device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r)
+__device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r, unsigned wm /* wmax[r], loaded with the data */)
 {
 	// Exclusivity inside a round needs no per-element lock here: an owner holds every id marked in the range it reserved
 	// (2(D+k+2)+k elements ahead of each instance), its scans reach D+k+2 elements, and k_commit checks after every
@@ -92,7 +92,6 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 	unsigned other = BT_NONE;
 	(void)stampv;
 	if (mode == 2) atomicMax(&g.rmax[r], tid);
-	unsigned wm = g.wmax[r];
 	if (wm > tid) bad = true;
 	if (bad) {
 		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
@@ -103,36 +102,59 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 // ListPositions (bifurcationstorage.h:59-72) with 64 lanes: + list then - list, chain order, dead nodes skipped.  Lists
 // start out as runs of consecutive node indices (k_build_lists), so 64 nodes are read per step, speculatively, and the
 // lanes whose predecessors all link consecutively are on the chain; front insertions and the end of a run re-anchor.
-__device__ __forceinline__ unsigned wave_list_positions(const GraphView &g, unsigned id, const BulgeWork &w, unsigned lane)
+// The first step of BOTH lists is issued together (heads h0 / h1 given by the caller, who loads them while something else is
+// going on): head -> nodes -> head -> nodes used to be four dependent memory round trips at the start of every probe,
+// reservation and transaction.  emit(offset, node, strand, element, aux[node]) is called for every live node, in list order.
+struct NodeChunk { unsigned nxt, dead, el, aux; bool inr; };
+__device__ __forceinline__ NodeChunk node_chunk_load(const GraphView &g, unsigned cur, unsigned lane, const unsigned *__restrict__ aux)
 {
+	NodeChunk c;
+	c.inr = cur != BT_NONE && (unsigned long long)cur + lane < g.cap_n;
+	const unsigned nd = cur + lane;
+	c.nxt = c.inr ? g.nnext[nd] : BT_NONE;
+	c.dead = c.inr ? g.ndead[nd] : 1u;
+	c.el = c.inr ? g.nslot[nd] : 0u;
+	c.aux = c.inr && aux ? aux[nd] : 0u;
+	return c;
+}
+template <class Emit>
+__device__ __forceinline__ unsigned wave_list_nodes(const GraphView &g, unsigned h0, unsigned h1, unsigned lane, const unsigned *__restrict__ aux, Emit emit)
+{
+	const NodeChunk first[2] = { node_chunk_load(g, h0, lane, aux), node_chunk_load(g, h1, lane, aux) };      // both in flight
 	unsigned m = 0;
 	for (unsigned s = 0; s < 2; s++) {
-		unsigned cur = g.head[s][id];
+		unsigned cur = s ? h1 : h0;
+		bool prefetched = true;
 		while (cur != BT_NONE) {
-			const bool inr = (unsigned long long)cur + lane < g.cap_n;
+			const NodeChunk c = prefetched ? first[s] : node_chunk_load(g, cur, lane, aux);
+			prefetched = false;
 			const unsigned nd = cur + lane;
-			const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
-			const unsigned dead = inr ? g.ndead[nd] : 1u;
-			const unsigned el = inr ? g.nslot[nd] : 0u;
-			const unsigned long long cont = __ballot(inr && nxt == nd + 1);
+			const unsigned long long cont = __ballot(c.inr && c.nxt == nd + 1);
 			const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;   // lanes 0 .. pre-1 are on the chain
-			const bool on = lane < pre && inr;
-			const unsigned long long lv = __ballot(on && !dead);
+			const bool on = lane < pre && c.inr;
+			const unsigned long long lv = __ballot(on && !c.dead);
 			const unsigned off = m + __popcll(lv & ((1ull << lane) - 1ull));
-			if (on && !dead && off < w.n) { w.start[off] = (nd << 1) | s; w.sel[off] = el; }
+			if (on && !c.dead) emit(off, nd, s, c.el, c.aux);
 			m += (unsigned)__popcll(lv);
-			cur = __shfl(nxt, pre - 1);
+			cur = __shfl(c.nxt, pre - 1);
 		}
 	}
 	return m;
 }
+__device__ __forceinline__ unsigned wave_list_positions(const GraphView &g, unsigned h0, unsigned h1, const BulgeWork &w, unsigned lane)
+{
+	return wave_list_nodes(g, h0, h1, lane, nullptr, [&](unsigned off, unsigned nd, unsigned s, unsigned el, unsigned) {
+		if (off < w.n) { w.start[off] = (nd << 1) | s; w.sel[off] = el; }
+	});
+}
 // bt_setup with the positions listed by all lanes; `ok` lives in LDS
 __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork &w, bool lite, unsigned lane, int &ok)
 {
+	const unsigned h0 = g.head[0][t.id], h1 = g.head[1][t.id];              // in flight while lane 0 lays the scratch out
 	if (lane == 0) ok = bt_setup(t, w, lite, false) && !t.err ? 1 : 0;
 	__syncthreads();
 	if (!ok) return false;
-	unsigned m = wave_list_positions(g, t.id, w, lane);
+	unsigned m = wave_list_positions(g, h0, h1, w, lane);
 	if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; ok = 0; }          // cannot happen on a consistent graph
 	__syncthreads();
 	return ok != 0;
@@ -142,8 +164,11 @@ __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork
 // consecutively there (it almost always is); blocks are then consumed in order and the burst is abandoned at the
 // first link break or separator.  One memory round trip per window instead of one per 64 elements.
 enum { SCAN_BURST = 3 };
-struct ScanBurst { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST]; bool inr[SCAN_BURST]; };
-__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b)
+// wmv: the write stamp of every element of the burst, loaded WITH the burst (stamped scans only): the order check "nothing I read was
+// written by a higher id" used to load it per 64-element block after the block had been consumed -- one exposed memory round trip
+// per block, three per window, in every probe and every writer pass.
+struct ScanBurst { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; bool inr[SCAN_BURST]; };
+__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
 {
 #pragma unroll
 	for (int u = 0; u < SCAN_BURST; u++) {
@@ -154,6 +179,7 @@ __device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur
 		b.chv[u] = b.inr[u] ? g.ch[b.cc[u]] : 0u;
 		b.bvl[u] = b.inr[u] ? g.bif[dir][b.cc[u]] : BT_NONE;
 		b.lnk[u] = b.inr[u] ? (dir ? g.pv[b.cc[u]] : g.nx[b.cc[u]]) : BT_NONE;
+		b.wmv[u] = mode && b.inr[u] ? g.wmax[b.cc[u] >> BT_BLOCK_SHIFT] : 0u;
 	}
 }
 
@@ -171,8 +197,8 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			nb++;
 		}
 		ScanBurst bst;
-		if (pre_burst && done == 0) bst = *pre_burst; else scan_burst_load(g, cur, dir, done, ws, lane, bst);
-		const unsigned (&cc)[SCAN_BURST] = bst.cc, (&plink)[SCAN_BURST] = bst.plink, (&chv)[SCAN_BURST] = bst.chv, (&bvl)[SCAN_BURST] = bst.bvl, (&lnk)[SCAN_BURST] = bst.lnk;
+		if (pre_burst && done == 0) bst = *pre_burst; else scan_burst_load(g, cur, dir, done, ws, lane, bst, mode);
+		const unsigned (&cc)[SCAN_BURST] = bst.cc, (&plink)[SCAN_BURST] = bst.plink, (&chv)[SCAN_BURST] = bst.chv, (&bvl)[SCAN_BURST] = bst.bvl, (&lnk)[SCAN_BURST] = bst.lnk, (&wmv)[SCAN_BURST] = bst.wmv;
 		const bool (&inr)[SCAN_BURST] = bst.inr;
 		const unsigned burst_done = done;
 #pragma unroll
@@ -201,7 +227,7 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 			}
 			if (mode) {
 				unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
-				if (st && chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk);
+				if (st && chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk, wmv[u]);
 			}
 			if (stop < pre) { wl = done + stop; finished = true; break; }
 			cur = __shfl(lnk[u], pre - 1);
@@ -218,10 +244,10 @@ __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWor
                                               unsigned first = 0, unsigned stride = 1)
 {
 	ScanBurst nb;
-	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, nb);
+	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, nb, mode);
 	for (unsigned i = first; i < w.n; i += stride) {
 		ScanBurst b = nb;
-		if (i + stride < w.n) scan_burst_load(g, w.sel[i + stride], w.start[i + stride] & 1u, 0, w.ws, lane, nb);
+		if (i + stride < w.n) scan_burst_load(g, w.sel[i + stride], w.start[i + stride] & 1u, 0, w.ws, lane, nb, mode);
 		wave_scan_instance(g, w, i, lane, stampv, tid, mode, id, &b);
 	}
 }
@@ -457,25 +483,9 @@ __global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream 
 		__syncthreads();
 		if (lane == 0) g.touch[id] = 0;
 		// ---- ListPositions: + list then - list, live nodes only (64 nodes per step where the list is a run of consecutive nodes)
-		unsigned n = 0;
-		for (unsigned s = 0; s < 2; s++) {
-			unsigned cur = g.head[s][id];
-			while (cur != BT_NONE) {
-				const bool inr = (unsigned long long)cur + lane < g.cap_n;
-				const unsigned nd = cur + lane;
-				const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
-				const unsigned dead = inr ? g.ndead[nd] : 1u;
-				const unsigned mj = inr ? nmark[nd] : 0u;
-				const unsigned long long cont = __ballot(inr && nxt == nd + 1);
-				const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;
-				const bool on = lane < pre && inr;
-				const unsigned long long lv = __ballot(on && !dead);
-				const unsigned off = n + __popcll(lv & ((1ull << lane) - 1ull));
-				if (on && !dead && off < SNAP_MAX_INST) s_inst[off] = (mj << 1) | s;
-				n += (unsigned)__popcll(lv);
-				cur = __shfl(nxt, pre - 1);
-			}
-		}
+		const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nmark, [&](unsigned off, unsigned, unsigned s, unsigned, unsigned mj) {
+			if (off < SNAP_MAX_INST) s_inst[off] = (mj << 1) | s;
+		});
 		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
 		if (n > SNAP_MAX_INST) { if (lane == 0) g.need[id] = 1; continue; }
 		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
@@ -586,10 +596,10 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	if (ok) {
 		unsigned distinct = 0;
 		ScanBurst nb;
-		scan_burst_load(g, w.sel[0], w.start[0] & 1u, 0, w.ws, lane, nb);
+		scan_burst_load(g, w.sel[0], w.start[0] & 1u, 0, w.ws, lane, nb, 3u);
 		for (unsigned i = 0; i < w.n && verdict == 0; i++) {
 			ScanBurst b = nb;
-			if (i + 1 < w.n) scan_burst_load(g, w.sel[i + 1], w.start[i + 1] & 1u, 0, w.ws, lane, nb);
+			if (i + 1 < w.n) scan_burst_load(g, w.sel[i + 1], w.start[i + 1] & 1u, 0, w.ws, lane, nb, 3u);
 			wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
 			__syncthreads();
 			if (w.mk_overflow) { verdict = -1; break; }                     // more marks than the LDS list holds: the generic path below decides
@@ -947,26 +957,10 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
 	if (wv == 0) {
-		// ListPositions by 64 lanes (see wave_list_positions): the instances land in LDS, the waves then share them out
-		unsigned m = 0;
-		for (unsigned s = 0; s < 2; s++) {
-			unsigned cur = g.head[s][id];
-			while (cur != BT_NONE) {
-				const bool inr = (unsigned long long)cur + lane < g.cap_n;
-				const unsigned nd = cur + lane;
-				const unsigned nxt = inr ? g.nnext[nd] : BT_NONE;
-				const unsigned dead = inr ? g.ndead[nd] : 1u;
-				const unsigned el = inr ? g.nslot[nd] : 0u;
-				const unsigned long long cont = __ballot(inr && nxt == nd + 1);
-				const unsigned pre = cont == ~0ull ? 64u : (unsigned)__builtin_ctzll(~cont) + 1u;
-				const bool on = lane < pre && inr;
-				const unsigned long long lv = __ballot(on && !dead);
-				const unsigned off = m + __popcll(lv & ((1ull << lane) - 1ull));
-				if (on && !dead && off < RESUME_SLOTS) inst[off] = (el << 1) | s;
-				m += (unsigned)__popcll(lv);
-				cur = __shfl(nxt, pre - 1);
-			}
-		}
+		// ListPositions by 64 lanes (see wave_list_nodes): the instances land in LDS, the waves then share them out
+		const unsigned m = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
+			if (off < RESUME_SLOTS) inst[off] = (el << 1) | s;
+		});
 		if (lane == 0) ninst_s = m;
 	}
 	__syncthreads();
@@ -1034,11 +1028,11 @@ __device__ __forceinline__ void wave_stamp_id_write(const GraphView &g, unsigned
 	}
 }
 // ErasePoint (bifurcationstorage.cpp:144-155) for one (strand, element) per lane; the lazy-erase chain head lives in LDS
-__device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned strand, unsigned e, unsigned stampv)
+// b / nd: the mark and its node as the caller loaded them (all loads of a step are issued together: the erase loops used to be a chain
+// of five dependent look-ups per step -- element, mark, node, mark of the other strand, its node)
+__device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned strand, unsigned e, unsigned stampv, unsigned b, unsigned nd)
 {
-	unsigned b = g.bif[strand][e];
 	if (b == BT_NONE) return;
-	unsigned nd = g.nodeof[strand][e];
 	g.bif[strand][e] = BT_NONE;
 	g.ndead[nd] = 1;
 	g.nclr[nd] = atomicExch(&t.tc_head, nd);
@@ -1061,16 +1055,23 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		bool in = i < k;
 		unsigned ea = in ? T[k - 1 - i] : 0u, eb = in ? T[dT + i] : 0u;
 		unsigned ba = in ? g.bif[opp][ea] : BT_NONE, bb = in ? g.bif[d][eb] : BT_NONE;
+		unsigned na = in ? g.nodeof[opp][ea] : 0u, nb2 = in ? g.nodeof[d][eb] : 0u;
+		// (a lane's two flank positions are on different strands, and no two lanes share a (strand, element) pair: the preloaded marks are current)
 		unsigned long long ma = __ballot(ba != BT_NONE), mb = __ballot(bb != BT_NONE);
-		if (ba != BT_NONE) { unsigned o = nlb + __popcll(ma & lt); w.lb[2 * o] = i; w.lb[2 * o + 1] = ba; wave_erase(g, t, opp, ea, stampv); }
-		if (bb != BT_NONE) { unsigned o = nlf + __popcll(mb & lt); w.lf[2 * o] = i; w.lf[2 * o + 1] = bb; wave_erase(g, t, d, eb, stampv); }
+		if (ba != BT_NONE) { unsigned o = nlb + __popcll(ma & lt); w.lb[2 * o] = i; w.lb[2 * o + 1] = ba; wave_erase(g, t, opp, ea, stampv, ba, na); }
+		if (bb != BT_NONE) { unsigned o = nlf + __popcll(mb & lt); w.lf[2 * o] = i; w.lf[2 * o + 1] = bb; wave_erase(g, t, d, eb, stampv, bb, nb2); }
 		nlb += __popcll(ma); nlf += __popcll(mb);
 	}
 	__syncthreads();
 	// ---- second loop: every own-strand mark after the target start and every opposite-strand mark over k + dT elements
 	for (unsigned i0 = 0; i0 < k + dT; i0 += 64) {
 		unsigned i = i0 + lane;
-		if (i < k + dT) { unsigned e = T[i]; if (i > 0) wave_erase(g, t, d, e, stampv); wave_erase(g, t, opp, e, stampv); }
+		if (i < k + dT) {
+			const unsigned e = T[i];
+			const unsigned b0 = g.bif[d][e], b1 = g.bif[opp][e], n0 = g.nodeof[d][e], n1 = g.nodeof[opp][e];
+			if (i > 0) wave_erase(g, t, d, e, stampv, b0, n0);
+			wave_erase(g, t, opp, e, stampv, b1, n1);
+		}
 	}
 	__syncthreads();
 	// ---- DNASequence::Replace in + coordinates: P(j) = j-th element of the old span, C(j) = j-th new character.
@@ -2155,13 +2156,14 @@ void sbl_simplify_free(sbl_ctx *c)
 	c->simp = nullptr;
 }
 
-static void sort_pairs64(sbl_ctx *c, SimplifyState *st, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n)
+static void sort_pairs64(sbl_ctx *c, SimplifyState *st, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n, unsigned bits = 64)
 {
 	size_t tmp = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
 	st->sorttmp.ensure(tmp);
-	HIP_TRY(rocprim::radix_sort_pairs(st->sorttmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	HIP_TRY(rocprim::radix_sort_pairs(st->sorttmp.p, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
 }
+static unsigned bits_of(unsigned long long v) { unsigned b = 1; while (b < 64 && (v >> b)) b++; return b; }
 static void scan_u32(sbl_ctx *c, SimplifyState *st, unsigned *in, unsigned *out, size_t n)
 {
 	size_t tmp = 0;
@@ -2230,13 +2232,14 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 	st->keys.ensure(nmax * 8 + 16); st->skeys.ensure(nmax * 8 + 16); st->selem.ensure(nmax * 4 + 16); st->iota.ensure(nmax * 4 + 16);
 	st->nmark.ensure(cap_n * 4);
 	for (int t = 0; t < 2; t++) st->maux[t].ensure(16);
+	const unsigned ordbits = bits_of(2ull * E), idbits = bits_of(be.nid_);      // sort keys of id_bits + ordbits bits (48 on the benchmark workload: 6 radix passes, not 8)
 	for (int t = 0; t < 2; t++) {
 		unsigned n = c->nmarks[t];
 		if (!n) continue;
 		k_instance_keys<<<nblocks(n, 256), 256, 0, s>>>(c->d_melem[t].as<unsigned>(), c->d_mid[t].as<unsigned>(), n, (unsigned)t,
-		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, st->keys.as<unsigned long long>(), st->iota.as<unsigned>());
-		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->iota.as<unsigned>(), st->selem.as<unsigned>(), n);
-		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), c->d_melem[t].as<unsigned>(), n, t ? (unsigned)n0 : 0u, (unsigned)t,
+		                                               c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, ordbits, st->keys.as<unsigned long long>(), st->iota.as<unsigned>());
+		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->iota.as<unsigned>(), st->selem.as<unsigned>(), n, std::min(64u, idbits + ordbits));
+		k_build_lists<<<nblocks(n, 256), 256, 0, s>>>(st->skeys.as<unsigned long long>(), st->selem.as<unsigned>(), c->d_melem[t].as<unsigned>(), n, t ? (unsigned)n0 : 0u, (unsigned)t, ordbits,
 		                                             st->nslot.as<unsigned>(), st->nnext.as<unsigned>(), st->nidst.as<unsigned>(), st->ndead.as<uint8_t>(),
 		                                             st->head[t].as<unsigned>(), st->lsize[t].as<unsigned>(), st->nodeof[t].as<unsigned>(), st->nmark.as<unsigned>());
 		st->maux[t].ensure((size_t)n * 4 + 16);
@@ -2249,7 +2252,7 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 	if (be.nid_) {
 		k_id_position_keys<<<nblocks(be.nid_, 256), 256, 0, s>>>(st->head[0].as<unsigned>(), st->head[1].as<unsigned>(), st->nslot.as<unsigned>(), be.nid_,
 		                                                       st->keys.as<unsigned long long>(), st->permin.as<unsigned>());
-		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->permin.as<unsigned>(), st->perm.as<unsigned>(), be.nid_);
+		sort_pairs64(c, st, st->keys.as<unsigned long long>(), st->skeys.as<unsigned long long>(), st->permin.as<unsigned>(), st->perm.as<unsigned>(), be.nid_, 32);      // keys are element slots, or 2^32 - 1
 	}
 	HIP_TRY(hipGetLastError());
 
