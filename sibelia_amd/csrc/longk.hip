@@ -47,14 +47,23 @@ __global__ void __launch_bounds__(256) k_lk_super(const uint8_t *__restrict__ ch
 	rank[i] = v;
 }
 
-__global__ void __launch_bounds__(256) k_lk_pair_keys(const unsigned *__restrict__ rank, unsigned np, unsigned h,
+// rb: bits of the largest rank of this round (ranks are dense: 5, 25, 625, ... distinct values in the first rounds), so that the sort
+// only runs over the 2 rb bits that can differ
+__global__ void __launch_bounds__(256) k_lk_pair_keys(const unsigned *__restrict__ rank, unsigned np, unsigned h, unsigned rb,
                                                       unsigned long long *__restrict__ keys, unsigned *__restrict__ idx)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= np) return;
 	unsigned hi = rank[i], lo = (unsigned long long)i + h < np ? rank[i + h] : 0u;
-	keys[i] = ((unsigned long long)hi << 32) | lo;
+	keys[i] = ((unsigned long long)hi << rb) | lo;
 	idx[i] = i;
+}
+// rank[] back in position order WITHOUT a random scatter: (position, new rank) pairs are radix-sorted by position instead
+// (k_lk_scatter_rank's 4-byte writes all over a 7-GB array were 61 ms per round at 1.8 G suffixes, a quarter of config 5)
+__global__ void __launch_bounds__(256) k_lk_rank_values(const unsigned *__restrict__ scan, unsigned n, unsigned *__restrict__ val)
+{
+	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) val[j] = scan[j] - 1;
 }
 __global__ void __launch_bounds__(256) k_lk_heads(const unsigned long long *__restrict__ skeys, unsigned n, unsigned *__restrict__ flag)
 {
@@ -75,7 +84,7 @@ __global__ void __launch_bounds__(256) k_lk_window_keys(const unsigned *__restri
                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ idx, unsigned *__restrict__ nvalid)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+	if (i >= n) return;                                          // (lanes that leave here take no part in the ballot below)
 	bool valid = false;
 	if (i < E) {
 		unsigned c = lk_chr_of(sepidx, nchr, i);
@@ -87,7 +96,9 @@ __global__ void __launch_bounds__(256) k_lk_window_keys(const unsigned *__restri
 	}
 	keys[i] = valid ? (((unsigned long long)rank[i] << 32) | rank[i + k - h]) : ~0ull;
 	idx[i] = i;
-	if (valid) atomicAdd(nvalid, 1u);
+	// one atomic per wave, not per window: 1.8 G atomics on one address were 319 ms of config 5's 2.87 s (rocprofv3, round 3)
+	const unsigned long long m = __ballot(valid);
+	if (m && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) atomicAdd(nvalid, (unsigned)__popcll(m));
 }
 
 // per sorted window: prev / next character masks (bit 0-3 = A C G T, bit 4 = '#'; next in bits 8-12) and the group-head flag
@@ -145,13 +156,21 @@ void sbl_longk_free(sbl_ctx *c)
 	c->lk = nullptr;
 }
 
-static void lk_sort(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n)
+static void lk_sort(sbl_ctx *c, unsigned long long *kin, unsigned long long *kout, unsigned *vin, unsigned *vout, size_t n, unsigned bits = 64)
 {
 	size_t tmp = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
 	lk_of(c).tmp.ensure(tmp);
-	HIP_TRY(rocprim::radix_sort_pairs(lk_of(c).tmp.p, tmp, kin, kout, vin, vout, n, 0, 64, c->stream));
+	HIP_TRY(rocprim::radix_sort_pairs(lk_of(c).tmp.p, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
 }
+static void lk_sort32(sbl_ctx *c, unsigned *kin, unsigned *kout, unsigned *vin, unsigned *vout, size_t n, unsigned bits)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
+	lk_of(c).tmp.ensure(tmp);
+	HIP_TRY(rocprim::radix_sort_pairs(lk_of(c).tmp.p, tmp, kin, kout, vin, vout, n, 0, bits, c->stream));
+}
+static unsigned lk_bits(unsigned long long v) { unsigned b = 1; while (b < 64 && (v >> b)) b++; return b; }
 static void lk_inclusive_scan(sbl_ctx *c, unsigned *in, unsigned *out, size_t n)
 {
 	size_t tmp = 0;
@@ -187,12 +206,22 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	k_lk_super<<<nblocks(np, 256), 256, 0, s>>>(c->d_ch.as<uint8_t>(), c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, (unsigned)np, rank);
 	HIP_TRY(hipMemcpyAsync(L.sym.p, rank, np * 4, hipMemcpyDeviceToDevice, s));
 	size_t h = 1;
+	unsigned maxrank = 4;                                            // symbols 0 .. 4
+	const bool by_sort = np >= (1u << 22) && getenv("SBL_LONGK_SCATTER") == nullptr;      // small inputs: the scatter stays in cache
 	while (2 * h <= k) {
-		k_lk_pair_keys<<<nblocks(np, 256), 256, 0, s>>>(rank, (unsigned)np, (unsigned)h, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
-		lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), np);
+		const unsigned rb = lk_bits(maxrank);
+		k_lk_pair_keys<<<nblocks(np, 256), 256, 0, s>>>(rank, (unsigned)np, (unsigned)h, rb, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
+		lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), np, std::min(64u, 2 * rb));
 		k_lk_heads<<<nblocks(np, 256), 256, 0, s>>>(L.skeys.as<unsigned long long>(), (unsigned)np, L.flag.as<unsigned>());
 		lk_inclusive_scan(c, L.flag.as<unsigned>(), L.scan.as<unsigned>(), np);
-		k_lk_scatter_rank<<<nblocks(np, 256), 256, 0, s>>>(L.sidx.as<unsigned>(), L.scan.as<unsigned>(), (unsigned)np, rank);
+		if (by_sort) {
+			// (sidx, scan - 1) sorted by sidx = rank[] in position order; L.flag / L.idx are free at this point
+			k_lk_rank_values<<<nblocks(np, 256), 256, 0, s>>>(L.scan.as<unsigned>(), (unsigned)np, L.flag.as<unsigned>());
+			lk_sort32(c, L.sidx.as<unsigned>(), L.idx.as<unsigned>(), L.flag.as<unsigned>(), rank, np, lk_bits(np - 1));
+		} else
+			k_lk_scatter_rank<<<nblocks(np, 256), 256, 0, s>>>(L.sidx.as<unsigned>(), L.scan.as<unsigned>(), (unsigned)np, rank);
+		HIP_TRY(hipMemcpyAsync(&maxrank, L.scan.as<unsigned>() + (np - 1), 4, hipMemcpyDeviceToHost, s));      // number of distinct 2h-prefixes
+		HIP_TRY(hipStreamSynchronize(s));
 		h *= 2;
 	}
 	k_lk_window_keys<<<nblocks(n, 256), 256, 0, s>>>(rank, c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, k, (unsigned)h,

@@ -239,15 +239,18 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; if (nm > w.mks) *const_cast<bool *>(&w.mk_overflow) = true; }
 }
 
-// windows first, first + stride, ... of the cache, each one's first burst issued while the previous window is consumed
+// windows first, first + stride, ... of the cache; the first bursts of the next TWO windows are in flight while a window is consumed
+// (a burst takes longer to arrive than a window takes to consume)
 __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
                                               unsigned first = 0, unsigned stride = 1)
 {
-	ScanBurst nb;
-	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, nb, mode);
+	ScanBurst b1, b2;
+	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, b1, mode);
+	if (first + stride < w.n) scan_burst_load(g, w.sel[first + stride], w.start[first + stride] & 1u, 0, w.ws, lane, b2, mode);
 	for (unsigned i = first; i < w.n; i += stride) {
-		ScanBurst b = nb;
-		if (i + stride < w.n) scan_burst_load(g, w.sel[i + stride], w.start[i + stride] & 1u, 0, w.ws, lane, nb, mode);
+		const ScanBurst b = b1;
+		b1 = b2;
+		if (i + 2 * stride < w.n) scan_burst_load(g, w.sel[i + 2 * stride], w.start[i + 2 * stride] & 1u, 0, w.ws, lane, b2, mode);
 		wave_scan_instance(g, w, i, lane, stampv, tid, mode, id, &b);
 	}
 }
@@ -595,11 +598,13 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	int verdict = 0;
 	if (ok) {
 		unsigned distinct = 0;
-		ScanBurst nb;
+		ScanBurst nb, nb2;                                                 // the next two windows' first bursts are in flight
 		scan_burst_load(g, w.sel[0], w.start[0] & 1u, 0, w.ws, lane, nb, 3u);
+		if (w.n > 1) scan_burst_load(g, w.sel[1], w.start[1] & 1u, 0, w.ws, lane, nb2, 3u);
 		for (unsigned i = 0; i < w.n && verdict == 0; i++) {
 			ScanBurst b = nb;
-			if (i + 1 < w.n) scan_burst_load(g, w.sel[i + 1], w.start[i + 1] & 1u, 0, w.ws, lane, nb, 3u);
+			nb = nb2;
+			if (i + 2 < w.n) scan_burst_load(g, w.sel[i + 2], w.start[i + 2] & 1u, 0, w.ws, lane, nb2, 3u);
 			wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
 			__syncthreads();
 			if (w.mk_overflow) { verdict = -1; break; }                     // more marks than the LDS list holds: the generic path below decides

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from sibelia_amd import BlockFinder, workloads as W
 total = int(sys.argv[1]); nrec = int(sys.argv[2]); k = int(sys.argv[3]); D = int(sys.argv[4])
 seqs = W.random_dna(total, nrec, seed=5)
