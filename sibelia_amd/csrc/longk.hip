@@ -65,6 +65,17 @@ __global__ void __launch_bounds__(256) k_lk_rank_values(const unsigned *__restri
 	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j < n) val[j] = scan[j] - 1;
 }
+// The first three doubling rounds without a sort: the rank of the 8 symbols from i is their base-5 number (order-preserving, equal iff
+// the strings are equal; positions past the end read '#' = 0, like the padding) -- 0 .. 390 624.
+__global__ void __launch_bounds__(256) k_lk_rank8(const unsigned *__restrict__ sym, unsigned np, unsigned *__restrict__ rank)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= np) return;
+	unsigned v = 0;
+#pragma unroll
+	for (unsigned j = 0; j < 8; j++) v = v * 5u + ((unsigned long long)i + j < np ? sym[i + j] : 0u);
+	rank[i] = v;
+}
 __global__ void __launch_bounds__(256) k_lk_heads(const unsigned long long *__restrict__ skeys, unsigned n, unsigned *__restrict__ flag)
 {
 	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,6 +218,11 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	HIP_TRY(hipMemcpyAsync(L.sym.p, rank, np * 4, hipMemcpyDeviceToDevice, s));
 	size_t h = 1;
 	unsigned maxrank = 4;                                            // symbols 0 .. 4
+	if (k >= 16 && getenv("SBL_LONGK_FROM_1") == nullptr) {          // (k > 32 here: always; the switch is for A/B tests)
+		k_lk_rank8<<<nblocks(np, 256), 256, 0, s>>>(L.sym.as<unsigned>(), (unsigned)np, L.rank[1].as<unsigned>());
+		rank = L.rank[1].as<unsigned>();
+		h = 8; maxrank = 390624;
+	}
 	const bool by_sort = np >= (1u << 22) && getenv("SBL_LONGK_SCATTER") == nullptr;      // small inputs: the scatter stays in cache
 	while (2 * h <= k) {
 		const unsigned rb = lk_bits(maxrank);
