@@ -400,3 +400,36 @@ def test_positions_clamp_at_a_chromosome_end_in_a_later_stage():
         assert bf.simplify_stage(k, D, 4) == orc.simplify_stage(k, D, 4)
         (sa, pa), (sb, pb) = bf.state(), orc.state()
         assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb)), (k, D)
+
+
+@pytest.mark.parametrize("k", [40, 100, 700])
+def test_long_k_active_set_doubling_equals_the_full_doubling(k, monkeypatch):
+    """k > 32: rank doubling over the still-active suffixes only (the default) against the plain doubling that sorts every suffix in
+    every round (SBL_LONGK_NO_DISCARD=1) and against the oracle, on related strains (most suffixes stay active) with a random record
+    and a short one appended (suffixes that settle early; a record shorter than k)"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=40_000, n=3, seed=77, inv_min=400, inv_max=2000) + W.random_dna(30_000, 1, seed=9) + [b"ACGTTGCA" * 4]
+    a = _bf(seqs).enumerate(k)                                # default: the variant is chosen after the first round
+    monkeypatch.setenv("SBL_LONGK_FORCE_ACTIVE", "1")
+    f = _bf(seqs).enumerate(k)                                # active suffixes only, whatever their share
+    monkeypatch.delenv("SBL_LONGK_FORCE_ACTIVE")
+    monkeypatch.setenv("SBL_LONGK_NO_DISCARD", "1")
+    b = _bf(seqs).enumerate(k)                                # every suffix in every round
+    c = Oracle(seqs).enumerate(k)
+    for x in (f, b, c):
+        assert a[0] == x[0] and (a[1] == x[1]).all() and (a[2] == x[2]).all()
+    assert a[0] > 0
+
+
+def test_long_k_stage_on_random_records_takes_the_active_set_path():
+    """unrelated random records with one planted repeat: nearly every suffix is unique after 16 characters, the doubling continues over the
+    few that are not -- result equal to the oracle's, state included"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    seqs = W.longk_case(400_000, 4, seed=3)
+    bf, orc = _bf(seqs), Oracle(seqs)
+    for k, D in ((200, 600), (5000, 15000)):
+        assert bf.simplify_stage(k, D, 4) == orc.simplify_stage(k, D, 4)
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
