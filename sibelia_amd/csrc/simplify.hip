@@ -1772,6 +1772,16 @@ __global__ void __launch_bounds__(64) k_dense_stage(GraphView g, uint8_t *arena,
 	if (lane == 0) out[0] = iter;
 }
 
+// ids whose windows or lists changed since their verdict was taken (what an incremental snapshot has to look at)
+__global__ void __launch_bounds__(256) k_count_touched(const uint8_t *__restrict__ touch, unsigned nid, unsigned *__restrict__ out)
+{
+	unsigned c = 0;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nid; i += gridDim.x * blockDim.x) c += touch[i] != 0;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
 // The list is a chain of "segments" = maximal runs of consecutive slots linked consecutively.  Heads are
 // found with a flag pass, segments are ranked by pointer jumping, elements scatter to rank + offset.
@@ -2005,6 +2015,17 @@ struct DeviceBackend {
 		}
 		HIP_TRY(hipGetLastError());
 	}
+	// Linearising the marks for the stream costs ~1.5 ms whatever the number of ids to look at; when only a few per cent of the ids were
+	// touched (iterations 3, 4: what the few collapses of the previous iteration can see) the window-walking snapshot of just those is cheaper.
+	bool few_touched()
+	{
+		unsigned *cnt = st->ctr.as<unsigned>() + CTR_DETAIL + 8, n = 0;
+		HIP_TRY(hipMemsetAsync(cnt, 0, 4, c->stream));
+		k_count_touched<<<256, 256, 0, c->stream>>>(st->touch.as<uint8_t>(), nid_, cnt);
+		HIP_TRY(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		return (unsigned long long)n * 16 < nid_;
+	}
 	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
@@ -2015,7 +2036,7 @@ struct DeviceBackend {
 			for (int t = 0; t < 2; t++) { ms.elem[t] = c->d_melem[t].as<unsigned>(); ms.id[t] = c->d_mid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = c->nmarks[t]; }
 			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
 			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>());
-		} else if (incremental && later_stream) {
+		} else if (incremental && later_stream && !few_touched()) {
 			// iterations 2 ..: the same stream over the marks of the current graph in list order
 			st->nmark.ensure((size_t)cap_n * 4);
 			MarkStream ms;
