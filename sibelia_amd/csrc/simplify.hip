@@ -574,6 +574,91 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	}
 }
 
+// ---- one window of a probe, scan and verdict in one go ---------------------------------------------------------------------------
+// The probe is issue-bound, not memory-bound (rocprofv3 SQ counters, round 3: its waves are actively issuing 26 % of their lifetime
+// at ~3 waves per SIMD): wave_scan_instance writes per-window summaries and a compacted mark list, a barrier later
+// wave_verdict_instance reads them back and ballots again.  For a window that lies in consecutive slots over its whole length --
+// almost all do -- everything the verdict needs is in the registers of the burst: window length (first separator), endChar (step
+// k), the marked steps before the window's end and before the instance's own id recurs.  Returns 1 (some id is now reached by two
+// instances with different endChars), 0, -1 (the table could fill up), -2 (a link break inside the window, k or D beyond the burst:
+// the generic pair of functions takes this window).
+__device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanBurst &b, unsigned dir, unsigned ws, VerdictTable &vt, unsigned lane,
+                                                 unsigned id, unsigned tid, unsigned &distinct)
+{
+	const unsigned k = g.k, D = g.D;
+	if (k >= 64u * SCAN_BURST) return -2;
+	unsigned firstbad = ~0u, firstsep = ~0u;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		const unsigned long long in = __ballot(b.inr[u]), good = __ballot(b.inr[u] && b.plink[u] == b.cc[u]), sep = __ballot(b.inr[u] && b.chv[u] == BT_SEP);
+		const unsigned long long bad = in & ~good;
+		if (bad && firstbad == ~0u) firstbad = 64u * u + (unsigned)__builtin_ctzll(bad);
+		if (sep && firstsep == ~0u) firstsep = 64u * u + (unsigned)__builtin_ctzll(sep);
+	}
+	const unsigned covered = ws < 64u * SCAN_BURST ? ws : 64u * SCAN_BURST;      // steps the burst holds
+	const unsigned len = firstsep < covered ? firstsep : covered;                // steps before the separator (wlen), as far as the burst shows
+	if (firstbad < len || firstbad <= firstsep && firstbad < covered) return -2; // the walk leaves consecutive slots inside the window
+	if (firstsep >= covered && covered < ws && D > covered) return -2;           // the window goes on beyond the burst
+	// order check of everything read (mode 3): elements before the separator
+	bool viol = false;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) viol |= b.inr[u] && 64u * u + lane < len && b.wmv[u] > tid;
+	if (__any(viol)) wave_stamp(g, 0, tid, 3, id, 0, tid + 1);
+	if (len < k + 1) return 0;                                                   // endChar == ' '
+	const unsigned kc = __shfl(b.chv[0], k & 63u), kc1 = SCAN_BURST > 1 ? __shfl(b.chv[1], k & 63u) : 0u, kc2 = SCAN_BURST > 2 ? __shfl(b.chv[2], k & 63u) : 0u;
+	const unsigned craw = k < 64 ? kc : k < 128 ? kc1 : kc2;
+	const char ec = dir ? bt_comp((char)craw) : (char)craw;
+	const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
+	const unsigned start = __shfl(b.bvl[0], 0);
+	const unsigned lim = len < D ? len : D;
+	// marked steps 1 .. lim - 1, up to the first recurrence of the instance's own id
+	unsigned firstown = ~0u;
+	unsigned long long cand[SCAN_BURST];
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		const unsigned step = 64u * u + lane;
+		const bool c = b.inr[u] && step >= 1 && step < lim && b.bvl[u] != BT_NONE;
+		cand[u] = __ballot(c);
+		const unsigned long long own = __ballot(c && b.bvl[u] == start);
+		if (own && firstown == ~0u) firstown = 64u * u + (unsigned)__builtin_ctzll(own);
+	}
+	unsigned total = 0;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		if (firstown != ~0u) {                                                   // keep the steps below firstown only
+			const unsigned lo = 64u * u;
+			cand[u] = firstown <= lo ? 0ull : firstown >= lo + 64u ? cand[u] : cand[u] & ((1ull << (firstown - lo)) - 1ull);
+		}
+		total += (unsigned)__popcll(cand[u]);
+	}
+	if (!total) return 0;
+	if (distinct + total > (VT_SLOTS * 3) / 4) return -1;
+	bool found = false, fresh_any = false;
+	unsigned nfresh = 0;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		bool fresh = false;
+		if ((cand[u] >> lane) & 1ull) {
+			const unsigned bb = b.bvl[u];
+			unsigned h = (bb * 2654435761u) >> 23;
+			for (;;) {
+				unsigned old = atomicCAS(&vt.key[h], BT_NONE, bb);
+				if (old == BT_NONE || old == bb) {
+					fresh = old == BT_NONE;
+					unsigned m = atomicOr(&vt.mask[h], bit) | bit;
+					if (m & (m - 1)) found = true;
+					break;
+				}
+				h = (h + 1) & (VT_SLOTS - 1);
+			}
+		}
+		nfresh += (unsigned)__popcll(__ballot(fresh));
+	}
+	(void)fresh_any;
+	distinct += nfresh;
+	return __any(found) ? 1 : 0;
+}
+
 // Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
 // without reservation (ss_probe); the others are flagged live and go through reserve / commit.
 #define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
@@ -605,10 +690,13 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 			ScanBurst b = nb;
 			nb = nb2;
 			if (i + 2 < w.n) scan_burst_load(g, w.sel[i + 2], w.start[i + 2] & 1u, 0, w.ws, lane, nb2, 3u);
-			wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
-			__syncthreads();
-			if (w.mk_overflow) { verdict = -1; break; }                     // more marks than the LDS list holds: the generic path below decides
-			verdict = wave_verdict_instance(g, w, vt, lane, i, distinct);
+			verdict = wave_probe_window(g, b, w.start[i] & 1u, w.ws, vt, lane, id, tid, distinct);
+			if (verdict == -2) {                                            // a link break inside the window (an earlier collapse): the generic pair
+				wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
+				__syncthreads();
+				if (w.mk_overflow) { verdict = -1; break; }                 // more marks than the LDS list holds: the generic path below decides
+				verdict = wave_verdict_instance(g, w, vt, lane, i, distinct);
+			}
 		}
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
