@@ -54,8 +54,14 @@ __global__ void __launch_bounds__(256) k_build_lists(const unsigned long long *_
 	nslot[nd] = e; ndead[nd] = 0; nidst[nd] = (id << 1) | strand;
 	nnext[nd] = last ? SBL_NONE : nd + 1;
 	nodeof[e] = nd;
-	if (first) head[id] = nd;
-	atomicAdd(&lsize[id], 1u);
+	if (first) {
+		// the list's size = the length of its run in the sorted array (an atomic per instance kept this kernel in issue stalls for two
+		// thirds of its time: SQ_WAIT_INST_ANY 66 %, profiles/r03_sq_counters.json)
+		head[id] = nd;
+		unsigned len = 1;
+		while (i + len < n && (unsigned)(skeys[i + len] >> ordbits) == id) len++;
+		lsize[id] = len;
+	}
 }
 
 // largest number of instances of any id (sizes the per-transaction scratch arena)
