@@ -60,7 +60,7 @@ typedef struct {
 	uint64_t bif_count, instances;   /* after enumeration */
 	uint64_t bulges;                 /* return value of PerformGraphSimplifications */
 	uint32_t iterations, rounds;     /* SimplifyGraph iterations run; ordered-commit rounds launched */
-	uint32_t replays;                /* iterations re-run (order validation fired, or a pool had to grow) */
+	uint32_t replays;                /* iterations re-run (order validation fired, or a pool had to grow), + 1 for an abandoned checkpoint-free first attempt */
 	uint32_t grow_replays;           /* ... of which because the element / node pool had to grow */
 	double enumerate_ms, simplify_ms, copyback_ms, total_ms;
 	double kmer_table_ms;            /* duration of the dominant kernel (k-mer table build) */

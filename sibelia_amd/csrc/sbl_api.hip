@@ -254,7 +254,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		}
 		c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
 		HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, KB_CTR_WORDS * 4, s));
-		k_bucket_classify<<<(unsigned)((size_t)1 << bits), KB_THREADS, 0, s>>>(k1, v1, c->d_boff.as<unsigned>(), k, c->d_counters.as<unsigned>(),
+		k_bucket_classify<<<nblocks((size_t)1 << bits, KB_GROUP), KB_THREADS, 0, s>>>(k1, v1, c->d_boff.as<unsigned>(), (unsigned)((size_t)1 << bits), k, c->d_counters.as<unsigned>(),
 		                                                                      c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(), (unsigned)maxpairs,
 		                                                                      members, (unsigned)maxmembers);
 		HIP_TRY(hipGetLastError());

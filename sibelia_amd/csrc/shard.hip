@@ -441,7 +441,7 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		for (;;) {
 			c->d_keys.ensure(maxpairs * 16 + 16); c->d_payload.ensure(maxpairs * 8 + 16);
 			HIP_TRY(hipMemsetAsync(ctr, 0, KB_CTR_WORDS * 4, s));
-			k_bucket_classify<<<(unsigned)nb, KB_THREADS, 0, s>>>(ok, ov, c->d_boff.as<unsigned>(), k, ctr, c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(),
+			k_bucket_classify<<<(unsigned)((nb + KB_GROUP - 1) / KB_GROUP), KB_THREADS, 0, s>>>(ok, ov, c->d_boff.as<unsigned>(), (unsigned)nb, k, ctr, c->d_keys.as<unsigned long long>(), c->d_payload.as<unsigned>(),
 			                                                     (unsigned)maxpairs, members, (unsigned)nrecv);
 			HIP_TRY(hipGetLastError());
 			unsigned all[KB_CTR_WORDS];

@@ -1969,6 +1969,8 @@ struct SimplifyState {
 	unsigned *h_ctr = nullptr;            // pinned
 };
 
+struct RestartStage {};      // thrown out of an optimistic attempt that would need a roll-back (DeviceBackend::restore)
+
 struct DeviceBackend {
 	sbl_ctx *c;
 	SimplifyState *st;
@@ -1984,6 +1986,10 @@ struct DeviceBackend {
 	bool later_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr && getenv("SBL_NO_LATER_STREAM") == nullptr;
 	bool first_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr;      // measurement switch: the generic window-walking snapshot for iteration 1 too
 	int prof = 0;
+	// Optimistic attempt: no iteration checkpoints (1.45 GB of device-to-device copies per iteration, 3.6 ms of a 105 ms stage, for a
+	// roll-back the benchmark workloads never take).  An order violation or a pool overflow then abandons the attempt (RestartStage) and
+	// the stage is run again from its input -- intact until the copy-back -- with checkpoints and iteration replays (sbl_simplify_run).
+	bool optimistic = false;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 
 	DeviceBackend() = default;
@@ -2021,6 +2027,7 @@ struct DeviceBackend {
 	{
 		read_ctr();
 		ck_ne = st->h_ctr[CTR_NE]; ck_nn = st->h_ctr[CTR_NN];
+		if (optimistic) return;
 		copy(st->ck_ch, st->ch, ck_ne); copy(st->ck_op, st->op, (size_t)ck_ne * 4); copy(st->ck_nx, st->nx, (size_t)ck_ne * 4); copy(st->ck_pv, st->pv, (size_t)ck_ne * 4);
 		for (int s = 0; s < 2; s++) {
 			copy(st->ck_bif[s], c->d_bif[s], (size_t)ck_ne * 4); copy(st->ck_nodeof[s], st->nodeof[s], (size_t)ck_ne * 4);
@@ -2031,6 +2038,7 @@ struct DeviceBackend {
 	}
 	void restore()
 	{
+		if (optimistic) throw RestartStage{};
 		auto back = [&](DevBuf &dst, const DevBuf &src, size_t bytes) { if (bytes) HIP_TRY(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, c->stream)); };
 		back(st->ch, st->ck_ch, ck_ne); back(st->op, st->ck_op, (size_t)ck_ne * 4); back(st->nx, st->ck_nx, (size_t)ck_ne * 4); back(st->pv, st->ck_pv, (size_t)ck_ne * 4);
 		for (int s = 0; s < 2; s++) {
@@ -2162,7 +2170,9 @@ struct DeviceBackend {
 		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_VIOL, &none, 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
+	// The selection is launched behind a round's last kernel and read with the round's counters: one host round trip per round.
+	bool sel_pending = false, sel_ready = false;
+	void select_launch(uint32_t lo, uint32_t limit, uint32_t W)
 	{
 		// chunks of >= 8192 ids, at most ~1024 of them
 		unsigned chunk = 8192;
@@ -2171,7 +2181,12 @@ struct DeviceBackend {
 		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), lo, limit, chunk0, chunk);
 		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks);
 		HIP_TRY(hipGetLastError());
-		read_ctr();
+		sel_pending = true; sel_ready = false;
+	}
+	void select_read(uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
+	{
+		if (!sel_ready) read_ctr();                                 // (the first selection of an iteration, or one re-issued behind a fence)
+		sel_pending = sel_ready = false;
 		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
 	}
 	void probe(uint32_t nwin, uint32_t round)
@@ -2224,6 +2239,7 @@ struct DeviceBackend {
 	SimplifyCounters counters()
 	{
 		read_ctr();
+		if (sel_pending) sel_ready = true;                          // the snapshot holds the selection launched before it as well
 		float ms = 0;
 		if (timed_reserve && timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, rsv_start, ev[2])); reserve_ms += ms; }
 		timed_reserve = false;
@@ -2294,15 +2310,38 @@ static void scan_u32(sbl_ctx *c, SimplifyState *st, unsigned *in, unsigned *out,
 
 // Inputs up to this many elements take the one-launch path (k_dense_stage) first; SBL_NO_DENSE_PATH=1 / SBL_DENSE_MAX_ELEMS=n: test switches
 #define DENSE_MAX_ELEMS (1u << 16)
-static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense);
+// The reference's callback sequence (blockfinder.cpp:23-48) is a function of the call index alone -- start, run(min(i, 50)) for i = 1, 2, ...,
+// end -- so an attempt that is abandoned and run again delivers only the calls the caller has not seen yet.
+struct ProgressFilter {
+	sbl_progress_fn fn; void *user;
+	bool started = false, ended = false;
+	uint64_t delivered = 0, seen = 0;          // run calls forwarded so far / made by the current attempt
+	static void relay(size_t p, int state, void *self_)
+	{
+		ProgressFilter *f = (ProgressFilter *)self_;
+		if (state == SBL_PROGRESS_START) { f->seen = 0; if (!f->started) { f->started = true; f->fn(p, state, f->user); } }
+		else if (state == SBL_PROGRESS_RUN) { if (++f->seen > f->delivered) { f->delivered = f->seen; f->fn(p, state, f->user); } }
+		else if (!f->ended) { f->ended = true; f->fn(p, state, f->user); }
+	}
+};
+enum { RUN_DONE = 0, RUN_DENSE_FAILED = 1, RUN_RESTART = 2 };
+static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic);
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
 {
-	// the stage's input (d_ch / d_op) is only replaced by the copy-back at the very end, so a one-launch attempt that ran out of
-	// pool or arena space is simply followed by the general path from the same input
-	if (simplify_run_impl(c, k, D, max_iter, progress, user, bulges, true)) return;
-	(void)simplify_run_impl(c, k, D, max_iter, progress, user, bulges, false);
+	// the stage's input (d_ch / d_op) is only replaced by the copy-back at the very end, so an attempt that cannot finish -- a one-launch
+	// run out of pool or arena space, an optimistic run that would need a roll-back -- is simply followed by the next one from the same input
+	ProgressFilter pf{progress, user};
+	sbl_progress_fn pfn = progress ? &ProgressFilter::relay : nullptr;
+	const bool optimistic = getenv("SBL_CHECKPOINTS") == nullptr;     // measurement / test switch: checkpoints from the first attempt on
+	int r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, true, optimistic);
+	if (r == RUN_DENSE_FAILED) r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, false, optimistic);
+	if (r == RUN_RESTART) {
+		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] optimistic attempt abandoned: the stage runs again with iteration checkpoints\n");
+		(void)simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, false, false);
+		c->stats.replays++;                                               // the abandoned attempt
+	}
 }
-static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense)
+static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic)
 {
 	hipStream_t s = c->stream;
 	if (!c->simp) { c->simp = new SimplifyState(); HIP_TRY(hipHostMalloc((void **)&c->simp->h_ctr, CTR_COUNT * 4)); }
@@ -2315,6 +2354,7 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 	// ---- E1: enumeration into mark arrays with room for inserted elements
 	size_t E = c->nelem, ne0 = (E + 31) / 32 * 32;
 	size_t cap_e = ne0 + E / 8 + (1u << 20);
+	if (const char *e = getenv("SBL_TEST_ELEM_SLACK")) cap_e = ne0 + (size_t)atoll(e);      // test hook: provoke the grow / restart paths
 	SBL_CHECK(cap_e < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
 	sbl_run_enumeration(c, k, cap_e);
 	be.nid_ = c->bif_count;
@@ -2435,6 +2475,7 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 		round_buffers(window);
 	}
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
+	be.optimistic = optimistic;
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {
 		unsigned long long z[64] = {0};
@@ -2463,7 +2504,7 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 		be.commit_ms = ms;
 		if (st->h_ctr[CTR_ERR]) {
 			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] one-launch path: capacity error %u, falling back to the ordered rounds\n", st->h_ctr[CTR_ERR]);
-			return false;
+			return RUN_DENSE_FAILED;
 		}
 		rep.iterations = st->h_ctr[CTR_DETAIL]; rep.bulges = st->h_ctr[CTR_BULGES]; rep.transactions = rep.executed = st->h_ctr[CTR_TXN];
 		rep.chain_transactions = rep.transactions;
@@ -2475,8 +2516,10 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 			for (uint64_t i = 0; i < due; i++) { tp = std::min<uint64_t>(tp + 1, 50); progress((size_t)tp, SBL_PROGRESS_RUN, user); }
 			progress(50, SBL_PROGRESS_END, user);
 		}
-	} else
-		rep = simplify_graph(be, max_iter, window, progress, user, window_max);
+	} else {
+		try { rep = simplify_graph(be, max_iter, window, progress, user, window_max); }
+		catch (const RestartStage &) { HIP_TRY(hipStreamSynchronize(s)); return RUN_RESTART; }
+	}
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 
 	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays
@@ -2544,5 +2587,5 @@ static bool simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_i
 		fprintf(stderr, "[sbl] longest transaction: %llu cycles, %llu instances, %llu collapses\n", mx[0], mx[1] >> 32, mx[1] & 0xFFFFFFFFull);
 	}
 	*bulges = rep.bulges;
-	return true;
+	return RUN_DONE;
 }

@@ -29,7 +29,8 @@ struct SimplifyReport {
 //   void snapshot_all(bool incremental);             need[id] = AnyBulges verdict, for every id (incremental: touched ids only)
 //   void reset_round_state(bool stamps_too);         own/lock = 0xFFFFFFFF (and rmax/wmax = 0)
 //   void clear_counters();                           ctr[ERR, BULGES, VIOL, BIG, COMMITTED] reset (VIOL = NONE)
-//   void select(lo, limit, W, &nwin, &newlo, &solo); lowest pending ids in [lo, limit]
+//   void select_launch(lo, limit, W);                lowest pending ids in [lo, limit]: issued right behind a round's last launch, so that
+//   void select_read(&nwin, &newlo, &solo);          ONE host round trip (counters()) brings back the round's counters and the next window
 //   void probe(nwin, round);                         retire window entries whose verdict is false now, flag the others
 //   void mark_live(nwin);                            flag every window entry live (solo rounds skip the probe)
 //   void reserve(nwin, round); void commit(nwin, round, solo);   (flagged entries only)
@@ -80,14 +81,17 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 				uint32_t prev_txn = 0, prev_done = 0, starved = 0;
 				bool chain_mode = false;
 				uint32_t wcur = window;
+				auto next_limit = [&]() { while (fi < fences.size() && fences[fi] < lo) fi++; return fi < fences.size() ? fences[fi] : nid - 1; };
+				uint32_t limit = next_limit();
+				be.select_launch(lo, limit, wcur);
 				for (;;) {
-					while (fi < fences.size() && fences[fi] < lo) fi++;
-					uint32_t limit = fi < fences.size() ? fences[fi] : nid - 1;
 					uint32_t nwin = 0, newlo = lo, solo = 0;
-					be.select(lo, limit, wcur, &nwin, &newlo, &solo);
+					be.select_read(&nwin, &newlo, &solo);
 					if (nwin == 0) {
 						if (limit >= nid - 1) break;
 						lo = limit + 1;                                       // the fence's turn has passed
+						limit = next_limit();
+						be.select_launch(lo, limit, wcur);
 						continue;
 					}
 					lo = newlo;
@@ -100,9 +104,14 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 						be.reserve(nwin, round);
 						be.commit(nwin, round, solo != 0);
 					}
+					// the next window is selected behind this round's last launch, BEFORE the host looks at the round: one host round trip per
+					// round instead of two (its width is the one the previous round's outcome suggested)
+					const uint32_t this_limit = limit;
+					limit = next_limit();
+					be.select_launch(lo, limit, wcur);
 					SimplifyCounters c = be.counters();
 					if (trace) fprintf(stderr, "[sbl] iter %u round %u lo %u limit %u nwin %u solo %u committed %u bulges %u big %u viol %d err %u\n",
-					                   rep.iterations, round, lo, limit, nwin, solo, c.v[CTR_COMMITTED], c.v[CTR_BULGES], c.v[CTR_BIG], (int)c.v[CTR_VIOL], c.v[CTR_ERR]);
+					                   rep.iterations, round, lo, this_limit, nwin, solo, c.v[CTR_COMMITTED], c.v[CTR_BULGES], c.v[CTR_BIG], (int)c.v[CTR_VIOL], c.v[CTR_ERR]);
 					if (trace && c.v[CTR_VIOL] != BT_NONE) fprintf(stderr, "[sbl] violation detail: kind %u resource %u other %u id %u info %u\n", c.v[CTR_DETAIL], c.v[CTR_DETAIL + 1], c.v[CTR_DETAIL + 2], c.v[CTR_DETAIL + 3], c.v[CTR_DETAIL + 4]);
 					if (c.v[CTR_ERR]) {
 						if (!be.grow(c.v[CTR_ERR])) throw SblError{SBL_ERR_INTERNAL, "bulge removal: unrecoverable capacity error"};

@@ -67,6 +67,10 @@ struct HostBackend {
 	{
 		ctr[CTR_ERR] = 0; ctr[CTR_BULGES] = 0; ctr[CTR_VIOL] = BT_NONE; ctr[CTR_BIG] = 0; ctr[CTR_COMMITTED] = 0; ctr[CTR_TXN] = 0;
 	}
+	// (the device backend launches the selection behind a round and reads it with the round's counters; here it is evaluated when read)
+	uint32_t sel_lo = 0, sel_limit = 0, sel_W = 0;
+	void select_launch(uint32_t lo, uint32_t limit, uint32_t W) { sel_lo = lo; sel_limit = limit; sel_W = W; }
+	void select_read(uint32_t *nwin, uint32_t *newlo, uint32_t *solo) { select(sel_lo, sel_limit, sel_W, nwin, newlo, solo); }
 	void select(uint32_t lo, uint32_t limit, uint32_t W, uint32_t *nwin, uint32_t *newlo, uint32_t *solo)
 	{
 		uint32_t n = 0;

@@ -90,6 +90,33 @@ def test_one_launch_path_falls_back_when_a_pool_runs_out(monkeypatch):
         bf.close()
 
 
+@pytest.mark.parametrize("checkpoints", [False, True])
+def test_abandoned_optimistic_attempt_is_rerun_with_checkpoints(monkeypatch, checkpoints):
+    """The first attempt at a stage takes no iteration checkpoints; when it would need a roll-back (here: the element pool is made too
+    small for the insertions of the stage) it is abandoned and the stage runs again from its input with checkpoints, pool growth
+    and iteration replays -- same result as the oracle, one progress sequence, the abandoned attempt counted as a replay."""
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.gen_strains(L0=60_000, n=4, seed=21, inv_min=2000, inv_max=6000)
+    monkeypatch.setenv("SBL_TEST_ELEM_SLACK", "64")
+    monkeypatch.setenv("SBL_NO_DENSE_PATH", "1")
+    if checkpoints:
+        monkeypatch.setenv("SBL_CHECKPOINTS", "1")
+    bf, orc = _bf(seqs), Oracle(seqs)
+    calls = []
+    try:
+        assert bf.PerformGraphSimplifications(25, 150, 4, lambda p, s: calls.append((p, s))) == orc.simplify_stage(25, 150, 4)
+        (sa, pa), (sb, pb) = bf.state(), orc.state()
+        assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+        st = bf.stats()
+        assert st["grow_replays"] >= 1 and st["replays"] >= st["grow_replays"] + (0 if checkpoints else 1)
+        assert calls[0] == (0, 0) and calls[-1] == (50, 2) and [s for _, s in calls].count(0) == 1 and [s for _, s in calls].count(2) == 1
+        runs = [p for p, s in calls if s == 1]
+        assert runs == [min(i + 1, 50) for i in range(len(runs))]
+    finally:
+        bf.close()
+
+
 @pytest.mark.parametrize("window", [1, 7, 100000])
 def test_window_size_does_not_change_results(window):
     # the number of ids committed per ordered round is a pure performance knob
