@@ -62,6 +62,8 @@ struct GraphView {
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
+	// start stamps of the round kernels (device wall clock; simplify.hip: DeviceBackend::stamp_*): 4 slots per round, nullptr = off
+	unsigned long long *tstamp; uint32_t tslot;
 };
 
 // ------------------------------------------------------------------------------------------- atomics (host + device)

@@ -4,6 +4,7 @@
 // launches (simplify_driver.h) and reads a 64-byte counter block back per round.
 #include <cstring>
 #include <algorithm>
+#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 
 #include "sbl_ctx.h"
@@ -11,6 +12,27 @@
 #include "simplify_driver.h"
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// ---- explicit address spaces for the transaction scratch -----------------------------------------------------------------
+// The scratch arrays of a transaction (bulge_txn.h: BulgeWork) are reached through pointers kept in LDS, some into the fast scratch
+// (LDS), some into the arena (HBM): to the compiler they are generic pointers, i.e. FLAT loads and stores.  On gfx9 a pending FLAT
+// operation forces every later wait to s_waitcnt vmcnt(0) lgkmcnt(0) (it may complete out of order), so ONE flat store in a scan
+// loop drains the bursts prefetched for the next windows as well: 73 of 86 waits in k_probe and 539 of 580 in k_commit were full
+// drains.  These accessors pick the address space explicitly: global_* / ds_* instructions, partial vmcnt waits, real prefetch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SBL_AS1 __attribute__((address_space(1)))
+#define SBL_AS3 __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ T ldg(const T *p) { return *(const SBL_AS1 T *)p; }                  // arena (t.alloc)
+template <class T> __device__ __forceinline__ void stg(T *p, T v) { *(SBL_AS1 T *)p = v; }
+template <class T> __device__ __forceinline__ T ldx(const T *p)                                                     // fast scratch or arena (t.alloc2 / falloc)
+{ return __builtin_amdgcn_is_shared((const void *)p) ? *(const SBL_AS3 T *)p : *(const SBL_AS1 T *)p; }
+template <class T> __device__ __forceinline__ void stx(T *p, T v) { if (__builtin_amdgcn_is_shared((const void *)p)) *(SBL_AS3 T *)p = v; else *(SBL_AS1 T *)p = v; }
+#else       // (the host pass of hipcc only parses the kernels)
+template <class T> __device__ __forceinline__ T ldg(const T *p) { return *p; }
+template <class T> __device__ __forceinline__ void stg(T *p, T v) { *p = v; }
+template <class T> __device__ __forceinline__ T ldx(const T *p) { return *p; }
+template <class T> __device__ __forceinline__ void stx(T *p, T v) { *p = v; }
+#endif
 
 // ------------------------------------------------------------------------------------------- graph construction kernels
 __global__ void __launch_bounds__(256) k_init_links(unsigned *__restrict__ nx, unsigned *__restrict__ pv, unsigned *__restrict__ nodeof0,
@@ -86,6 +108,14 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 }
 
 // ------------------------------------------------------------------------------------------- SimplifyGraph kernels
+// Start stamp of a round kernel: the first workgroup writes the device wall clock (constant rate, hipDeviceAttributeWallClockRate) into
+// the round's slot.  The kernels of a stream run back to back, so the difference of two consecutive start stamps is what a kernel cost,
+// launch gap included -- per-kernel times of every round for one 8-byte store each, where an event pair around a kernel costs ~8 us of
+// barrier packets (1.7 - 2.2 ms of a 100 ms stage for probe + reserve + commit).
+__device__ __forceinline__ void round_stamp(const GraphView &g, unsigned which)
+{
+	if (g.tstamp && blockIdx.x == 0 && threadIdx.x == 0) g.tstamp[g.tslot + which] = wall_clock64();
+}
 // ---- wave-cooperative window scan ---------------------------------------------------------------------------
 // Fills instance i's window cache (bulge_txn.h: BulgeWork) with 64 lanes: the same values bt_scan_instance
 // writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
@@ -150,7 +180,7 @@ __device__ __forceinline__ unsigned wave_list_nodes(const GraphView &g, unsigned
 __device__ __forceinline__ unsigned wave_list_positions(const GraphView &g, unsigned h0, unsigned h1, const BulgeWork &w, unsigned lane)
 {
 	return wave_list_nodes(g, h0, h1, lane, nullptr, [&](unsigned off, unsigned nd, unsigned s, unsigned el, unsigned) {
-		if (off < w.n) { w.start[off] = (nd << 1) | s; w.sel[off] = el; }
+		if (off < w.n) { stx(&w.start[off], (nd << 1) | s); stx(&w.sel[off], el); }
 	});
 }
 // bt_setup with the positions listed by all lanes; `ok` lives in LDS
@@ -189,60 +219,88 @@ __device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur
 	}
 }
 
-// pre: the first burst of this window, already in flight (issued while the previous window was being consumed)
-__device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
-                                                   unsigned stampv, unsigned tid, unsigned mode, unsigned id, const ScanBurst *pre_burst = nullptr)
+// one burst of a window scan: up to SCAN_BURST blocks of 64 consecutive slots, consumed in order, abandoned at the first link break or
+// separator.  (A function of its own, always inlined: as a lambda inside wave_scan_instance it stayed out of line in the largest
+// kernels, and a burst handed to it by reference was parked in scratch memory, every load waited for one by one.)
+struct ScanState { unsigned cur, done, wl, nm, lastc; bool finished; };
+__device__ __forceinline__ void scan_consume(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
+                                             const ScanBurst &bst, ScanState &s, unsigned dir, unsigned ws, bool lite, unsigned mks,
+                                             unsigned *wel, unsigned *wbf, uint8_t *wch, unsigned long long *wmk)
 {
-	const size_t base = (size_t)i * w.ws;
-	const unsigned packed = w.start[i], dir = packed & 1u, ws = w.ws;
-	unsigned cur = w.sel[i], done = 0, wl = ws, nm = 0, nb = 0, lastc = 0;
-	bool finished = false;
-	while (done < ws && cur != BT_NONE && !finished) {
-		if (!w.lite && done && cur != (dir ? lastc - 1 : lastc + 1)) {      // the walk leaves consecutive slots here
-			if (lane == 0 && nb < BT_MAX_BREAKS) w.wbk[i * BT_MAX_BREAKS + nb] = done;
+	const size_t base = (size_t)i * ws;
+	const unsigned kk = g.k;
+	const unsigned burst_done = s.done;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		if (burst_done + 64u * u >= ws) break;
+		const unsigned c = bst.cc[u], done = s.done;
+		unsigned long long ml = __ballot(bst.inr[u] && bst.plink[u] == c);
+		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
+		if (pre == 0) { s.cur = BT_NONE; s.finished = true; break; }     // cannot happen for u = 0; for u > 0 handled by the re-anchor below
+		bool mine = lane < pre;
+		unsigned long long ms = __ballot(mine && bst.chv[u] == BT_SEP);
+		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+		bool st = mine && lane <= stop;                               // the separator step itself is cached too
+		unsigned bv = st ? bst.bvl[u] : BT_NONE;
+		if (st) {
+			if (!lite) { stg(&wel[base + done + lane], c); stg(&wch[base + done + lane], (uint8_t)bst.chv[u]); stg(&wbf[base + done + lane], bv); }
+			if (done + lane == 0) stx(&w.wst[i], bv);
+			if (done + lane == kk) stx(&w.wck[i], dir ? bt_comp((char)bst.chv[u]) : (char)bst.chv[u]);
+		}
+		{	// compact list of the marked steps (>= 1, before the separator), in step order
+			bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
+			unsigned long long mm = __ballot(marked);
+			unsigned mo = s.nm + __popcll(mm & ((1ull << lane) - 1ull));
+			if (marked && mo < mks) stx(&wmk[mo], ((unsigned long long)(done + lane) << 32) | bv);
+			s.nm += __popcll(mm);
+		}
+		if (mode) {
+			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
+			if (st && bst.chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk, bst.wmv[u]);
+		}
+		if (stop < pre) { s.wl = done + stop; s.finished = true; break; }
+		s.cur = __shfl(bst.lnk[u], pre - 1);
+		s.lastc = __shfl(c, pre - 1);
+		s.done = done + pre;
+		if (pre < 64 || s.cur != (dir ? s.lastc - 1 : s.lastc + 1)) break;      // link break: re-anchor with a fresh burst
+	}
+}
+
+// pre_burst: the first burst of this window when it was issued ahead of time (while the previous windows were being consumed); it is
+// consumed from the registers it was loaded into
+template <bool HAVE_PRE>
+__device__ __forceinline__ void wave_scan_instance_t(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
+                                                     unsigned stampv, unsigned tid, unsigned mode, unsigned id, const ScanBurst pre_burst)
+{
+	const unsigned packed = ldx(&w.start[i]), dir = packed & 1u, ws = w.ws;
+	ScanState s;
+	s.cur = ldx(&w.sel[i]); s.done = 0; s.wl = ws; s.nm = 0; s.lastc = 0; s.finished = false;
+	unsigned nb = 0;
+	const bool lite = w.lite;
+	const unsigned mks = w.mks;
+	unsigned *const wel = w.wel, *const wbf = w.wbf, *const wbk = w.wbk; uint8_t *const wch = w.wch;
+	unsigned long long *const wmk = reinterpret_cast<unsigned long long *>(w.wmk) + (size_t)i * mks;
+	if (s.cur != BT_NONE) {
+		if (HAVE_PRE) scan_consume(g, w, i, lane, stampv, tid, mode, id, pre_burst, s, dir, ws, lite, mks, wel, wbf, wch, wmk);
+		else { ScanBurst bst; scan_burst_load(g, s.cur, dir, 0, ws, lane, bst, mode); scan_consume(g, w, i, lane, stampv, tid, mode, id, bst, s, dir, ws, lite, mks, wel, wbf, wch, wmk); }
+	}
+	while (s.done < ws && s.cur != BT_NONE && !s.finished) {
+		if (!lite && s.cur != (dir ? s.lastc - 1 : s.lastc + 1)) {        // the walk leaves consecutive slots here
+			if (lane == 0 && nb < BT_MAX_BREAKS) stg(&wbk[i * BT_MAX_BREAKS + nb], s.done);
 			nb++;
 		}
 		ScanBurst bst;
-		if (pre_burst && done == 0) bst = *pre_burst; else scan_burst_load(g, cur, dir, done, ws, lane, bst, mode);
-		const unsigned (&cc)[SCAN_BURST] = bst.cc, (&plink)[SCAN_BURST] = bst.plink, (&chv)[SCAN_BURST] = bst.chv, (&bvl)[SCAN_BURST] = bst.bvl, (&lnk)[SCAN_BURST] = bst.lnk, (&wmv)[SCAN_BURST] = bst.wmv;
-		const bool (&inr)[SCAN_BURST] = bst.inr;
-		const unsigned burst_done = done;
-#pragma unroll
-		for (int u = 0; u < SCAN_BURST; u++) {
-			if (burst_done + 64u * u >= ws) break;
-			const unsigned c = cc[u];
-			unsigned long long ml = __ballot(inr[u] && plink[u] == c);
-			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-			if (pre == 0) { cur = BT_NONE; finished = true; break; }     // cannot happen for u = 0; for u > 0 handled by the re-anchor below
-			bool mine = lane < pre;
-			unsigned long long ms = __ballot(mine && chv[u] == BT_SEP);
-			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
-			bool st = mine && lane <= stop;                               // the separator step itself is cached too
-			unsigned bv = st ? bvl[u] : BT_NONE;
-			if (st) {
-				if (!w.lite) { w.wel[base + done + lane] = c; w.wch[base + done + lane] = (uint8_t)chv[u]; w.wbf[base + done + lane] = bv; }
-				if (done + lane == 0) w.wst[i] = bv;
-				if (done + lane == g.k) w.wck[i] = dir ? bt_comp((char)chv[u]) : (char)chv[u];
-			}
-			{	// compact list of the marked steps (>= 1, before the separator), in step order
-				bool marked = mine && lane < stop && bv != BT_NONE && done + lane > 0;
-				unsigned long long mm = __ballot(marked);
-				unsigned mo = nm + __popcll(mm & ((1ull << lane) - 1ull));
-				if (marked && mo < w.mks) w.wmk[(size_t)i * w.mks + mo] = ((unsigned long long)(done + lane) << 32) | bv;
-				nm += __popcll(mm);
-			}
-			if (mode) {
-				unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
-				if (st && chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk, wmv[u]);
-			}
-			if (stop < pre) { wl = done + stop; finished = true; break; }
-			cur = __shfl(lnk[u], pre - 1);
-			lastc = __shfl(c, pre - 1);
-			done += pre;
-			if (pre < 64 || cur != (dir ? lastc - 1 : lastc + 1)) break;      // link break: re-anchor with a fresh burst
-		}
+		scan_burst_load(g, s.cur, dir, s.done, ws, lane, bst, mode);
+		scan_consume(g, w, i, lane, stampv, tid, mode, id, bst, s, dir, ws, lite, mks, wel, wbf, wch, wmk);
 	}
-	if (lane == 0) { w.wlen[i] = wl < ws ? wl : ws; w.wmn[i] = nm; if (!w.lite) w.wnb[i] = nb; if (nm > w.mks) *const_cast<bool *>(&w.mk_overflow) = true; }
+	if (lane == 0) { stx(&w.wlen[i], s.wl < ws ? s.wl : ws); stx(&w.wmn[i], s.nm); if (!lite) stg(&w.wnb[i], nb); if (s.nm > mks) *const_cast<bool *>(&w.mk_overflow) = true; }
+}
+
+__device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
+                                                   unsigned stampv, unsigned tid, unsigned mode, unsigned id, const ScanBurst *pre_burst = nullptr)
+{
+	if (pre_burst) wave_scan_instance_t<true>(g, w, i, lane, stampv, tid, mode, id, *pre_burst);
+	else { ScanBurst none; wave_scan_instance_t<false>(g, w, i, lane, stampv, tid, mode, id, none); }
 }
 
 // windows first, first + stride, ... of the cache; the first bursts of the next TWO windows are in flight while a window is consumed
@@ -250,14 +308,18 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
                                               unsigned first = 0, unsigned stride = 1)
 {
-	ScanBurst b1, b2;
-	if (first < w.n) scan_burst_load(g, w.sel[first], w.start[first] & 1u, 0, w.ws, lane, b1, mode);
-	if (first + stride < w.n) scan_burst_load(g, w.sel[first + stride], w.start[first + stride] & 1u, 0, w.ws, lane, b2, mode);
-	for (unsigned i = first; i < w.n; i += stride) {
-		const ScanBurst b = b1;
-		b1 = b2;
-		if (i + 2 * stride < w.n) scan_burst_load(g, w.sel[i + 2 * stride], w.start[i + 2 * stride] & 1u, 0, w.ws, lane, b2, mode);
-		wave_scan_instance(g, w, i, lane, stampv, tid, mode, id, &b);
+	// Two windows in flight, each in registers of its own: the loop body is unrolled twice so that a burst is consumed from the
+	// registers it was loaded into (rotating the bursts through copies makes every copy wait for its load, i.e. no prefetch at all)
+	const unsigned n = w.n, ws = w.ws;
+	ScanBurst b0, b1;
+	if (first < n) scan_burst_load(g, ldx(&w.sel[first]), ldx(&w.start[first]) & 1u, 0, ws, lane, b0, mode);
+	if (first + stride < n) scan_burst_load(g, ldx(&w.sel[first + stride]), ldx(&w.start[first + stride]) & 1u, 0, ws, lane, b1, mode);
+	for (unsigned i = first; i < n; i += 2 * stride) {
+		wave_scan_instance_t<true>(g, w, i, lane, stampv, tid, mode, id, b0);
+		if (i + 2 * stride < n) scan_burst_load(g, ldx(&w.sel[i + 2 * stride]), ldx(&w.start[i + 2 * stride]) & 1u, 0, ws, lane, b0, mode);
+		if (i + stride >= n) break;
+		wave_scan_instance_t<true>(g, w, i + stride, lane, stampv, tid, mode, id, b1);
+		if (i + 3 * stride < n) scan_burst_load(g, ldx(&w.sel[i + 3 * stride]), ldx(&w.start[i + 3 * stride]) & 1u, 0, ws, lane, b1, mode);
 	}
 }
 
@@ -275,15 +337,15 @@ __device__ __forceinline__ int wave_verdict_instance(const GraphView &g, const B
 	const unsigned D = g.D, k = g.k;
 	bool found = false;
 	{
-		const unsigned len = w.wlen[i];
+		const unsigned len = ldx(&w.wlen[i]);
 		if (len < k + 1) return 0;                                     // endChar == ' '
-		const char ec = w.wck[i];
+		const char ec = ldx(&w.wck[i]);
 		const unsigned bit = ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
-		const unsigned lim = len < D ? len : D, nm = w.wmn[i], start = w.wst[i];
+		const unsigned lim = len < D ? len : D, nm = ldx(&w.wmn[i]), start = ldx(&w.wst[i]);
 		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
 		for (unsigned j0 = 0; j0 < nm; j0 += 64) {
 			unsigned j = j0 + lane;
-			unsigned long long v = j < nm ? mk[j] : ~0ull;
+			unsigned long long v = j < nm ? ldx(&mk[j]) : ~0ull;
 			unsigned b = (unsigned)v, step = (unsigned)(v >> 32);
 			bool stop = j >= nm || step >= lim || b == start;
 			unsigned long long ms = __ballot(stop);
@@ -676,6 +738,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
 	const unsigned wi = blockIdx.x, lane = threadIdx.x & 63u;
+	round_stamp(g, 0);
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
@@ -689,20 +752,27 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	int verdict = 0;
 	if (ok) {
 		unsigned distinct = 0;
-		ScanBurst nb, nb2;                                                 // the next two windows' first bursts are in flight
-		scan_burst_load(g, w.sel[0], w.start[0] & 1u, 0, w.ws, lane, nb, 3u);
-		if (w.n > 1) scan_burst_load(g, w.sel[1], w.start[1] & 1u, 0, w.ws, lane, nb2, 3u);
-		for (unsigned i = 0; i < w.n && verdict == 0; i++) {
-			ScanBurst b = nb;
-			nb = nb2;
-			if (i + 2 < w.n) scan_burst_load(g, w.sel[i + 2], w.start[i + 2] & 1u, 0, w.ws, lane, nb2, 3u);
-			verdict = wave_probe_window(g, b, w.start[i] & 1u, w.ws, vt, lane, id, tid, distinct);
-			if (verdict == -2) {                                            // a link break inside the window (an earlier collapse): the generic pair
+		// two windows in flight, each consumed from the registers it was loaded into (see wave_scan_all)
+		const unsigned n = w.n, ws = w.ws;
+		ScanBurst b0, b1;
+		auto issue = [&](unsigned i, ScanBurst &b) { if (i < n) scan_burst_load(g, ldx(&w.sel[i]), ldx(&w.start[i]) & 1u, 0, ws, lane, b, 3u); };
+		auto step = [&](unsigned i, const ScanBurst &b) -> int {
+			int v = wave_probe_window(g, b, ldx(&w.start[i]) & 1u, ws, vt, lane, id, tid, distinct);
+			if (v == -2) {                                                  // a link break inside the window (an earlier collapse): the generic pair
 				wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
 				__syncthreads();
-				if (w.mk_overflow) { verdict = -1; break; }                 // more marks than the LDS list holds: the generic path below decides
-				verdict = wave_verdict_instance(g, w, vt, lane, i, distinct);
+				if (w.mk_overflow) return -1;                               // more marks than the LDS list holds: the generic path below decides
+				v = wave_verdict_instance(g, w, vt, lane, i, distinct);
 			}
+			return v;
+		};
+		issue(0, b0); issue(1, b1);
+		for (unsigned i = 0; i < n; i += 2) {
+			if ((verdict = step(i, b0)) != 0) break;
+			issue(i + 2, b0);
+			if (i + 1 >= n) break;
+			if ((verdict = step(i + 1, b1)) != 0) break;
+			issue(i + 3, b1);
 		}
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
@@ -759,6 +829,7 @@ __device__ __forceinline__ void select_scan_flags(const GraphView &g, unsigned l
 __global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsigned *__restrict__ sel, unsigned lo, unsigned limit, unsigned chunk0, unsigned chunk)
 {
 	__shared__ unsigned s_cnt;
+	round_stamp(g, 3);                                               // the selection behind a round: its start is the end of the round's last kernel
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
 	const unsigned per = chunk / SEL_THREADS;
@@ -1048,6 +1119,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	round_stamp(g, 1);
 	if (w >= nwin || !live[w]) return;
 	__shared__ unsigned seen[SEEN_SLOTS];
 	__shared__ unsigned resume[RESUME_SLOTS], inst[RESUME_SLOTS];     // per instance: end of the core walk; (element << 1) | strand
@@ -1683,7 +1755,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	}
 }
 
-__global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -1691,6 +1763,7 @@ __global__ void __launch_bounds__(64) k_commit(GraphView g, unsigned nwin, uint8
 	__shared__ ABShared absh;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[COMMIT_FAST_BYTES];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	round_stamp(g, 2);
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi;
@@ -1728,6 +1801,7 @@ __global__ void __launch_bounds__(64) k_chain(GraphView g, uint8_t *arena, unsig
 	__shared__ ABShared absh;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[12288];
 	const unsigned lane = threadIdx.x;
+	round_stamp(g, 2);
 	if (!nwin) return;
 	const unsigned long long limit = g.win[nwin - 1];
 	unsigned long long cur = g.win[0];
@@ -1963,7 +2037,7 @@ struct SimplifyState {
 	DevBuf arena, snap_arena, big_arena, claims, live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
-	DevBuf nmark, maux[2], iota, sel;
+	DevBuf nmark, maux[2], iota, sel, tstamp;
 	DevBuf lin, elin, lmpos[2], lmid[2], cnt1k, off1k;      // linearised marks of the later snapshots
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
 	unsigned *h_ctr = nullptr;            // pinned
@@ -1981,8 +2055,7 @@ struct DeviceBackend {
 	uint32_t big_arena_bytes = 1u << 28;
 	size_t nres = 0;
 	hipEvent_t ev[8] = {};
-	bool timed_reserve = false, timed_commit = false, timed_probe = false;
-	hipEvent_t rsv_start = nullptr;
+	bool timed_commit = false;
 	bool later_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr && getenv("SBL_NO_LATER_STREAM") == nullptr;
 	bool first_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr;      // measurement switch: the generic window-walking snapshot for iteration 1 too
 	int prof = 0;
@@ -2005,13 +2078,14 @@ struct DeviceBackend {
 		}
 		g.nslot = st->nslot.as<uint32_t>(); g.nnext = st->nnext.as<uint32_t>(); g.nidst = st->nidst.as<uint32_t>(); g.nclr = st->nclr.as<uint32_t>(); g.ndead = st->ndead.as<uint8_t>();
 		g.ctr = st->ctr.as<uint32_t>(); g.need = st->need.as<uint8_t>(); g.big = st->big.as<uint8_t>(); g.touch = st->touch.as<uint8_t>();
-		g.own = st->own.as<uint32_t>(); g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
+		g.own = st->own.as<uint32_t>(); g.lock = nullptr; g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 		g.cap_e = cap_e; g.cap_n = cap_n; g.nid = nid_;
 		g.nblk = (cap_e >> BT_BLOCK_SHIFT) + 1;
 		g.win = st->win.as<uint32_t>();
 		nres = (size_t)g.nblk + nid_ + 1;
-		st->lock.ensure(nres * 4); st->rmax.ensure(nres * 4); st->wmax.ensure(nres * 4);
-		g.lock = st->lock.as<uint32_t>(); g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
+		// (lock[] belongs to the element-wise stamping of the host-side test driver; the kernels check exclusivity against own[])
+		st->rmax.ensure(nres * 4); st->wmax.ensure(nres * 4);
+		g.lock = nullptr; g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 	}
 	void read_ctr()
 	{
@@ -2156,7 +2230,6 @@ struct DeviceBackend {
 	void reset_round_state(bool stamps_too)
 	{
 		HIP_TRY(hipMemsetAsync(st->own.p, 0xFF, ((size_t)nid_ + 1) * 4, c->stream));
-		HIP_TRY(hipMemsetAsync(st->lock.p, 0xFF, nres * 4, c->stream));
 		if (stamps_too) {
 			HIP_TRY(hipMemsetAsync(st->rmax.p, 0, nres * 4, c->stream));
 			HIP_TRY(hipMemsetAsync(st->wmax.p, 0, nres * 4, c->stream));
@@ -2178,7 +2251,12 @@ struct DeviceBackend {
 		unsigned chunk = 8192;
 		while ((unsigned long long)chunk * 1024 < (unsigned long long)nid_ + 1) chunk <<= 1;
 		const unsigned chunk0 = lo / chunk, nchunks = limit / chunk - chunk0 + 1;
-		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), lo, limit, chunk0, chunk);
+		// (one launch with a look-back over per-chunk slots was tried: 37.7 us against 10.7 + 10.6 us for the two -- the agent-scope
+		// release / acquire of the slots writes back and invalidates the L2 of the XCD, which a kernel boundary does once)
+		GraphView gs = g;
+		if (sel_stamped) gs.tslot = TS_CAP * 4;                     // only the selection right behind a round marks that round's end
+		sel_stamped = true;
+		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(gs, st->sel.as<unsigned>(), lo, limit, chunk0, chunk);
 		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks);
 		HIP_TRY(hipGetLastError());
 		sel_pending = true; sel_ready = false;
@@ -2189,39 +2267,70 @@ struct DeviceBackend {
 		sel_pending = sel_ready = false;
 		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
 	}
+	// Per-kernel times of the rounds: start stamps written by the kernels themselves (round_stamp) for probe and reservation, and a
+	// HIP event pair around the dominant kernel, k_commit (what bench.py's roofline is computed from).
+	bool phase_events = getenv("SBL_NO_PHASE_EVENTS") == nullptr;    // measurement switch: what the per-round events themselves cost
+	enum { TS_CAP = 16384 };                                         // rounds with stamps per stage (later ones go untimed)
+	uint32_t ts_round = 0;
+	bool sel_stamped = true;
+	std::vector<uint8_t> ts_kind;                                    // per round: bit 0 probe, bit 1 reservation launched
+	void stamps_init()
+	{
+		st->tstamp.ensure((size_t)(TS_CAP + 1) * 4 * 8);
+		HIP_TRY(hipMemsetAsync(st->tstamp.p, 0, (size_t)(TS_CAP + 1) * 4 * 8, c->stream));
+		ts_round = 0; ts_kind.clear(); sel_stamped = true;
+		g.tstamp = st->tstamp.as<unsigned long long>(); g.tslot = TS_CAP * 4;      // (the slot behind the last round: writes nobody reads)
+	}
+	void begin_round()
+	{
+		if (ts_round < TS_CAP) { g.tslot = 4 * ts_round++; ts_kind.push_back(0); sel_stamped = false; }
+		else g.tslot = TS_CAP * 4;
+	}
+	// probe_ms / reserve_ms of the stage from the stamps (the event pair gives commit_ms)
+	void stamps_collect()
+	{
+		if (!ts_round) return;
+		std::vector<unsigned long long> h((size_t)ts_round * 4);
+		HIP_TRY(hipMemcpyAsync(h.data(), st->tstamp.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		int khz = 0;
+		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+		const double ms_per_tick = 1.0 / (double)khz;
+		for (uint32_t r = 0; r < ts_round; r++) {
+			const unsigned long long tp = h[4 * r], tr = h[4 * r + 1], tc = h[4 * r + 2];
+			const bool probed = ts_kind[r] & 1, reserved = ts_kind[r] & 2;
+			if (probed) { const unsigned long long next = reserved ? tr : tc; if (next > tp && tp) probe_ms += (double)(next - tp) * ms_per_tick; }
+			if (reserved && tc > tr && tr) reserve_ms += (double)(tc - tr) * ms_per_tick;
+		}
+	}
 	void probe(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		HIP_TRY(hipEventRecord(ev[4], c->stream));
+		begin_round();
+		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
 		k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
 		k_count_retired<<<(nwin + 1023) / 1024, 256, 0, c->stream>>>(st->live.as<uint8_t>(), nwin, g.ctr + CTR_COMMITTED);
-		HIP_TRY(hipEventRecord(ev[5], c->stream));
-		timed_probe = true;
 		HIP_TRY(hipGetLastError());
 	}
-	void mark_live(uint32_t nwin) { HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
+	void mark_live(uint32_t nwin) { begin_round(); HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		// an event between two kernels costs a ~5 us bubble on the stream: the probe's end event doubles as the start of the reservation,
-		// the commit's start event as its end (solo rounds have no probe: own start event)
-		rsv_start = timed_probe ? ev[5] : ev[0];
-		if (!timed_probe) HIP_TRY(hipEventRecord(ev[0], c->stream));
+		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 2;
 		k_reserve<<<nwin, 64 * RSV_WAVES, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
-		timed_reserve = true;
 		HIP_TRY(hipGetLastError());
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		HIP_TRY(hipEventRecord(ev[2], c->stream));
+		if (phase_events) HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
 			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr, prof);
 		} else
 			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
-		HIP_TRY(hipEventRecord(ev[3], c->stream));
-		timed_commit = true;
+		if (phase_events) HIP_TRY(hipEventRecord(ev[3], c->stream));
+		timed_commit = phase_events;
 		HIP_TRY(hipGetLastError());
 	}
 	// serial chain over what is pending in the id range of the window (k_chain); timed with the commit phase
@@ -2229,10 +2338,10 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		st->big_arena.ensure(big_arena_bytes);
-		HIP_TRY(hipEventRecord(ev[2], c->stream));
+		if (phase_events) HIP_TRY(hipEventRecord(ev[2], c->stream));
 		k_chain<<<1, 64, 0, c->stream>>>(g, st->big_arena.as<uint8_t>(), big_arena_bytes, nwin, prof);
-		HIP_TRY(hipEventRecord(ev[3], c->stream));
-		timed_commit = true;
+		if (phase_events) HIP_TRY(hipEventRecord(ev[3], c->stream));
+		timed_commit = phase_events;
 		HIP_TRY(hipGetLastError());
 		return true;
 	}
@@ -2241,10 +2350,7 @@ struct DeviceBackend {
 		read_ctr();
 		if (sel_pending) sel_ready = true;                          // the snapshot holds the selection launched before it as well
 		float ms = 0;
-		if (timed_reserve && timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, rsv_start, ev[2])); reserve_ms += ms; }
-		timed_reserve = false;
 		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_ms += ms; timed_commit = false; }
-		if (timed_probe) { HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); probe_ms += ms; timed_probe = false; }
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
 		return r;
@@ -2284,7 +2390,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
 	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
-	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
+	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
@@ -2485,6 +2591,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	be.g.tstamp = nullptr; be.g.tslot = 0;
+	if (!dense && be.phase_events) be.stamps_init();
 	HIP_TRY(hipEventRecord(c->ev[3], s));
 
 	// ---- SimplifyGraph
@@ -2521,6 +2629,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		catch (const RestartStage &) { HIP_TRY(hipStreamSynchronize(s)); return RUN_RESTART; }
 	}
 	HIP_TRY(hipEventRecord(c->ev[4], s));
+	if (!dense && be.phase_events) be.stamps_collect();
 
 	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays
 	be.read_ctr();
