@@ -203,19 +203,46 @@ enum { SCAN_BURST = 3 };
 // wmv: the write stamp of every element of the burst, loaded WITH the burst (stamped scans only): the order check "nothing I read was
 // written by a higher id" used to load it per 64-element block after the block had been consumed -- one exposed memory round trip
 // per block, three per window, in every probe and every writer pass.
-struct ScanBurst { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; bool inr[SCAN_BURST]; };
+// What a burst HOLDS while it is in flight: four loaded values per element (character, own-strand mark, link, write stamp) -- the
+// element indices, the in-range flags and the link of the PREVIOUS element (= the link the lane before loaded) are recomputed when the
+// burst is consumed (burst_view).  Every lane loads unconditionally (lanes beyond the window read the window's first element): a
+// predicated load becomes a branch around the instruction, and a load that may not have been issued makes the compiler wait for ALL
+// outstanding loads wherever a later burst is consumed -- with unconditional loads it emits vmcnt(n) for exactly the younger ones, so
+// the bursts of a whole batch of windows are in flight together (one memory round trip per SCAN_BATCH windows).
+struct ScanBurst { unsigned chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; unsigned cur, done; };
+struct ScanView { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; bool inr[SCAN_BURST]; };
 __device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
 {
+	(void)mode;
+	b.cur = cur; b.done = done;
+	const unsigned *__restrict__ link = dir ? g.pv : g.nx, *__restrict__ mark = g.bif[dir];
 #pragma unroll
 	for (int u = 0; u < SCAN_BURST; u++) {
-		unsigned off = lane + 64u * u;
-		b.inr[u] = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
-		b.cc[u] = dir ? cur - off : cur + off;
-		b.plink[u] = b.inr[u] && off ? (dir ? g.pv[b.cc[u] + 1] : g.nx[b.cc[u] - 1]) : b.cc[u];
-		b.chv[u] = b.inr[u] ? g.ch[b.cc[u]] : 0u;
-		b.bvl[u] = b.inr[u] ? g.bif[dir][b.cc[u]] : BT_NONE;
-		b.lnk[u] = b.inr[u] ? (dir ? g.pv[b.cc[u]] : g.nx[b.cc[u]]) : BT_NONE;
-		b.wmv[u] = mode && b.inr[u] ? g.wmax[b.cc[u] >> BT_BLOCK_SHIFT] : 0u;
+		const unsigned off = lane + 64u * u;
+		const bool inr = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
+		const unsigned x = inr ? (dir ? cur - off : cur + off) : cur;
+		b.chv[u] = g.ch[x];
+		b.bvl[u] = mark[x];
+		b.lnk[u] = link[x];
+		b.wmv[u] = g.wmax[x >> BT_BLOCK_SHIFT];
+	}
+}
+// the burst as its consumers see it (the values scan_burst_load used to produce directly)
+__device__ __forceinline__ void burst_view(const GraphView &g, const ScanBurst &b, unsigned dir, unsigned ws, unsigned lane, unsigned mode, ScanView &v)
+{
+	const unsigned cur = b.cur, done = b.done;
+#pragma unroll
+	for (int u = 0; u < SCAN_BURST; u++) {
+		const unsigned off = lane + 64u * u;
+		v.inr[u] = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
+		v.cc[u] = dir ? cur - off : cur + off;
+		unsigned prev = __shfl_up(b.lnk[u], 1);                           // the link loaded by the lane before: the previous element's link
+		if (u > 0) { const unsigned last = __shfl(b.lnk[u > 0 ? u - 1 : 0], 63); if (lane == 0) prev = last; }
+		v.plink[u] = v.inr[u] && off ? prev : v.cc[u];
+		v.chv[u] = v.inr[u] ? b.chv[u] : 0u;
+		v.bvl[u] = v.inr[u] ? b.bvl[u] : BT_NONE;
+		v.lnk[u] = v.inr[u] ? b.lnk[u] : BT_NONE;
+		v.wmv[u] = mode && v.inr[u] ? b.wmv[u] : 0u;
 	}
 }
 
@@ -224,9 +251,11 @@ __device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur
 // kernels, and a burst handed to it by reference was parked in scratch memory, every load waited for one by one.)
 struct ScanState { unsigned cur, done, wl, nm, lastc; bool finished; };
 __device__ __forceinline__ void scan_consume(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
-                                             const ScanBurst &bst, ScanState &s, unsigned dir, unsigned ws, bool lite, unsigned mks,
+                                             const ScanBurst &raw, ScanState &s, unsigned dir, unsigned ws, bool lite, unsigned mks,
                                              unsigned *wel, unsigned *wbf, uint8_t *wch, unsigned long long *wmk)
 {
+	ScanView bst;
+	burst_view(g, raw, dir, ws, lane, mode, bst);
 	const size_t base = (size_t)i * ws;
 	const unsigned kk = g.k;
 	const unsigned burst_done = s.done;
@@ -303,23 +332,30 @@ __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const Bul
 	else { ScanBurst none; wave_scan_instance_t<false>(g, w, i, lane, stampv, tid, mode, id, none); }
 }
 
-// windows first, first + stride, ... of the cache; the first bursts of the next TWO windows are in flight while a window is consumed
-// (a burst takes longer to arrive than a window takes to consume)
+// windows first, first + stride, ... of the cache, SCAN_BATCH at a time: the first bursts of a whole batch are issued together and
+// then consumed in order (see ScanBurst: one memory round trip per batch instead of one per window)
+#ifndef SCAN_BATCH
+#define SCAN_BATCH 4
+#endif
 __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned stampv, unsigned tid, unsigned mode, unsigned id,
                                               unsigned first = 0, unsigned stride = 1)
 {
-	// Two windows in flight, each in registers of its own: the loop body is unrolled twice so that a burst is consumed from the
-	// registers it was loaded into (rotating the bursts through copies makes every copy wait for its load, i.e. no prefetch at all)
 	const unsigned n = w.n, ws = w.ws;
-	ScanBurst b0, b1;
-	if (first < n) scan_burst_load(g, ldx(&w.sel[first]), ldx(&w.start[first]) & 1u, 0, ws, lane, b0, mode);
-	if (first + stride < n) scan_burst_load(g, ldx(&w.sel[first + stride]), ldx(&w.start[first + stride]) & 1u, 0, ws, lane, b1, mode);
-	for (unsigned i = first; i < n; i += 2 * stride) {
-		wave_scan_instance_t<true>(g, w, i, lane, stampv, tid, mode, id, b0);
-		if (i + 2 * stride < n) scan_burst_load(g, ldx(&w.sel[i + 2 * stride]), ldx(&w.start[i + 2 * stride]) & 1u, 0, ws, lane, b0, mode);
-		if (i + stride >= n) break;
-		wave_scan_instance_t<true>(g, w, i + stride, lane, stampv, tid, mode, id, b1);
-		if (i + 3 * stride < n) scan_burst_load(g, ldx(&w.sel[i + 3 * stride]), ldx(&w.start[i + 3 * stride]) & 1u, 0, ws, lane, b1, mode);
+	for (unsigned i = first; i < n; i += SCAN_BATCH * stride) {
+		unsigned sel[SCAN_BATCH], dir[SCAN_BATCH];
+		ScanBurst b[SCAN_BATCH];
+#pragma unroll
+		for (int j = 0; j < SCAN_BATCH; j++) {                            // (all look-ups first: they may be loads from the arena themselves)
+			const unsigned x = i + j * stride < n ? i + j * stride : i;   // a short last batch loads its first window again
+			sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u;
+		}
+#pragma unroll
+		for (int j = 0; j < SCAN_BATCH; j++) scan_burst_load(g, sel[j], dir[j], 0, ws, lane, b[j], mode);
+#pragma unroll
+		for (int j = 0; j < SCAN_BATCH; j++) {
+			if (i + j * stride >= n) break;
+			wave_scan_instance_t<true>(g, w, i + j * stride, lane, stampv, tid, mode, id, b[j]);
+		}
 	}
 }
 
@@ -650,9 +686,11 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 // k), the marked steps before the window's end and before the instance's own id recurs.  Returns 1 (some id is now reached by two
 // instances with different endChars), 0, -1 (the table could fill up), -2 (a link break inside the window, k or D beyond the burst:
 // the generic pair of functions takes this window).
-__device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanBurst &b, unsigned dir, unsigned ws, VerdictTable &vt, unsigned lane,
+__device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanBurst &raw, unsigned dir, unsigned ws, VerdictTable &vt, unsigned lane,
                                                  unsigned id, unsigned tid, unsigned &distinct)
 {
+	ScanView b;
+	burst_view(g, raw, dir, ws, lane, 3u, b);
 	const unsigned k = g.k, D = g.D;
 	if (k >= 64u * SCAN_BURST) return -2;
 	unsigned firstbad = ~0u, firstsep = ~0u;
@@ -729,6 +767,9 @@ __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanB
 
 // Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
 // without reservation (ss_probe); the others are flagged live and go through reserve / commit.
+#ifndef PROBE_BATCH
+#define PROBE_BATCH 4
+#endif
 #define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
 __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
 {
@@ -752,12 +793,10 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	int verdict = 0;
 	if (ok) {
 		unsigned distinct = 0;
-		// two windows in flight, each consumed from the registers it was loaded into (see wave_scan_all)
+		// the first bursts of PROBE_BATCH windows are in flight together (see ScanBurst / wave_scan_all)
 		const unsigned n = w.n, ws = w.ws;
-		ScanBurst b0, b1;
-		auto issue = [&](unsigned i, ScanBurst &b) { if (i < n) scan_burst_load(g, ldx(&w.sel[i]), ldx(&w.start[i]) & 1u, 0, ws, lane, b, 3u); };
-		auto step = [&](unsigned i, const ScanBurst &b) -> int {
-			int v = wave_probe_window(g, b, ldx(&w.start[i]) & 1u, ws, vt, lane, id, tid, distinct);
+		auto step = [&](unsigned i, unsigned dir, const ScanBurst &b) __attribute__((always_inline)) -> int {
+			int v = wave_probe_window(g, b, dir, ws, vt, lane, id, tid, distinct);
 			if (v == -2) {                                                  // a link break inside the window (an earlier collapse): the generic pair
 				wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
 				__syncthreads();
@@ -766,13 +805,21 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 			}
 			return v;
 		};
-		issue(0, b0); issue(1, b1);
-		for (unsigned i = 0; i < n; i += 2) {
-			if ((verdict = step(i, b0)) != 0) break;
-			issue(i + 2, b0);
-			if (i + 1 >= n) break;
-			if ((verdict = step(i + 1, b1)) != 0) break;
-			issue(i + 3, b1);
+		for (unsigned i = 0; i < n && verdict == 0; i += PROBE_BATCH) {
+			unsigned sel[PROBE_BATCH], dir[PROBE_BATCH];
+			ScanBurst b[PROBE_BATCH];
+#pragma unroll
+			for (int j = 0; j < PROBE_BATCH; j++) {
+				const unsigned x = i + j < n ? i + j : i;
+				sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u;
+			}
+#pragma unroll
+			for (int j = 0; j < PROBE_BATCH; j++) scan_burst_load(g, sel[j], dir[j], 0, ws, lane, b[j], 3u);
+#pragma unroll
+			for (int j = 0; j < PROBE_BATCH; j++) {
+				if (i + j >= n) break;
+				if ((verdict = step(i + j, dir[j], b[j])) != 0) break;
+			}
 		}
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
