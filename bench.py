@@ -144,7 +144,7 @@ def main():
         bulges = step()
         st = bf.stats()
         for key, v in st.items():
-            if key.endswith("_ms"):
+            if key.endswith("_ms") or key == "commit_event_launches":
                 agg[key] = agg.get(key, 0.0) + v
     torch.cuda.synchronize()
     if world > 1:
@@ -220,7 +220,15 @@ def main():
                "k_reserve": 8.0 * nbh * inst_per_launch, "k_commit": 8.0 * (a.D + a.k) * inst_per_launch,
                "k_probe": 4.0 * (a.D + a.k) * probed_per_launch}
         dom = max(per, key=lambda kk: per[kk])
-        dur_ms = per[dom] / launches[dom]
+        dur_ms = per[dom] / launches[dom]                  # device wall-clock start stamps, every launch of the timed steps
+        dur_ms_clock, timing = dur_ms, "device wall-clock start stamps written by the round kernels, every launch of the timed steps"
+        ev_launches = agg.pop("commit_event_launches", 0.0)
+        if dom == "k_commit" and ev_launches > 0:
+            # HIP event pairs on the context's stream around every 4th launch of k_commit (which ones rotates from step to step): an
+            # event pair around every round kernel cost 1.7 - 2.2 ms of the stage; the stamps beside them time every launch
+            dur_ms = agg["commit_event_ms"] / ev_launches
+            timing = ("HIP event pairs around %d of the %d launches of k_commit in the timed steps (every 4th, rotating); "
+                      "avg_launch_ms_all_launches = device wall-clock start stamps of every launch" % (int(ev_launches), launches[dom] * a.steps))
         achieved_design = alg[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         # SURVEY.md 8d's figure (what roofline.achieved / frac use): bytes = N x 24.125 (table: 0.125 sequence + 16 build + 8 resolve)
         # + 12 x instances + iterations x N x 4 (one streaming pass over the dense marks per iteration).  The simplification share
@@ -257,7 +265,8 @@ def main():
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": dur_ms, "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg8d[dom],
+                         "avg_launch_ms": dur_ms, "avg_launch_ms_all_launches": dur_ms_clock, "timing": timing,
+                         "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg8d[dom],
                          "algorithmic_model": "SURVEY.md 8d: N x 24.125 + 12 x instances + iterations x N x 4 = %.2f GB per stage; the simplification share "
                                               "(iterations x N x 4 B) spread over the launches of the dominant kernel" % (stage_8d / 1e9),
                          "stage": {"bytes_8d": stage_8d, "achieved": stage_8d / (ms_step * 1e-3) / 1e9, "frac": stage_8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -54,7 +54,7 @@ typedef struct {
 	char pad_[3];
 } sbl_edge;
 
-/* Per-stage counters / timings of the last sbl_simplify_stage (seconds are device-event times). */
+/* Per-stage counters / timings of the last sbl_simplify_stage (times measured on the device). */
 typedef struct {
 	uint64_t strand_kmers;           /* N = 2 * sum(max(0, len - k + 1)), the metric's unit */
 	uint64_t bif_count, instances;   /* after enumeration */
@@ -72,6 +72,10 @@ typedef struct {
 	double exchange_ms;              /* sharded enumeration: host time inside the collectives (all-to-all + gathers) */
 	uint64_t exchange_bytes;         /* ... and the bytes this GPU sent to its peers */
 	uint64_t chain_transactions;     /* transactions run by the serial chain (dense conflict neighbourhoods: small k, low complexity) */
+	/* probe_ms / reserve_ms / commit_ms come from start stamps the round kernels write themselves (device wall clock, every launch);
+	 * HIP event pairs are recorded around every 4th launch of the commit kernel only (an event pair costs ~8 us of barrier packets): */
+	double commit_event_ms;          /* sum of those event-pair times */
+	uint64_t commit_event_launches;  /* ... and how many launches they cover */
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -4,6 +4,7 @@
 
 struct sbl_ctx {
 	int device = 0;
+	unsigned stage_seq = 0;          // stages run on this context (rotates which launches carry an event pair, simplify.hip)
 	hipStream_t stream = nullptr;
 	std::string err;
 	GlibcRand rng;

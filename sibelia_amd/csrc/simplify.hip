@@ -2111,6 +2111,8 @@ struct DeviceBackend {
 	// the stage is run again from its input -- intact until the copy-back -- with checkpoints and iteration replays (sbl_simplify_run).
 	bool optimistic = false;
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
+	double commit_event_ms = 0; uint64_t commit_event_launches = 0;      // the event pairs around every 4th launch of the commit kernel
+	unsigned ev_phase = 0;
 
 	DeviceBackend() = default;
 	DeviceBackend(const DeviceBackend &) = delete;
@@ -2320,7 +2322,7 @@ struct DeviceBackend {
 	enum { TS_CAP = 16384 };                                         // rounds with stamps per stage (later ones go untimed)
 	uint32_t ts_round = 0;
 	bool sel_stamped = true;
-	std::vector<uint8_t> ts_kind;                                    // per round: bit 0 probe, bit 1 reservation launched
+	std::vector<uint8_t> ts_kind;                                    // per round: bit 0 probe, bit 1 reservation, bit 2 commit / chain launched
 	void stamps_init()
 	{
 		st->tstamp.ensure((size_t)(TS_CAP + 1) * 4 * 8);
@@ -2348,6 +2350,8 @@ struct DeviceBackend {
 			const bool probed = ts_kind[r] & 1, reserved = ts_kind[r] & 2;
 			if (probed) { const unsigned long long next = reserved ? tr : tc; if (next > tp && tp) probe_ms += (double)(next - tp) * ms_per_tick; }
 			if (reserved && tc > tr && tr) reserve_ms += (double)(tc - tr) * ms_per_tick;
+			const unsigned long long te = h[4 * r + 3];                 // start of the selection behind the round
+			if ((ts_kind[r] & 4) && te > tc && tc) commit_ms += (double)(te - tc) * ms_per_tick;
 		}
 	}
 	void probe(uint32_t nwin, uint32_t round)
@@ -2370,14 +2374,17 @@ struct DeviceBackend {
 	void commit(uint32_t nwin, uint32_t round, bool solo)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
-		if (phase_events) HIP_TRY(hipEventRecord(ev[2], c->stream));
+		// an event pair around every 4th launch (which ones rotates from stage to stage); the start stamps time all of them
+		const bool sampled = phase_events && ((round + ev_phase) & 3u) == 0;
+		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 4;
+		if (sampled) HIP_TRY(hipEventRecord(ev[2], c->stream));
 		if (solo) {
 			st->big_arena.ensure(big_arena_bytes);
 			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr, prof);
 		} else
 			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
-		if (phase_events) HIP_TRY(hipEventRecord(ev[3], c->stream));
-		timed_commit = phase_events;
+		if (sampled) HIP_TRY(hipEventRecord(ev[3], c->stream));
+		timed_commit = sampled;
 		HIP_TRY(hipGetLastError());
 	}
 	// serial chain over what is pending in the id range of the window (k_chain); timed with the commit phase
@@ -2385,10 +2392,9 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		st->big_arena.ensure(big_arena_bytes);
-		if (phase_events) HIP_TRY(hipEventRecord(ev[2], c->stream));
+		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 4;
 		k_chain<<<1, 64, 0, c->stream>>>(g, st->big_arena.as<uint8_t>(), big_arena_bytes, nwin, prof);
-		if (phase_events) HIP_TRY(hipEventRecord(ev[3], c->stream));
-		timed_commit = phase_events;
+		timed_commit = false;
 		HIP_TRY(hipGetLastError());
 		return true;
 	}
@@ -2397,7 +2403,7 @@ struct DeviceBackend {
 		read_ctr();
 		if (sel_pending) sel_ready = true;                          // the snapshot holds the selection launched before it as well
 		float ms = 0;
-		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_ms += ms; timed_commit = false; }
+		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_event_ms += ms; commit_event_launches++; timed_commit = false; }
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
 		return r;
@@ -2629,6 +2635,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.optimistic = optimistic;
+	be.ev_phase = c->stage_seq++;
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {
 		unsigned long long z[64] = {0};
@@ -2726,6 +2733,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	c->stats.total_ms = ms_enum + ms_simp + ms_copy;
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
+	c->stats.commit_event_ms = be.commit_event_ms; c->stats.commit_event_launches = be.commit_event_launches;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
 	if (be.prof) {
 		unsigned long long z[16];
