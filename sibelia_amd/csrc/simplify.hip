@@ -978,10 +978,11 @@ __device__ __forceinline__ unsigned wave_walk_marks(const GraphView &g, unsigned
 		bool inr = done + lane < maxcount && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
 		// all loads of the step are issued together (speculatively for lanes past a link break): one memory round trip per 64 elements
-		unsigned plink = inr && lane ? (dir ? g.pv[c + 1] : g.nx[c - 1]) : c;
 		unsigned chv = inr ? g.ch[c] : 0u;
 		unsigned b0 = inr && (strands & 1u) ? g.bif[0][c] : BT_NONE, b1 = inr && (strands & 2u) ? g.bif[1][c] : BT_NONE;
 		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
+		const unsigned lprev = __shfl_up(lnk, 1);                        // the previous element's link is what the lane before loaded
+		unsigned plink = inr && lane ? lprev : c;
 		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);      // intact prefix, >= 1
 		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
@@ -1006,12 +1007,12 @@ __device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca
 		const bool ina = aa && da + lane < na && (dira ? lane <= ca : (unsigned long long)ca + lane < g.cap_e);
 		const bool inb = ab && db + lane < nb && (dirb ? lane <= cb : (unsigned long long)cb + lane < g.cap_e);
 		const unsigned xa = dira ? ca - lane : ca + lane, xb = dirb ? cb - lane : cb + lane;
-		const unsigned pla = ina && lane ? (dira ? g.pv[xa + 1] : g.nx[xa - 1]) : xa;
-		const unsigned plb = inb && lane ? (dirb ? g.pv[xb + 1] : g.nx[xb - 1]) : xb;
 		const unsigned cha = ina ? g.ch[xa] : 0u, chb = inb ? g.ch[xb] : 0u;
 		const unsigned a0 = ina && (sa & 1u) ? g.bif[0][xa] : BT_NONE, a1 = ina && (sa & 2u) ? g.bif[1][xa] : BT_NONE;
 		const unsigned b0 = inb && (sb & 1u) ? g.bif[0][xb] : BT_NONE, b1 = inb && (sb & 2u) ? g.bif[1][xb] : BT_NONE;
 		const unsigned lka = ina ? (dira ? g.pv[xa] : g.nx[xa]) : BT_NONE, lkb = inb ? (dirb ? g.pv[xb] : g.nx[xb]) : BT_NONE;
+		const unsigned lpa = __shfl_up(lka, 1), lpb = __shfl_up(lkb, 1);      // previous links: what the lanes before loaded
+		const unsigned pla = ina && lane ? lpa : xa, plb = inb && lane ? lpb : xb;
 		if (aa) {
 			unsigned long long ml = __ballot(ina && pla == xa);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
@@ -1103,10 +1104,11 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 	while (done < nreg && cur != BT_NONE) {
 		bool inr = done + lane < nreg && (d ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = d ? cur - lane : cur + lane;
-		unsigned plink = inr && lane ? (d ? g.pv[c + 1] : g.nx[c - 1]) : c;
 		unsigned chv = inr ? g.ch[c] : 0u;
 		unsigned b0 = inr ? g.bif[0][c] : BT_NONE, b1 = inr ? g.bif[1][c] : BT_NONE;
 		unsigned lnk = inr ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
+		const unsigned lprev = __shfl_up(lnk, 1);
+		unsigned plink = inr && lane ? lprev : c;
 		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
 		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
@@ -1135,11 +1137,11 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 		bool inu = au && du + lane < reach && (diru ? lane <= cu : (unsigned long long)cu + lane < g.cap_e);
 		bool ind = ad && dd + lane < reach && (dird ? lane <= cd : (unsigned long long)cd + lane < g.cap_e);
 		unsigned xu = diru ? cu - lane : cu + lane, xd = dird ? cd - lane : cd + lane;
-		unsigned plu = inu && lane ? (diru ? g.pv[xu + 1] : g.nx[xu - 1]) : xu;
-		unsigned pld = ind && lane ? (dird ? g.pv[xd + 1] : g.nx[xd - 1]) : xd;
 		unsigned chu = inu ? g.ch[xu] : 0u, chd = ind ? g.ch[xd] : 0u;
 		unsigned bu = inu ? g.bif[d][xu] : BT_NONE, bd = ind ? g.bif[d ^ 1u][xd] : BT_NONE;
 		unsigned lku = inu ? (diru ? g.pv[xu] : g.nx[xu]) : BT_NONE, lkd = ind ? (dird ? g.pv[xd] : g.nx[xd]) : BT_NONE;
+		const unsigned lpu = __shfl_up(lku, 1), lpd = __shfl_up(lkd, 1);
+		unsigned plu = inu && lane ? lpu : xu, pld = ind && lane ? lpd : xd;
 		if (au) {
 			unsigned long long ml = __ballot(inu && plu == xu);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
