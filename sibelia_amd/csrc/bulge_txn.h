@@ -64,6 +64,9 @@ struct GraphView {
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
 	// start stamps of the round kernels (device wall clock; simplify.hip: DeviceBackend::stamp_*): 4 slots per round, nullptr = off
 	unsigned long long *tstamp; uint32_t tslot;
+	// the separators' slots (ascending; they never move during a stage) and the number of original slots: a walk that starts at an
+	// original slot recognises the separators of its chromosome by their slot instead of loading characters (simplify.hip: SepBounds)
+	const uint32_t *sep; uint32_t nsep, norig;
 };
 
 // ------------------------------------------------------------------------------------------- atomics (host + device)

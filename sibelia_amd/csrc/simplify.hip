@@ -967,25 +967,45 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
 #define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
 struct ClaimList { unsigned *buf; unsigned *n; unsigned *seen; };      // n: LDS counter shared by the waves of the workgroup
 
+// Separators by SLOT.  A walk stops before a separator; it used to recognise one by its character -- a load of its own per element
+// (one in four or five of a neighbourhood walk's loads, and what a round kernel costs is the number of memory instructions it issues).
+// Separators never move during a stage and a walk never leaves its chromosome, so the only separators it can meet are the two that
+// bound the chromosome of its first element: two compares.  Valid for walks that start at an ORIGINAL slot (the chromosome of a freshly
+// inserted element is not known without looking) with at most 64 separators (one lane each); otherwise by == false and the character
+// is loaded as before.
+struct SepBounds { unsigned lo, hi; bool by; };
+__device__ __forceinline__ SepBounds sep_bounds(const GraphView &g, const unsigned *s_sep /* LDS copy of g.sep, 64 entries, padded with BT_NONE */, unsigned e0, unsigned lane)
+{
+	SepBounds r; r.lo = r.hi = BT_NONE; r.by = false;
+	if (!s_sep || e0 >= g.norig) return r;
+	const unsigned sv = s_sep[lane];
+	const unsigned long long le = __ballot(sv <= e0), ge = __ballot(sv != BT_NONE && sv >= e0);
+	if (!le || !ge) return r;
+	r.lo = __shfl(sv, 63 - (unsigned)__builtin_clzll(le));
+	r.hi = __shfl(sv, (unsigned)__builtin_ctzll(ge));
+	r.by = true;
+	return r;
+}
+
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
 template <class F>
 __device__ __forceinline__ unsigned wave_walk_marks(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
-                                                   unsigned strands /* bit s: report marks of strand s */, F f)
+                                                   unsigned strands /* bit s: report marks of strand s */, F f, const SepBounds sb = SepBounds{BT_NONE, BT_NONE, false})
 {
 	unsigned cur = first, done = 0;
 	while (done < maxcount && cur != BT_NONE) {
 		bool inr = done + lane < maxcount && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = dir ? cur - lane : cur + lane;
 		// all loads of the step are issued together (speculatively for lanes past a link break): one memory round trip per 64 elements
-		unsigned chv = inr ? g.ch[c] : 0u;
+		unsigned chv = inr && !sb.by ? g.ch[c] : 0u;
 		unsigned b0 = inr && (strands & 1u) ? g.bif[0][c] : BT_NONE, b1 = inr && (strands & 2u) ? g.bif[1][c] : BT_NONE;
 		unsigned lnk = inr ? (dir ? g.pv[c] : g.nx[c]) : BT_NONE;
 		const unsigned lprev = __shfl_up(lnk, 1);                        // the previous element's link is what the lane before loaded
 		unsigned plink = inr && lane ? lprev : c;
 		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);      // intact prefix, >= 1
-		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
+		unsigned long long ms = __ballot(lane < pre && (sb.by ? (c == sb.lo || c == sb.hi) : chv == BT_SEP));
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;                // first separator inside the prefix
 		bool proc = lane < pre && lane < stop;
 		f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
@@ -999,7 +1019,8 @@ __device__ __forceinline__ unsigned wave_walk_marks(const GraphView &g, unsigned
 // Two independent walks advancing together (one memory round trip serves both): same visiting rules as wave_walk_marks.
 template <class F>
 __device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca, unsigned dira, unsigned na, unsigned sa,
-                                                 unsigned cb, unsigned dirb, unsigned nb, unsigned sb, unsigned lane, F f)
+                                                 unsigned cb, unsigned dirb, unsigned nb, unsigned sb, unsigned lane, F f,
+                                                 const SepBounds sp = SepBounds{BT_NONE, BT_NONE, false})
 {
 	unsigned da = 0, db = 0;
 	while ((da < na && ca != BT_NONE) || (db < nb && cb != BT_NONE)) {
@@ -1007,16 +1028,17 @@ __device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca
 		const bool ina = aa && da + lane < na && (dira ? lane <= ca : (unsigned long long)ca + lane < g.cap_e);
 		const bool inb = ab && db + lane < nb && (dirb ? lane <= cb : (unsigned long long)cb + lane < g.cap_e);
 		const unsigned xa = dira ? ca - lane : ca + lane, xb = dirb ? cb - lane : cb + lane;
-		const unsigned cha = ina ? g.ch[xa] : 0u, chb = inb ? g.ch[xb] : 0u;
+		const unsigned cha = ina && !sp.by ? g.ch[xa] : 0u, chb = inb && !sp.by ? g.ch[xb] : 0u;
 		const unsigned a0 = ina && (sa & 1u) ? g.bif[0][xa] : BT_NONE, a1 = ina && (sa & 2u) ? g.bif[1][xa] : BT_NONE;
 		const unsigned b0 = inb && (sb & 1u) ? g.bif[0][xb] : BT_NONE, b1 = inb && (sb & 2u) ? g.bif[1][xb] : BT_NONE;
 		const unsigned lka = ina ? (dira ? g.pv[xa] : g.nx[xa]) : BT_NONE, lkb = inb ? (dirb ? g.pv[xb] : g.nx[xb]) : BT_NONE;
 		const unsigned lpa = __shfl_up(lka, 1), lpb = __shfl_up(lkb, 1);      // previous links: what the lanes before loaded
 		const unsigned pla = ina && lane ? lpa : xa, plb = inb && lane ? lpb : xb;
+		const bool sepa = sp.by ? (xa == sp.lo || xa == sp.hi) : cha == BT_SEP, sepb = sp.by ? (xb == sp.lo || xb == sp.hi) : chb == BT_SEP;
 		if (aa) {
 			unsigned long long ml = __ballot(ina && pla == xa);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-			unsigned long long ms = __ballot(lane < pre && cha == BT_SEP);
+			unsigned long long ms = __ballot(lane < pre && sepa);
 			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 			bool proc = lane < pre && lane < stop;
 			f(proc ? a0 : BT_NONE, proc ? a1 : BT_NONE);
@@ -1025,7 +1047,7 @@ __device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca
 		if (ab) {
 			unsigned long long ml = __ballot(inb && plb == xb);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-			unsigned long long ms = __ballot(lane < pre && chb == BT_SEP);
+			unsigned long long ms = __ballot(lane < pre && sepb);
 			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 			bool proc = lane < pre && lane < stop;
 			f(proc ? b0 : BT_NONE, proc ? b1 : BT_NONE);
@@ -1083,9 +1105,9 @@ __device__ __forceinline__ void wave_claim_order(const GraphView &g, ClaimList &
 }
 
 __device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned first, unsigned dir, unsigned maxcount, unsigned lane,
-                                                    unsigned strands, ClaimList &cl, unsigned st)
+                                                    unsigned strands, ClaimList &cl, unsigned st, const SepBounds sb = SepBounds{BT_NONE, BT_NONE, false})
 {
-	return wave_walk_marks(g, first, dir, maxcount, lane, strands, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); });
+	return wave_walk_marks(g, first, dir, maxcount, lane, strands, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); }, sb);
 }
 
 // After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
@@ -1173,6 +1195,9 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 	__shared__ unsigned seen[SEEN_SLOTS];
 	__shared__ unsigned resume[RESUME_SLOTS], inst[RESUME_SLOTS];     // per instance: end of the core walk; (element << 1) | strand
 	__shared__ unsigned nclaims, ninst_s;
+	__shared__ unsigned s_sep[64];                                     // the separators' slots (see SepBounds), when there are at most 64
+	const unsigned *sepl = g.sep && g.nsep <= 64 ? s_sep : nullptr;
+	if (sepl && threadIdx.x < 64) s_sep[threadIdx.x] = threadIdx.x < g.nsep ? g.sep[threadIdx.x] : BT_NONE;
 	for (unsigned i = threadIdx.x; i < SEEN_SLOTS; i += 64 * RSV_WAVES) seen[i] = BT_NONE;
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
@@ -1195,15 +1220,15 @@ __global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigne
 	const unsigned ninst = ninst_s;
 	if (ninst <= RESUME_SLOTS) {
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
-			unsigned nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st);
+			unsigned nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st, sep_bounds(g, sepl, inst[i] >> 1, lane));
 			if (lane == 0) resume[i] = nxt;
 		}
 		__syncthreads();
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {
 			const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
-			// further downstream (opposite strand) and upstream (same strand) together
+			// further downstream (opposite strand) and upstream (same strand) together; all three walks of an instance stay in its chromosome
 			wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
-			                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order);
+			                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sep_bounds(g, sepl, e0, lane));
 		}
 	} else {                                                          // more instances than the LDS list holds: walk the node lists
 		unsigned k1 = 0;
@@ -2648,6 +2673,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	be.bind();
 	be.g.k = k; be.g.D = D;
 	be.g.tstamp = nullptr; be.g.tslot = 0;
+	be.g.sep = c->d_sepidx.as<unsigned>(); be.g.nsep = c->nchr + 1; be.g.norig = (uint32_t)E;
+	if (getenv("SBL_SEP_BY_CHAR")) be.g.sep = nullptr;                   // measurement switch: separators recognised by their character everywhere
 	if (!dense && be.phase_events) be.stamps_init();
 	HIP_TRY(hipEventRecord(c->ev[3], s));
 
