@@ -108,6 +108,26 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 }
 
 // ------------------------------------------------------------------------------------------- SimplifyGraph kernels
+// Separators by SLOT.  A walk stops before a separator; it used to recognise one by its character -- a load of its own per element
+// (one in four or five of a neighbourhood walk's loads, and what a round kernel costs is the number of memory instructions it issues).
+// Separators never move during a stage and a walk never leaves its chromosome, so the only separators it can meet are the two that
+// bound the chromosome of its first element: two compares.  Valid for walks that start at an ORIGINAL slot (the chromosome of a freshly
+// inserted element is not known without looking) with at most 64 separators (one lane each); otherwise by == false and the character
+// is loaded as before.
+struct SepBounds { unsigned lo, hi; bool by; };
+__device__ __forceinline__ SepBounds sep_bounds(const GraphView &g, const unsigned *s_sep /* LDS copy of g.sep, 64 entries, padded with BT_NONE */, unsigned e0, unsigned lane)
+{
+	SepBounds r; r.lo = r.hi = BT_NONE; r.by = false;
+	if (!s_sep || e0 >= g.norig) return r;
+	const unsigned sv = s_sep[lane];
+	const unsigned long long le = __ballot(sv <= e0), ge = __ballot(sv != BT_NONE && sv >= e0);
+	if (!le || !ge) return r;
+	r.lo = __shfl(sv, 63 - (unsigned)__builtin_clzll(le));
+	r.hi = __shfl(sv, (unsigned)__builtin_ctzll(ge));
+	r.by = true;
+	return r;
+}
+
 // Start stamp of a round kernel: the first workgroup writes the device wall clock (constant rate, hipDeviceAttributeWallClockRate) into
 // the round's slot.  The kernels of a stream run back to back, so the difference of two consecutive start stamps is what a kernel cost,
 // launch gap included -- per-kernel times of every round for one 8-byte store each, where an event pair around a kernel costs ~8 us of
@@ -211,9 +231,11 @@ enum { SCAN_BURST = 3 };
 // the bursts of a whole batch of windows are in flight together (one memory round trip per SCAN_BATCH windows).
 struct ScanBurst { unsigned chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; unsigned cur, done; };
 struct ScanView { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; bool inr[SCAN_BURST]; };
-__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
+// CH0: characters of the first block only (a probe whose separators are recognised by their slot needs one character per window, the
+// one at step k < 64)
+template <bool CH0>
+__device__ __forceinline__ void scan_burst_load_t(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b)
 {
-	(void)mode;
 	b.cur = cur; b.done = done;
 	const unsigned *__restrict__ link = dir ? g.pv : g.nx, *__restrict__ mark = g.bif[dir];
 #pragma unroll
@@ -221,11 +243,16 @@ __device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur
 		const unsigned off = lane + 64u * u;
 		const bool inr = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
 		const unsigned x = inr ? (dir ? cur - off : cur + off) : cur;
-		b.chv[u] = g.ch[x];
+		b.chv[u] = !CH0 || u == 0 ? g.ch[x] : 0u;
 		b.bvl[u] = mark[x];
 		b.lnk[u] = link[x];
 		b.wmv[u] = g.wmax[x >> BT_BLOCK_SHIFT];
 	}
+}
+__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
+{
+	(void)mode;
+	scan_burst_load_t<false>(g, cur, dir, done, ws, lane, b);
 }
 // the burst as its consumers see it (the values scan_burst_load used to produce directly)
 __device__ __forceinline__ void burst_view(const GraphView &g, const ScanBurst &b, unsigned dir, unsigned ws, unsigned lane, unsigned mode, ScanView &v)
@@ -686,9 +713,13 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 // k), the marked steps before the window's end and before the instance's own id recurs.  Returns 1 (some id is now reached by two
 // instances with different endChars), 0, -1 (the table could fill up), -2 (a link break inside the window, k or D beyond the burst:
 // the generic pair of functions takes this window).
+// CH0: the burst holds the characters of its first block only and the separators are recognised by their slot (sp; a window whose
+// bounds are unknown -- its instance sits on an inserted element -- goes to the generic pair); the caller guarantees k < 64
+template <bool CH0>
 __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanBurst &raw, unsigned dir, unsigned ws, VerdictTable &vt, unsigned lane,
-                                                 unsigned id, unsigned tid, unsigned &distinct)
+                                                 unsigned id, unsigned tid, unsigned &distinct, const SepBounds sp)
 {
+	if (CH0 && !sp.by) return -2;
 	ScanView b;
 	burst_view(g, raw, dir, ws, lane, 3u, b);
 	const unsigned k = g.k, D = g.D;
@@ -696,7 +727,8 @@ __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanB
 	unsigned firstbad = ~0u, firstsep = ~0u;
 #pragma unroll
 	for (int u = 0; u < SCAN_BURST; u++) {
-		const unsigned long long in = __ballot(b.inr[u]), good = __ballot(b.inr[u] && b.plink[u] == b.cc[u]), sep = __ballot(b.inr[u] && b.chv[u] == BT_SEP);
+		const unsigned long long in = __ballot(b.inr[u]), good = __ballot(b.inr[u] && b.plink[u] == b.cc[u]);
+		const unsigned long long sep = __ballot(b.inr[u] && (CH0 ? (b.cc[u] == sp.lo || b.cc[u] == sp.hi) : b.chv[u] == BT_SEP));
 		const unsigned long long bad = in & ~good;
 		if (bad && firstbad == ~0u) firstbad = 64u * u + (unsigned)__builtin_ctzll(bad);
 		if (sep && firstsep == ~0u) firstsep = 64u * u + (unsigned)__builtin_ctzll(sep);
@@ -767,9 +799,44 @@ __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanB
 
 // Probe of the window entries between rounds (no writer runs): entries whose AnyBulges verdict is false NOW are retired
 // without reservation (ss_probe); the others are flagged live and go through reserve / commit.
+// The windows of a probed id, PROBE_BATCH at a time: the first bursts of a batch are in flight together (see ScanBurst / wave_scan_all)
+// and their marks go straight into the verdict table -- an entry that IS live stops at the first id two instances with different endChars
+// reach, without scanning the rest.  Returns the verdict (1 / 0; -1: undecided by the table).
 #ifndef PROBE_BATCH
 #define PROBE_BATCH 4
 #endif
+template <bool CH0>
+__device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, VerdictTable &vt, unsigned lane, unsigned id, unsigned tid, const unsigned *sepl)
+{
+	int verdict = 0;
+	unsigned distinct = 0;
+	const unsigned n = w.n, ws = w.ws;
+	for (unsigned i = 0; i < n && verdict == 0; i += PROBE_BATCH) {
+		unsigned sel[PROBE_BATCH], dir[PROBE_BATCH];
+		ScanBurst b[PROBE_BATCH];
+#pragma unroll
+		for (int j = 0; j < PROBE_BATCH; j++) {
+			const unsigned x = i + j < n ? i + j : i;
+			sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u;
+		}
+#pragma unroll
+		for (int j = 0; j < PROBE_BATCH; j++) scan_burst_load_t<CH0>(g, sel[j], dir[j], 0, ws, lane, b[j]);
+#pragma unroll
+		for (int j = 0; j < PROBE_BATCH; j++) {
+			if (i + j >= n) break;
+			int v = wave_probe_window<CH0>(g, b[j], dir[j], ws, vt, lane, id, tid, distinct, CH0 ? sep_bounds(g, sepl, sel[j], lane) : SepBounds{BT_NONE, BT_NONE, false});
+			if (v == -2) {                                                  // a link break inside the window (an earlier collapse), or no bounds: the generic pair
+				if (CH0) wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id); else wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id, &b[j]);
+				__syncthreads();
+				if (w.mk_overflow) return -1;                               // more marks than the LDS list holds: the generic path decides
+				v = wave_verdict_instance(g, w, vt, lane, i + j, distinct);
+			}
+			if ((verdict = v) != 0) break;
+		}
+	}
+	return verdict;
+}
+
 #define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
 __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
 {
@@ -792,35 +859,9 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	// an entry that IS live stops at the first id two instances with different endChars reach, without scanning the rest
 	int verdict = 0;
 	if (ok) {
-		unsigned distinct = 0;
-		// the first bursts of PROBE_BATCH windows are in flight together (see ScanBurst / wave_scan_all)
-		const unsigned n = w.n, ws = w.ws;
-		auto step = [&](unsigned i, unsigned dir, const ScanBurst &b) __attribute__((always_inline)) -> int {
-			int v = wave_probe_window(g, b, dir, ws, vt, lane, id, tid, distinct);
-			if (v == -2) {                                                  // a link break inside the window (an earlier collapse): the generic pair
-				wave_scan_instance(g, w, i, lane, 0, tid, 3, id, &b);
-				__syncthreads();
-				if (w.mk_overflow) return -1;                               // more marks than the LDS list holds: the generic path below decides
-				v = wave_verdict_instance(g, w, vt, lane, i, distinct);
-			}
-			return v;
-		};
-		for (unsigned i = 0; i < n && verdict == 0; i += PROBE_BATCH) {
-			unsigned sel[PROBE_BATCH], dir[PROBE_BATCH];
-			ScanBurst b[PROBE_BATCH];
-#pragma unroll
-			for (int j = 0; j < PROBE_BATCH; j++) {
-				const unsigned x = i + j < n ? i + j : i;
-				sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u;
-			}
-#pragma unroll
-			for (int j = 0; j < PROBE_BATCH; j++) scan_burst_load(g, sel[j], dir[j], 0, ws, lane, b[j], 3u);
-#pragma unroll
-			for (int j = 0; j < PROBE_BATCH; j++) {
-				if (i + j >= n) break;
-				if ((verdict = step(i + j, dir[j], b[j])) != 0) break;
-			}
-		}
+		// (probe_windows<true> -- one character per window, separators by slot: two loads in twelve less -- was measured 0.9 ms SLOWER per
+		// stage: the probe is issue-bound, and the bounds of every window cost more instructions than its two 64-byte loads)
+		verdict = probe_windows<false>(g, w, vt, lane, id, tid, nullptr);
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
 			__syncthreads();
@@ -967,26 +1008,6 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
 #define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
 struct ClaimList { unsigned *buf; unsigned *n; unsigned *seen; };      // n: LDS counter shared by the waves of the workgroup
 
-// Separators by SLOT.  A walk stops before a separator; it used to recognise one by its character -- a load of its own per element
-// (one in four or five of a neighbourhood walk's loads, and what a round kernel costs is the number of memory instructions it issues).
-// Separators never move during a stage and a walk never leaves its chromosome, so the only separators it can meet are the two that
-// bound the chromosome of its first element: two compares.  Valid for walks that start at an ORIGINAL slot (the chromosome of a freshly
-// inserted element is not known without looking) with at most 64 separators (one lane each); otherwise by == false and the character
-// is loaded as before.
-struct SepBounds { unsigned lo, hi; bool by; };
-__device__ __forceinline__ SepBounds sep_bounds(const GraphView &g, const unsigned *s_sep /* LDS copy of g.sep, 64 entries, padded with BT_NONE */, unsigned e0, unsigned lane)
-{
-	SepBounds r; r.lo = r.hi = BT_NONE; r.by = false;
-	if (!s_sep || e0 >= g.norig) return r;
-	const unsigned sv = s_sep[lane];
-	const unsigned long long le = __ballot(sv <= e0), ge = __ballot(sv != BT_NONE && sv >= e0);
-	if (!le || !ge) return r;
-	r.lo = __shfl(sv, 63 - (unsigned)__builtin_clzll(le));
-	r.hi = __shfl(sv, (unsigned)__builtin_ctzll(ge));
-	r.by = true;
-	return r;
-}
-
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
 template <class F>
@@ -1116,8 +1137,9 @@ __device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned
 // 64 lanes).  Only instances walking TOWARDS the region can see it: upstream that is the target's own strand, beyond the
 // end of the region the opposite strand, inside it both.  The region is walked once (write stamps on its first
 // newlen + 2k elements, pushes on newlen + 2k + 1), then the upstream and the downstream walk advance together.
-__device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane)
+__device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsigned id, unsigned e, unsigned d, unsigned newlen, unsigned lane, const unsigned *sepl = nullptr)
 {
+	const SepBounds sp = sep_bounds(g, sepl, e, lane);                      // the region and both walks stay in the chromosome of e
 	const unsigned reach = g.D + g.k + 2, tid = id + 1, nstamp = newlen + 2 * g.k, nreg = nstamp + 1;
 	auto push1 = [&](unsigned b) { if (b != BT_NONE && b < g.nid) { g.touch[b] = 1; if (b > id) g.need[b] = 1; } };
 	// ---- the region
@@ -1126,14 +1148,14 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 	while (done < nreg && cur != BT_NONE) {
 		bool inr = done + lane < nreg && (d ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
 		unsigned c = d ? cur - lane : cur + lane;
-		unsigned chv = inr ? g.ch[c] : 0u;
+		unsigned chv = inr && !sp.by ? g.ch[c] : 0u;
 		unsigned b0 = inr ? g.bif[0][c] : BT_NONE, b1 = inr ? g.bif[1][c] : BT_NONE;
 		unsigned lnk = inr ? (d ? g.pv[c] : g.nx[c]) : BT_NONE;
 		const unsigned lprev = __shfl_up(lnk, 1);
 		unsigned plink = inr && lane ? lprev : c;
 		unsigned long long ml = __ballot(inr && plink == c);
 		unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-		unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
+		unsigned long long ms = __ballot(lane < pre && (sp.by ? (c == sp.lo || c == sp.hi) : chv == BT_SEP));
 		unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 		if (lane < pre && lane < stop) {
 			push1(b0); push1(b1);
@@ -1159,7 +1181,8 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 		bool inu = au && du + lane < reach && (diru ? lane <= cu : (unsigned long long)cu + lane < g.cap_e);
 		bool ind = ad && dd + lane < reach && (dird ? lane <= cd : (unsigned long long)cd + lane < g.cap_e);
 		unsigned xu = diru ? cu - lane : cu + lane, xd = dird ? cd - lane : cd + lane;
-		unsigned chu = inu ? g.ch[xu] : 0u, chd = ind ? g.ch[xd] : 0u;
+		unsigned chu = inu && !sp.by ? g.ch[xu] : 0u, chd = ind && !sp.by ? g.ch[xd] : 0u;
+		const bool sepu = sp.by ? (xu == sp.lo || xu == sp.hi) : chu == BT_SEP, sepd = sp.by ? (xd == sp.lo || xd == sp.hi) : chd == BT_SEP;
 		unsigned bu = inu ? g.bif[d][xu] : BT_NONE, bd = ind ? g.bif[d ^ 1u][xd] : BT_NONE;
 		unsigned lku = inu ? (diru ? g.pv[xu] : g.nx[xu]) : BT_NONE, lkd = ind ? (dird ? g.pv[xd] : g.nx[xd]) : BT_NONE;
 		const unsigned lpu = __shfl_up(lku, 1), lpd = __shfl_up(lkd, 1);
@@ -1167,7 +1190,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 		if (au) {
 			unsigned long long ml = __ballot(inu && plu == xu);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-			unsigned long long ms = __ballot(lane < pre && chu == BT_SEP);
+			unsigned long long ms = __ballot(lane < pre && sepu);
 			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 			if (lane < pre && lane < stop) push1(bu);
 			if (stop < pre || pre == 0) cu = BT_NONE; else { cu = __shfl(lku, pre - 1); du += pre; }
@@ -1175,7 +1198,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 		if (ad) {
 			unsigned long long ml = __ballot(ind && pld == xd);
 			unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);
-			unsigned long long ms = __ballot(lane < pre && chd == BT_SEP);
+			unsigned long long ms = __ballot(lane < pre && sepd);
 			unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
 			if (lane < pre && lane < stop) push1(bd);
 			if (stop < pre || pre == 0) cd = BT_NONE; else { cd = __shfl(lkd, pre - 1); dd += pre; }
@@ -1682,7 +1705,8 @@ __device__ unsigned long long g_txn_max[2];        // longest transaction: cycle
 // solo: 0 = ordered round (the probe found bulges, the entry owns its claims), 1 = the id runs with nothing else in flight
 // (big-arena solo round, or the serial chain: stampv == BT_NONE, no reservation exists and none is checked).
 __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWork &w, int &flag, ABShared &absh, uint8_t *fast, unsigned fast_bytes,
-                                            unsigned wi, unsigned id, unsigned stampv, int solo, bool prepass, uint8_t *mine, unsigned arena_bytes, int prof)
+                                            unsigned wi, unsigned id, unsigned stampv, int solo, bool prepass, uint8_t *mine, unsigned arena_bytes, int prof,
+                                            const unsigned *sepl = nullptr /* LDS copy of the separators' slots (SepBounds), or none */)
 {
 	const unsigned lane = threadIdx.x, tid = id + 1;
 	PH_T0();
@@ -1750,7 +1774,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				wave_collapse(g, t, w, lane, stampv);
 				PH_ADD(5);
 				if (t.err) break;
-				wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane);
+				wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
 				if (lane == 0) w.epoch++;                                // every cached window is stale until the loops ask for it
 				__syncthreads();
 				PH_ADD(6);
@@ -1789,7 +1813,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 					}
 				if (escape && !solo) { g.big[id] = 1; atomicMin(&g.ctr[CTR_VIOL], id); }     // replay with this id running alone
 			}
-			wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane);
+			wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
 			PH_ADD(6);
 			PH_ADD(7);
 			for (unsigned i = 0; i < w.n; i++)
@@ -1858,7 +1882,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		}
 		if (!owner) return;                                       // stays pending
 	}
-	commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)wi * arena_bytes, arena_bytes, prof);
+	__shared__ unsigned s_sep[64];                                    // the separators' slots (SepBounds), when there are at most 64
+	const unsigned *sepl = g.sep && g.nsep <= 64 ? s_sep : nullptr;
+	if (sepl) s_sep[lane] = lane < g.nsep ? g.sep[lane] : BT_NONE;
+	commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)wi * arena_bytes, arena_bytes, prof, sepl);
 }
 
 // Serial chain: one wave runs what is pending in the id range of the window strictly in ascending order, one transaction
