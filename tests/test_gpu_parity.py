@@ -155,6 +155,29 @@ def test_progress_callback_contract():
     assert runs == sorted(runs) and all(1 <= p <= 50 for p in runs)
 
 
+def test_round_kernel_times_from_stamps_and_sampled_events_agree():
+    """probe / reserve / commit times of a stage come from start stamps the round kernels write themselves (every launch); HIP event
+    pairs are recorded around every 4th launch of the commit kernel only.  Both must be there and tell the same story."""
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=400_000, n=8, seed=4, inv_min=3000, inv_max=12000)
+    bf = _bf(seqs)
+    try:
+        bf.save_state()
+        ev_ms = ev_n = clock_ms = rounds = 0.0
+        for _ in range(4):                                   # the sampled launches rotate from stage to stage
+            bf.restore_state()
+            bf.PerformGraphSimplifications(25, 150, 4)
+            st = bf.stats()
+            assert st["rounds"] > 8 and st["probe_ms"] > 0 and st["reserve_ms"] > 0 and st["commit_ms"] > 0
+            assert st["probe_ms"] + st["reserve_ms"] + st["commit_ms"] < st["simplify_ms"]
+            ev_ms += st["commit_event_ms"]; ev_n += st["commit_event_launches"]; clock_ms += st["commit_ms"]; rounds += st["rounds"]
+        assert rounds / 4 - 16 <= ev_n <= rounds / 4 + 16    # every 4th launch of every iteration of four stages
+        a, b = ev_ms / ev_n, clock_ms / rounds
+        assert abs(a - b) < 0.25 * b, (a, b)
+    finally:
+        bf.close()
+
+
 def test_errors_cross_the_abi_as_codes():
     from sibelia_amd import SibeliaError
     bf = _bf([b"ACGTACGTAC"])
