@@ -231,11 +231,9 @@ enum { SCAN_BURST = 3 };
 // the bursts of a whole batch of windows are in flight together (one memory round trip per SCAN_BATCH windows).
 struct ScanBurst { unsigned chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; unsigned cur, done; };
 struct ScanView { unsigned cc[SCAN_BURST], plink[SCAN_BURST], chv[SCAN_BURST], bvl[SCAN_BURST], lnk[SCAN_BURST], wmv[SCAN_BURST]; bool inr[SCAN_BURST]; };
-// CH0: characters of the first block only (a probe whose separators are recognised by their slot needs one character per window, the
-// one at step k < 64)
-template <bool CH0>
-__device__ __forceinline__ void scan_burst_load_t(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b)
+__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
 {
+	(void)mode;
 	b.cur = cur; b.done = done;
 	const unsigned *__restrict__ link = dir ? g.pv : g.nx, *__restrict__ mark = g.bif[dir];
 #pragma unroll
@@ -243,16 +241,11 @@ __device__ __forceinline__ void scan_burst_load_t(const GraphView &g, unsigned c
 		const unsigned off = lane + 64u * u;
 		const bool inr = done + off < ws && (dir ? off <= cur : (unsigned long long)cur + off < g.cap_e);
 		const unsigned x = inr ? (dir ? cur - off : cur + off) : cur;
-		b.chv[u] = !CH0 || u == 0 ? g.ch[x] : 0u;
+		b.chv[u] = g.ch[x];
 		b.bvl[u] = mark[x];
 		b.lnk[u] = link[x];
 		b.wmv[u] = g.wmax[x >> BT_BLOCK_SHIFT];
 	}
-}
-__device__ __forceinline__ void scan_burst_load(const GraphView &g, unsigned cur, unsigned dir, unsigned done, unsigned ws, unsigned lane, ScanBurst &b, unsigned mode = 0)
-{
-	(void)mode;
-	scan_burst_load_t<false>(g, cur, dir, done, ws, lane, b);
 }
 // the burst as its consumers see it (the values scan_burst_load used to produce directly)
 __device__ __forceinline__ void burst_view(const GraphView &g, const ScanBurst &b, unsigned dir, unsigned ws, unsigned lane, unsigned mode, ScanView &v)
@@ -713,13 +706,9 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 // k), the marked steps before the window's end and before the instance's own id recurs.  Returns 1 (some id is now reached by two
 // instances with different endChars), 0, -1 (the table could fill up), -2 (a link break inside the window, k or D beyond the burst:
 // the generic pair of functions takes this window).
-// CH0: the burst holds the characters of its first block only and the separators are recognised by their slot (sp; a window whose
-// bounds are unknown -- its instance sits on an inserted element -- goes to the generic pair); the caller guarantees k < 64
-template <bool CH0>
 __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanBurst &raw, unsigned dir, unsigned ws, VerdictTable &vt, unsigned lane,
-                                                 unsigned id, unsigned tid, unsigned &distinct, const SepBounds sp)
+                                                 unsigned id, unsigned tid, unsigned &distinct)
 {
-	if (CH0 && !sp.by) return -2;
 	ScanView b;
 	burst_view(g, raw, dir, ws, lane, 3u, b);
 	const unsigned k = g.k, D = g.D;
@@ -727,8 +716,7 @@ __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanB
 	unsigned firstbad = ~0u, firstsep = ~0u;
 #pragma unroll
 	for (int u = 0; u < SCAN_BURST; u++) {
-		const unsigned long long in = __ballot(b.inr[u]), good = __ballot(b.inr[u] && b.plink[u] == b.cc[u]);
-		const unsigned long long sep = __ballot(b.inr[u] && (CH0 ? (b.cc[u] == sp.lo || b.cc[u] == sp.hi) : b.chv[u] == BT_SEP));
+		const unsigned long long in = __ballot(b.inr[u]), good = __ballot(b.inr[u] && b.plink[u] == b.cc[u]), sep = __ballot(b.inr[u] && b.chv[u] == BT_SEP);
 		const unsigned long long bad = in & ~good;
 		if (bad && firstbad == ~0u) firstbad = 64u * u + (unsigned)__builtin_ctzll(bad);
 		if (sep && firstsep == ~0u) firstsep = 64u * u + (unsigned)__builtin_ctzll(sep);
@@ -805,8 +793,9 @@ __device__ __forceinline__ int wave_probe_window(const GraphView &g, const ScanB
 #ifndef PROBE_BATCH
 #define PROBE_BATCH 4
 #endif
-template <bool CH0>
-__device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, VerdictTable &vt, unsigned lane, unsigned id, unsigned tid, const unsigned *sepl)
+// (Recognising separators by their slot here as well -- one character per window instead of three loads -- was measured 0.9 ms SLOWER per
+// stage: the probe is issue-bound, and the bounds of every window cost more instructions than the two 64-byte loads they save.)
+__device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, VerdictTable &vt, unsigned lane, unsigned id, unsigned tid)
 {
 	int verdict = 0;
 	unsigned distinct = 0;
@@ -820,13 +809,13 @@ __device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, V
 			sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u;
 		}
 #pragma unroll
-		for (int j = 0; j < PROBE_BATCH; j++) scan_burst_load_t<CH0>(g, sel[j], dir[j], 0, ws, lane, b[j]);
+		for (int j = 0; j < PROBE_BATCH; j++) scan_burst_load(g, sel[j], dir[j], 0, ws, lane, b[j], 3u);
 #pragma unroll
 		for (int j = 0; j < PROBE_BATCH; j++) {
 			if (i + j >= n) break;
-			int v = wave_probe_window<CH0>(g, b[j], dir[j], ws, vt, lane, id, tid, distinct, CH0 ? sep_bounds(g, sepl, sel[j], lane) : SepBounds{BT_NONE, BT_NONE, false});
-			if (v == -2) {                                                  // a link break inside the window (an earlier collapse), or no bounds: the generic pair
-				if (CH0) wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id); else wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id, &b[j]);
+			int v = wave_probe_window(g, b[j], dir[j], ws, vt, lane, id, tid, distinct);
+			if (v == -2) {                                                  // a link break inside the window (an earlier collapse): the generic pair
+				wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id, &b[j]);
 				__syncthreads();
 				if (w.mk_overflow) return -1;                               // more marks than the LDS list holds: the generic path decides
 				v = wave_verdict_instance(g, w, vt, lane, i + j, distinct);
@@ -859,9 +848,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	// an entry that IS live stops at the first id two instances with different endChars reach, without scanning the rest
 	int verdict = 0;
 	if (ok) {
-		// (probe_windows<true> -- one character per window, separators by slot: two loads in twelve less -- was measured 0.9 ms SLOWER per
-		// stage: the probe is issue-bound, and the bounds of every window cost more instructions than its two 64-byte loads)
-		verdict = probe_windows<false>(g, w, vt, lane, id, tid, nullptr);
+		verdict = probe_windows(g, w, vt, lane, id, tid);
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
 			__syncthreads();
@@ -2666,7 +2653,9 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes)) & ~7u;   // a multiple of the 8 XCDs
 		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
 	}
-	uint32_t window = c->window ? c->window : std::min<uint32_t>(16384, std::max<uint32_t>(2048, be.nid_ / 64));
+	uint32_t base_window = 16384;
+	if (const char *e = getenv("SBL_BASE_WINDOW")) base_window = (uint32_t)std::max(64, atoi(e));      // measurement switch (tools/sweep_window.sh)
+	uint32_t window = c->window ? c->window : std::min<uint32_t>(base_window, std::max<uint32_t>(2048, be.nid_ / 64));
 	window = std::min<uint32_t>(window, (1u << 20) - 1);
 	window = (uint32_t)std::min<size_t>(window, std::max<size_t>(64, (24ull << 30) / be.arena_bytes));
 	window = std::max<uint32_t>(1, std::min<uint32_t>(window, be.nid_ ? be.nid_ : 1));
