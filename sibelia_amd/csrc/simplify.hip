@@ -1194,11 +1194,12 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 }
 
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
-#ifndef RSV_WAVES
-#define RSV_WAVES 4u                         // waves of a reservation workgroup: the instances of the id are dealt out to them
-#endif
-__global__ void __launch_bounds__(64 * RSV_WAVES) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
+// The instances of the id are dealt out to the waves of the workgroup (blockDim.x / 64 of them: two where ids have a handful of
+// instances -- 8 strains: 85.0 ms per stage against 86.1 with four and 88.8 with eight -- four where they have dozens, DeviceBackend::rsv_waves).
+#define RSV_WAVES_MAX 4u
+__global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
 {
+	const unsigned RSV_WAVES = blockDim.x >> 6;
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	round_stamp(g, 1);
 	if (w >= nwin || !live[w]) return;
@@ -2151,6 +2152,7 @@ struct DeviceBackend {
 	// roll-back the benchmark workloads never take).  An order violation or a pool overflow then abandons the attempt (RestartStage) and
 	// the stage is run again from its input -- intact until the copy-back -- with checkpoints and iteration replays (sbl_simplify_run).
 	bool optimistic = false;
+	unsigned rsv_waves = 4;                                           // waves of a reservation workgroup (k_reserve)
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 	double commit_event_ms = 0; uint64_t commit_event_launches = 0;      // the event pairs around every 4th launch of the commit kernel
 	unsigned ev_phase = 0;
@@ -2409,7 +2411,7 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 2;
-		k_reserve<<<nwin, 64 * RSV_WAVES, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
+		k_reserve<<<nwin, 64 * rsv_waves, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
 		HIP_TRY(hipGetLastError());
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
@@ -2653,7 +2655,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		be.snap_threads = (uint32_t)std::max<size_t>(256, std::min<size_t>(256 * 32, (16ull << 30) / be.arena_bytes)) & ~7u;   // a multiple of the 8 XCDs
 		be.big_arena_bytes = (uint32_t)std::min<size_t>(std::max<size_t>(256u << 20, 64 * be.arena_bytes), 0xFFFFFF00u);
 	}
-	uint32_t base_window = 16384;
+	uint32_t base_window = 14336;                                        // (swept again at the end of round 3: 86.1 ms against 86.9 ms at 16 384, 62 strains 4.12 against 4.19 s)
 	if (const char *e = getenv("SBL_BASE_WINDOW")) base_window = (uint32_t)std::max(64, atoi(e));      // measurement switch (tools/sweep_window.sh)
 	uint32_t window = c->window ? c->window : std::min<uint32_t>(base_window, std::max<uint32_t>(2048, be.nid_ / 64));
 	window = std::min<uint32_t>(window, (1u << 20) - 1);
@@ -2678,6 +2680,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
 	be.optimistic = optimistic;
+	be.rsv_waves = ninst > 12 * (size_t)std::max<uint32_t>(1, be.nid_) ? 4u : 2u;      // instances per id: a handful, or dozens (many strains)
+	if (const char *e = getenv("SBL_RSV_WAVES")) be.rsv_waves = (unsigned)std::min(4, std::max(1, atoi(e)));      // measurement switch
 	be.ev_phase = c->stage_seq++;
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {

@@ -64,6 +64,8 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 	if (window_max < window) window_max = window;
 	if (window_max > (1u << 20) - 1) window_max = (1u << 20) - 1;
 	if (getenv("SBL_FIXED_WINDOW")) window_max = window;              // measurement switch
+	double widen = 0.15;                                              // share of the base window that may stay blocked before the window widens
+	if (const char *e = getenv("SBL_WIDEN")) widen = atof(e);         // measurement switch
 	do {
 		rep.iterations++;
 		if (nid) {
@@ -136,7 +138,7 @@ SimplifyReport simplify_graph(Backend &be, uint32_t max_iter, uint32_t window, s
 					// retirements.  Widen while fewer than ~15 % of the base window stay blocked (measured optimum: 0.08 .. 0.25 within 1 %).
 					if (window_max > window && !solo && nwin) {
 						const double f = (double)blocked / (double)nwin;
-						const double want = f > 0 ? (0.15 * window) / f : (double)window_max;
+						const double want = f > 0 ? (widen * window) / f : (double)window_max;
 						wcur = want >= (double)window_max ? window_max : want <= (double)window ? window : (uint32_t)want;
 					}
 					if (chained) rep.chain_transactions += txn;
