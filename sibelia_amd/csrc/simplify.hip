@@ -4,7 +4,6 @@
 // launches (simplify_driver.h) and reads a 64-byte counter block back per round.
 #include <cstring>
 #include <algorithm>
-#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 
 #include "sbl_ctx.h"
@@ -844,8 +843,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	wave_setup(g, t, w, true, lane, ok);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 	__syncthreads();
-	// windows are scanned one at a time (the next one's burst in flight) and their marks go straight into the verdict table:
-	// an entry that IS live stops at the first id two instances with different endChars reach, without scanning the rest
+	// the windows go straight into the verdict table, a batch at a time (probe_windows)
 	int verdict = 0;
 	if (ok) {
 		verdict = probe_windows(g, w, vt, lane, id, tid);
