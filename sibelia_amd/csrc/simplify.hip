@@ -856,24 +856,10 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 		bool has = verdict > 0;
 		if (verdict < 0) { bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
-		if (!has) { g.need[id] = 0; g.touch[id] = 0; }             // verdict taken now: clean until somebody touches it again (counted by k_count_retired)
+		if (!has) { g.need[id] = 0; g.touch[id] = 0; }             // verdict taken now: clean until somebody touches it again (counted by the next selection, k_select_count)
 		else if (!t.err) g.need[id] = 2;
 		live[wi] = has ? 1 : 0;
 	}
-}
-
-// Entries the probe retired (live == 0): one atomic per 1024 entries instead of one per entry on a single counter -- late in an
-// iteration a launch retires up to 65 536 entries, and an address takes ~88 atomics per microsecond.
-__global__ void __launch_bounds__(256) k_count_retired(const uint8_t *__restrict__ live, unsigned nwin, unsigned *__restrict__ counter)
-{
-	unsigned base = blockIdx.x * 1024 + threadIdx.x * 4, c = 0;
-	for (unsigned i = 0; i < 4; i++) c += base + i < nwin && live[base + i] == 0;
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-	__shared__ unsigned s[4];
-	if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
-	__syncthreads();
-	if (threadIdx.x == 0) { unsigned t = s[0] + s[1] + s[2] + s[3]; if (t) atomicAdd(counter, t); }
 }
 
 // The lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window (and runs alone if it is the lowest).
@@ -899,12 +885,23 @@ __device__ __forceinline__ void select_scan_flags(const GraphView &g, unsigned l
 		f(idq, nb, bb);
 	}
 }
-__global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsigned *__restrict__ sel, unsigned lo, unsigned limit, unsigned chunk0, unsigned chunk)
+// (It also counts the entries the probe of the round before retired -- live == 0 -- for the host's bookkeeping: a slice of the window per
+// workgroup, one atomic each; that used to be a launch of its own behind every probe.)
+__global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsigned *__restrict__ sel, unsigned lo, unsigned limit, unsigned chunk0, unsigned chunk,
+                                                              const uint8_t *__restrict__ live, unsigned probed)
 {
-	__shared__ unsigned s_cnt;
+	__shared__ unsigned s_cnt, s_ret;
 	round_stamp(g, 3);                                               // the selection behind a round: its start is the end of the round's last kernel
-	if (threadIdx.x == 0) s_cnt = 0;
+	if (threadIdx.x == 0) { s_cnt = 0; s_ret = 0; }
 	__syncthreads();
+	if (probed) {
+		const unsigned per = (probed + gridDim.x - 1) / gridDim.x, from = blockIdx.x * per, to = from + per < probed ? from + per : probed;
+		unsigned r = 0;
+		for (unsigned i = from + threadIdx.x; i < to; i += SEL_THREADS) r += live[i] == 0;
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) r += __shfl_down(r, d);
+		if ((threadIdx.x & 63) == 0 && r) atomicAdd(&s_ret, r);
+	}
 	const unsigned per = chunk / SEL_THREADS;
 	const unsigned long long id0 = (unsigned long long)(chunk0 + blockIdx.x) * chunk + (unsigned long long)threadIdx.x * per;
 	unsigned cnt = 0, firstp = SBL_NONE, firstb = SBL_NONE;
@@ -917,7 +914,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsig
 	if (firstp != SBL_NONE) atomicMin(&sel[1], firstp);
 	if (firstb != SBL_NONE) atomicMin(&sel[0], firstb);
 	__syncthreads();
-	if (threadIdx.x == 0) sel[8 + blockIdx.x] = s_cnt;
+	if (threadIdx.x == 0) { sel[8 + blockIdx.x] = s_cnt; if (s_ret) atomicAdd(&g.ctr[CTR_COMMITTED], s_ret); }
 }
 __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsigned *__restrict__ sel, unsigned *__restrict__ win, unsigned lo, unsigned limit, unsigned W,
                                                               unsigned chunk0, unsigned chunk, unsigned nchunks)
@@ -2335,6 +2332,7 @@ struct DeviceBackend {
 	}
 	// The selection is launched behind a round's last kernel and read with the round's counters: one host round trip per round.
 	bool sel_pending = false, sel_ready = false;
+	uint32_t probed_nwin = 0;                                         // entries of the last probe whose retirements have not been counted yet
 	void select_launch(uint32_t lo, uint32_t limit, uint32_t W)
 	{
 		// chunks of >= 8192 ids, at most ~1024 of them
@@ -2346,7 +2344,8 @@ struct DeviceBackend {
 		GraphView gs = g;
 		if (sel_stamped) gs.tslot = TS_CAP * 4;                     // only the selection right behind a round marks that round's end
 		sel_stamped = true;
-		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(gs, st->sel.as<unsigned>(), lo, limit, chunk0, chunk);
+		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(gs, st->sel.as<unsigned>(), lo, limit, chunk0, chunk, st->live.as<uint8_t>(), probed_nwin);
+		probed_nwin = 0;
 		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks);
 		HIP_TRY(hipGetLastError());
 		sel_pending = true; sel_ready = false;
@@ -2401,7 +2400,7 @@ struct DeviceBackend {
 		begin_round();
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
 		k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
-		k_count_retired<<<(nwin + 1023) / 1024, 256, 0, c->stream>>>(st->live.as<uint8_t>(), nwin, g.ctr + CTR_COMMITTED);
+		probed_nwin = nwin;                                          // (the next selection counts what this probe retired)
 		HIP_TRY(hipGetLastError());
 	}
 	void mark_live(uint32_t nwin) { begin_round(); HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
