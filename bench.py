@@ -18,8 +18,9 @@ same K / W; --replicas makes that one the headline instead.
 The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
   cpu_baseline  the UNMODIFIED reference (oracle/_ref/ref_dump, built by oracle/build_ref.sh; kind "reference") timed on
-                rank 0 on a bounded sample of the same workload (8 strains, shorter genomes, ~20 s); the bit-exact port
-                (oracle/, kind "port") only where no reference build exists
+                rank 0 on the FULL workload of `value` (1 thread -- it has none more; ~4 - 8 min, its output hashed and compared
+                with the GPU's) with the bounded sample (8 strains, shorter genomes, ~20 s) beside it; --no-cpu-full keeps the
+                sample only; the bit-exact port (oracle/, kind "port") only where no reference build exists
 """
 import argparse
 import json
@@ -31,6 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def W_source_digest():
+    """sha256 (first 16 hex) over the kernel sources of the library: ties a PMC summary under profiles/ to the build it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sibelia_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -49,7 +61,8 @@ def main():
     ap.add_argument("--shard-enum", action="store_true", help="one job on all ranks: hash-prefix sharded enumeration over RCCL (the default for --gpus > 1)")
     ap.add_argument("--replicas", action="store_true", help="--gpus > 1: make the replicas configuration (one independent job per GPU) the headline value")
     ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
-    ap.add_argument("--cpu-full", action="store_true", help="also time the unmodified reference on the FULL workload (8 x 4.6 Mbp: ~500 s, once)")
+    ap.add_argument("--cpu-full", action="store_true", help="(default since round 4) time the unmodified reference on the FULL workload as well")
+    ap.add_argument("--no-cpu-full", action="store_true", help="bounded CPU sample only (~20 s) instead of the reference on the full workload (~4 - 8 min, 1 thread)")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL), so that the
@@ -241,11 +254,19 @@ def main():
         stage_8d = N * 24.125 + 12.0 * st["instances"] + sim_8d
         achieved = alg8d[dom] / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         # HBM traffic of that kernel per launch from the last committed PMC passes (tools/profile_summary.py), same workload only
-        traffic = None
+        # (PMC counters need the profiler around the process: they are collected by tools/collect_profiles.sh in passes of their own and
+        # summarised by tools/profile_summary.py, which records the digest of the kernel sources it ran on; traffic_source says which
+        # file the figure comes from and whether that digest is the one of THIS build)
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and (a.strains, a.L0, a.k, a.D, a.iters) == (8, 4_600_000, 25, 150, 4):
             try:
-                traffic = json.load(open(pmc))["kernels"][dom]["hbm_bytes_per_launch_est"]
+                doc = json.load(open(pmc))
+                traffic = doc["kernels"][dom]["hbm_bytes_per_launch_est"]
+                here = W_source_digest()
+                traffic_source = ("committed PMC passes: profiles/pmc_latest.json (round %s, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, kernel sources %s; "
+                                  "this build: %s = %s)" % (doc.get("round"), doc.get("source_digest", "unrecorded"), here,
+                                                            "the same sources" if doc.get("source_digest") == here else "DIFFERENT sources: indicative only"))
             except Exception:
                 traffic = None
         out = {
@@ -264,7 +285,8 @@ def main():
                        "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"]},
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_ratio": (traffic / alg8d[dom]) if traffic else None,
                          "avg_launch_ms": dur_ms, "avg_launch_ms_all_launches": dur_ms_clock, "timing": timing,
                          "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg8d[dom],
                          "algorithmic_model": "SURVEY.md 8d: N x 24.125 + 12 x instances + iterations x N x 4 = %.2f GB per stage; the simplification share "
@@ -337,20 +359,28 @@ def main():
                         ob, cdt = int(m.group(1)), float(m.group(2))
                         out["cpu_baseline"] = {"value": Ns / cdt, "unit": "strand-k-mers/s", "cores": 1, "kind": "reference", "host": host,
                                                "sample": "the unmodified reference's BlockFinder::PerformGraphSimplifications(%d,%d,%d) (oracle/_ref, 1 thread: it has no "
-                                                         "parallelism) on %d strains x %.2f Mbp from the same generator (%d strand-k-mers, %.1f s, %d bulges); on the full "
-                                                         "8 x 4.6 Mbp input it takes 499.8 s = 0.147 M/s (BASELINE.md)"
+                                                         "parallelism) on %d strains x %.2f Mbp from the same generator (%d strand-k-mers, %.1f s, %d bulges)"
                                                          % (a.k, a.D, a.iters, a.strains, a.cpu_sample_L0 / 1e6, Ns, cdt, ob)}
-                    if "cpu_baseline" in out and a.cpu_full:
-                        # the same binary on the FULL workload of `value`, once (~500 s): like-for-like on this host
+                    if "cpu_baseline" in out and not a.no_cpu_full:
+                        # the same binary on the FULL workload of `value`, once, on THIS host (north_star: "the reference's own CPU path
+                        # timed on the GPU box's host cores in the same run"): it becomes the baseline, the bounded sample stays beside it
                         fa2 = os.path.join(d, "full.fa")
                         W.write_fasta(fa2, seqs)
                         r2 = subprocess.run([ref_dump, fa2, os.path.join(d, "f"), "stage:%d:%d:%d" % (a.k, a.D, a.iters)], capture_output=True, text=True)
                         m2 = re.search(r"bulges=(\d+) seconds=([0-9.]+)", r2.stderr)
                         if r2.returncode == 0 and m2:
                             fb, fdt = int(m2.group(1)), float(m2.group(2))
-                            out["cpu_baseline"]["full"] = {"value": N / fdt, "unit": "strand-k-mers/s", "seconds": fdt, "bulges": fb, "bulges_equal_gpu": fb == bulges,
-                                                           "gpu_over_reference": (Ntot / (dt / a.steps)) / (N / fdt),
-                                                           "sample_over_full_rate": out["cpu_baseline"]["value"] / (N / fdt)}
+                            import hashlib
+                            fsha = hashlib.sha256(open(os.path.join(d, "f.0.out"), "rb").read()).hexdigest()
+                            smp = dict(out["cpu_baseline"])
+                            out["cpu_baseline"] = {"value": N / fdt, "unit": "strand-k-mers/s", "cores": 1, "kind": "reference", "host": host,
+                                                   "sample": "the FULL workload of `value` (%d strains x %.1f Mbp, %d strand-k-mers): the unmodified reference's "
+                                                             "BlockFinder::PerformGraphSimplifications(%d,%d,%d), 1 thread (it has no parallelism), %.1f s, %d bulges"
+                                                             % (a.strains, a.L0 / 1e6, N, a.k, a.D, a.iters, fdt, fb),
+                                                   "full": {"seconds": fdt, "bulges": fb, "bulges_equal_gpu": fb == bulges, "state_sha256": fsha,
+                                                            "state_equal_gpu": fsha == verify["state_sha256"],
+                                                            "gpu_over_reference": (Ntot / (dt / a.steps)) / (N / fdt)},
+                                                   "bounded_sample": {"value": smp["value"], "sample": smp["sample"], "sample_over_full_rate": smp["value"] / (N / fdt)}}
             if "cpu_baseline" not in out:                 # no reference build on this box: the bit-exact port (oracle/) instead
                 o = Oracle(sample)
                 t1 = time.perf_counter()

@@ -175,7 +175,7 @@ const char *sbl_strerror(sbl_status s);
 
 /* ---- Multi-GPU (one context per GPU).  The reference is a single-threaded CPU program with no
  * counterpart; these entry points attach a communicator to a context, after which the enumeration inside
- * sbl_enumerate / sbl_simplify_stage / sbl_list_edges (k <= 32) shards the k-mer table by hash prefix:
+ * sbl_enumerate / sbl_simplify_stage / sbl_list_edges shards the k-mer table by hash prefix (k <= 32; k > 32: see sbl_longk_* below):
  * every GPU turns its contiguous slice of base positions into 16-B k-mer records (one per position, no local
  * pre-aggregation), partitions them by hash prefix and sends every owner GPU its contiguous bucket range in ONE
  * all-to-all; owners classify their buckets (LDS tables), the bifurcation codes and the member marks are all-gathered.  Simplification is globally ordered and runs replicated (bit-identical) on
@@ -200,6 +200,22 @@ sbl_status sbl_comm_detach(sbl_ctx *ctx);
 sbl_status sbl_shard_layout(uint32_t nranks, uint32_t rank, uint32_t bits, uint64_t ntiles, uint32_t *first_bucket /* nranks + 1 */, uint64_t *tile_range /* 2 */);
 sbl_status sbl_shard_exchange_plan(uint32_t nranks, uint32_t rank, const uint64_t *count, const uint32_t *send_at /* nranks + 1 */, uint64_t record_bytes,
                                    uint64_t *sbytes, uint64_t *soff, uint64_t *rbytes, uint64_t *roff, uint64_t *nrecv);
+
+/* k > 32 with a communicator attached: the exact rank doubling of ONE job is split over the GPUs (csrc/longk.hip, "sharded rank
+ * doubling"; replaces the single-threaded suffix array of EnumerateBifurcationsSArrayInRAM, src/vertexenumeration.cpp:263-364, for
+ * BASELINE.json's config 5).  Two partitions of the suffixes of the superGenome S (np = 2E - 1 + k positions) and one exchange
+ * between them per doubling round: the POSITION side (rank r owns S[first[r], first[r + 1]) and a halo of H ranks behind it) and the
+ * SORTED side (rank q owns an interval of the global sorted order; owner = binary search in its bounds).  The layout arithmetic,
+ * device-free, as the pipeline itself calls it:
+ *   sbl_longk_slices        first[r] = np * r / nranks
+ *   sbl_longk_value_bounds  equal parts of the value range [0, maxvalue] (round 1 routes by the base-5 value of 8 symbols)
+ *   sbl_longk_owner         largest q < nranks with bounds[q] <= x (position owner: bounds = first; sorted-side owner: bounds = G)
+ *   sbl_longk_halo_plan     byte counts / offsets (4-B ranks) of the halo fetch: what `rank` sends to every peer out of its slice,
+ *                           what it receives from every peer into its halo of H positions. */
+sbl_status sbl_longk_slices(uint32_t nranks, uint64_t np, uint64_t *first /* nranks + 1 */);
+sbl_status sbl_longk_value_bounds(uint32_t nranks, uint64_t maxvalue, uint64_t *bounds /* nranks + 1 */);
+sbl_status sbl_longk_owner(uint32_t nranks, const uint64_t *bounds /* nranks + 1 */, uint64_t x, uint32_t *owner);
+sbl_status sbl_longk_halo_plan(uint32_t nranks, uint32_t rank, uint64_t np, uint64_t H, uint64_t *sbytes, uint64_t *soff, uint64_t *rbytes, uint64_t *roff);
 
 /* Tuning knob (0 = default): number of bifurcation ids speculatively committed per ordered round. */
 sbl_status sbl_set_window(sbl_ctx *ctx, uint32_t window);

@@ -24,7 +24,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_int, C.c_void_p)
 EXPORTS = ["sbl_create", "sbl_destroy", "sbl_load", "sbl_enumerate", "sbl_simplify_stage", "sbl_get_state", "sbl_nchr",
            "sbl_list_edges", "sbl_last_stats", "sbl_last_error", "sbl_strerror", "sbl_set_window",
            "sbl_save_state", "sbl_restore_state", "sbl_load_fasta", "sbl_record_name", "sbl_kmer_hashes", "sbl_generate_blocks", "sbl_postprocess", "sbl_serialize_graph",
-           "sbl_set_tempfile_mode", "sbl_rand_advance", "sbl_shard_layout", "sbl_shard_exchange_plan", "sbl_glue_stripes", "sbl_comm_unique_id", "sbl_comm_attach_rccl", "sbl_comm_attach_local", "sbl_comm_detach"]
+           "sbl_set_tempfile_mode", "sbl_rand_advance", "sbl_shard_layout", "sbl_shard_exchange_plan", "sbl_glue_stripes", "sbl_comm_unique_id", "sbl_comm_attach_rccl", "sbl_comm_attach_local", "sbl_comm_detach",
+           "sbl_longk_slices", "sbl_longk_value_bounds", "sbl_longk_owner", "sbl_longk_halo_plan"]
 
 
 class StageStats(C.Structure):
@@ -294,6 +295,46 @@ def shard_exchange_plan(nranks: int, rank: int, count: np.ndarray, send_at: np.n
     if rc:
         raise SibeliaError("sbl_shard_exchange_plan: " + L.sbl_strerror(rc).decode())
     return out[0], out[1], out[2], out[3], int(nrecv.value)
+
+
+def longk_slices(nranks: int, np_: int) -> np.ndarray:
+    """Position slices of the sharded rank doubling (csrc/longk.hip): first[r] = np * r / nranks, nranks + 1 values."""
+    L = load_library()
+    out = np.zeros(nranks + 1, dtype=np.uint64)
+    L.sbl_longk_slices.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+    if L.sbl_longk_slices(nranks, np_, out.ctypes.data):
+        raise SibeliaError("sbl_longk_slices")
+    return out
+
+
+def longk_value_bounds(nranks: int, maxvalue: int) -> np.ndarray:
+    L = load_library()
+    out = np.zeros(nranks + 1, dtype=np.uint64)
+    L.sbl_longk_value_bounds.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+    if L.sbl_longk_value_bounds(nranks, maxvalue, out.ctypes.data):
+        raise SibeliaError("sbl_longk_value_bounds")
+    return out
+
+
+def longk_owner(bounds: np.ndarray, x: int) -> int:
+    L = load_library()
+    b = np.ascontiguousarray(bounds, dtype=np.uint64)
+    o = C.c_uint32()
+    L.sbl_longk_owner.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    if L.sbl_longk_owner(len(b) - 1, b.ctypes.data, int(x), C.byref(o)):
+        raise SibeliaError("sbl_longk_owner")
+    return int(o.value)
+
+
+def longk_halo_plan(nranks: int, rank: int, np_: int, H: int):
+    """(sbytes, soff, rbytes, roff) of the halo fetch of the sharded rank doubling: 4-B ranks, offsets into the sender's slice /
+    the receiver's halo."""
+    L = load_library()
+    out = [np.zeros(nranks, dtype=np.uint64) for _ in range(4)]
+    L.sbl_longk_halo_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4
+    if L.sbl_longk_halo_plan(nranks, rank, np_, H, *[o.ctypes.data for o in out]):
+        raise SibeliaError("sbl_longk_halo_plan")
+    return out
 
 
 def glue_stripes(blocks: np.ndarray, nchr: int) -> np.ndarray:

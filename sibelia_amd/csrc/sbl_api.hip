@@ -211,7 +211,11 @@ static void device_sort_records(sbl_ctx *c, unsigned long long *kin, unsigned lo
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
-	if (k > 32) { sbl_run_enumeration_longk(c, k, elem_capacity); return; }      // long k: rank doubling (longk.hip)
+	if (k > 32) {                                                                  // long k: rank doubling (longk.hip), split over the attached GPUs when there are any
+		if (c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr) sbl_run_enumeration_longk_sharded(c, k, elem_capacity);
+		else sbl_run_enumeration_longk(c, k, elem_capacity);
+		return;
+	}
 	if (c->comm) { sbl_run_enumeration_sharded(c, k, elem_capacity); return; }    // k-mer table sharded by hash prefix over the attached GPUs
 	SBL_CHECK(kmer_hash(~0ull) == KB_EMPTY_KEY && kmer_unhash(kmer_hash(0x123456789ABCDEFull)) == 0x123456789ABCDEFull, SBL_ERR_INTERNAL, "k-mer hash constants");
 	hipStream_t s = c->stream;
@@ -348,8 +352,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	(void)hipSetDevice(c->device);
 	if (c->child) { sbl_destroy(c->child); c->child = nullptr; }
 	if (c->tiny_out) { (void)hipHostFree(c->tiny_out); c->tiny_out = nullptr; }
-	if (c->h_ch) (void)hipHostFree(c->h_ch);
-	if (c->h_opos) (void)hipHostFree(c->h_opos);
+	c->release_host_state();
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);
@@ -505,12 +508,22 @@ extern "C" sbl_status sbl_get_state(sbl_ctx *c, uint32_t chr, const uint8_t **se
 		SBL_CHECK(chr < c->nchr, SBL_ERR_BAD_ARG, "chromosome index out of range");
 		if (!c->host_state_valid) {
 			if (c->nelem > c->h_cap) {                               // pinned staging, grown with slack (stages change the length by a few per cent)
-				if (c->h_ch) (void)hipHostFree(c->h_ch);
-				if (c->h_opos) (void)hipHostFree(c->h_opos);
+				// the buffer being replaced is kept for one generation (see sbl_ctx::h_old_ch), the one before it goes
+				c->host_free(c->h_old_ch, c->h_old_pinned); c->host_free(c->h_old_opos, c->h_old_pinned);
+				c->h_old_ch = c->h_ch; c->h_old_opos = c->h_opos; c->h_old_pinned = c->h_pinned;
 				c->h_ch = nullptr; c->h_opos = nullptr; c->h_cap = 0;
 				const size_t cap = c->nelem + c->nelem / 8 + 4096;
-				HIP_TRY(hipHostMalloc((void **)&c->h_ch, cap));
-				HIP_TRY(hipHostMalloc((void **)&c->h_opos, cap * 4));
+				// 5 B per element pinned (1.4 GB for 62 strains x 4.6 Mbp); a host that cannot pin that much still gets its state, through
+				// pageable memory (SBL_TEST_NO_PINNED_STATE=1: test switch)
+				c->h_pinned = getenv("SBL_TEST_NO_PINNED_STATE") == nullptr
+				              && hipHostMalloc((void **)&c->h_ch, cap) == hipSuccess && hipHostMalloc((void **)&c->h_opos, cap * 4) == hipSuccess;
+				if (!c->h_pinned) {
+					(void)hipGetLastError();
+					if (c->h_ch) { (void)hipHostFree(c->h_ch); c->h_ch = nullptr; }
+					c->h_opos = nullptr;
+					c->h_ch = (uint8_t *)malloc(cap); c->h_opos = (uint32_t *)malloc(cap * 4);
+					if (!c->h_ch || !c->h_opos) { free(c->h_ch); free(c->h_opos); c->h_ch = nullptr; c->h_opos = nullptr; throw SblError{SBL_ERR_OOM, "host staging buffer for the state"}; }
+				}
 				c->h_cap = cap;
 			}
 			// d_op never carries anything above the 29 position bits (the marks live in arrays of their own; the copy-back kernel masks)

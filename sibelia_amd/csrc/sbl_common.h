@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,20 @@ struct SblError {
 
 #define SBL_CHECK(cond, status, text) do { if (!(cond)) throw SblError{(status), (text)}; } while (0)
 
+// Bytes held by all DevBufs of the process, and the test cap on them (SBL_TEST_ALLOC_LIMIT_MB: an allocation that would take the total
+// beyond it fails exactly like a hipMalloc that finds no memory -- the out-of-memory paths can be exercised on a 288-GB device).
+inline std::atomic<size_t> &sbl_devbuf_total() { static std::atomic<size_t> t{0}; return t; }
+inline void sbl_devbuf_cap_check(size_t old_cap, size_t want)
+{
+	const char *e = getenv("SBL_TEST_ALLOC_LIMIT_MB");
+	if (!e) return;
+	const size_t limit = (size_t)atoll(e) << 20, now = sbl_devbuf_total().load();
+	if (now - old_cap + want > limit) {
+		char b[160]; snprintf(b, sizeof b, "out of memory: device allocation of %zu bytes refused (%zu held, test cap %zu)", want, now, limit);
+		throw SblError{SBL_ERR_OOM, b};
+	}
+}
+
 // Grow-only device buffer.
 struct DevBuf {
 	void *p = nullptr;
@@ -29,15 +45,17 @@ struct DevBuf {
 	{
 		if (bytes <= cap) return;
 		size_t want = bytes + bytes / 16 + 256;
+		sbl_devbuf_cap_check(cap, want);
 		void *q = nullptr;
 		// the new allocation first: a failure then leaves the old buffer (which views may still point into) intact ...
 		if (hipMalloc(&q, want) != hipSuccess) {
 			(void)hipGetLastError();
 			// ... unless only releasing the old one makes room (contents are not preserved by ensure() anyway)
-			if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+			if (p) { (void)hipFree(p); p = nullptr; sbl_devbuf_total() -= cap; cap = 0; }
 			HIP_TRY(hipMalloc(&q, want));
 		}
 		if (p) (void)hipFree(p);
+		sbl_devbuf_total() += want - cap;
 		p = q; cap = want;
 	}
 	// grow preserving the first `keep` bytes
@@ -46,13 +64,15 @@ struct DevBuf {
 		if (bytes <= cap) return;
 		void *q = nullptr;
 		size_t want = bytes + bytes / 16 + 256;
+		sbl_devbuf_cap_check(0, want);                                // (old and new buffer coexist during the copy)
 		HIP_TRY(hipMalloc(&q, want));
 		if (p && keep) HIP_TRY(hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (p) (void)hipFree(p);
+		sbl_devbuf_total() += want - cap;
 		p = q; cap = want;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p) (void)hipFree(p); sbl_devbuf_total() -= cap; p = nullptr; cap = 0; }
 	template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 

@@ -43,9 +43,19 @@ struct sbl_ctx {
 	// (copy-back contract of the reference: blockfinder.cpp:85-95).  ONE pinned staging buffer for the whole element array, filled
 	// by two bulk device-to-host copies (1 + 4 B per element); the per-chromosome pointers handed out are slices of it.
 	bool host_state_valid = false;
-	uint8_t *h_ch = nullptr;             // pinned [h_cap]
+	uint8_t *h_ch = nullptr;             // pinned [h_cap] (pageable when the pinned allocation fails: h_pinned)
 	uint32_t *h_opos = nullptr;          // pinned [h_cap]
 	size_t h_cap = 0;
+	bool h_pinned = true;
+	// the staging buffer it replaced: pointers handed out by sbl_get_state stay readable (stale, not dangling) for one more
+	// generation -- a caller that still holds a slice across a stage + sbl_get_state reads old data instead of freed memory
+	uint8_t *h_old_ch = nullptr; uint32_t *h_old_opos = nullptr; bool h_old_pinned = true;
+	void host_free(void *p, bool pinned) { if (!p) return; if (pinned) (void)hipHostFree(p); else free(p); }
+	void release_host_state()
+	{
+		host_free(h_ch, h_pinned); host_free(h_opos, h_pinned); host_free(h_old_ch, h_old_pinned); host_free(h_old_opos, h_old_pinned);
+		h_ch = h_old_ch = nullptr; h_opos = h_old_opos = nullptr; h_cap = 0;
+	}
 
 	// ---- enumeration workspace
 	DevBuf d_pk, d_sp;                   // packed bases / separator bits
@@ -79,6 +89,10 @@ struct sbl_ctx {
 	// ---- simplification workspace lives in simplify.hip (opaque here)
 	struct SimplifyState *simp = nullptr;
 	uint32_t window = 0;
+	// what an abandoned attempt learnt, carried into the rerun and into later stages (simplify.hip: sbl_simplify_run): the element slack
+	// and node capacity a pool overflow asked for, and "the previous stage needed a roll-back: take iteration checkpoints from the start"
+	size_t hint_elem_slack = 0, hint_cap_n = 0;
+	bool hint_checkpoints = false;
 
 	sbl_stage_stats stats{};
 	hipEvent_t ev[8] = {};
@@ -116,6 +130,7 @@ void sbl_run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity); 
 void sbl_comm_release(sbl_ctx *c);
 // implemented in longk.hip
 void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k > 32: exact rank doubling
+void sbl_run_enumeration_longk_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // ... split over the GPUs of c->comm
 void sbl_longk_free(sbl_ctx *c);
 // implemented in simplify.hip
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);

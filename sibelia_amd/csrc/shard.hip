@@ -34,24 +34,13 @@
 #include <rccl/rccl.h>
 
 #include "sbl_ctx.h"
+#include "sbl_comm.h"
 #include "kmer_kernels.h"
 #include "kmer_bucket_kernels.h"
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------- transports
-struct SblComm {
-	uint32_t rank = 0, n = 1;
-	virtual ~SblComm() {}
-	// small host payloads (counts): out = n x bytes
-	virtual void allgather_host(sbl_ctx *c, const void *in, size_t bytes, void *out) = 0;
-	// device buffers; byte counts / offsets per peer
-	virtual void alltoallv(sbl_ctx *c, const char *send, const size_t *sbytes, const size_t *soff,
-	                       char *recv, const size_t *rbytes, const size_t *roff) = 0;
-	// this rank is leaving a collective call with an error: release peers that would wait for it (local transport)
-	virtual void abort_peers() {}
-};
-
 struct RcclApi {
 	void *h = nullptr;
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -426,6 +415,7 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 		c->d_recv.ensure(nrecv * 8 + 16); c->d_send.ensure(nrecv * 8 + 16);      // received keys / values
 		clk.time([&] { cm->alltoallv(c, c->d_rec_keys[1].as<char>(), sb.data(), so.data(), c->d_recv.as<char>(), rb.data(), ro.data()); });
 		clk.time([&] { cm->alltoallv(c, c->d_rec_vals[1].as<char>(), sb.data(), so.data(), c->d_send.as<char>(), rb.data(), ro.data()); });
+		if (const char *e = getenv("SBL_TEST_FAIL_RANK")) if ((uint32_t)atoi(e) == r) throw SblError{SBL_ERR_OOM, "out of memory (SBL_TEST_FAIL_RANK: this rank leaves the collective enumeration)"};
 		// ---- C: owner side: partition again (R runs, each sorted by bucket), per-bucket tables
 		for (int i = 0; i < 2; i++) { c->d_otable.ensure(nrecv * 8 + 16); c->d_oused.ensure(nrecv * 8 + 16); }
 		unsigned long long *ok = c->d_otable.as<unsigned long long>(), *ov = c->d_oused.as<unsigned long long>();

@@ -2134,6 +2134,7 @@ struct DeviceBackend {
 	SimplifyState *st;
 	GraphView g{};
 	uint32_t cap_e = 0, cap_n = 0, nid_ = 0;
+	size_t ne0_ = 0;                                                  // elements of the stage's input (padded): cap_e - ne0_ is the insertion slack
 	uint32_t ck_ne = 0, ck_nn = 0;
 	uint32_t window = 0, arena_bytes = 1u << 17, snap_arena_bytes = 1u << 17, snap_threads = 256 * 32;   // snap_threads = resident waves
 	uint32_t big_arena_bytes = 1u << 28;
@@ -2451,6 +2452,14 @@ struct DeviceBackend {
 	bool grow(uint32_t err)
 	{
 		if (err & ~(uint32_t)(BT_ERR_ELEM_CAP | BT_ERR_NODE_CAP)) return false;
+		if (optimistic) {
+			// no checkpoint to replay from: the attempt is abandoned BEFORE any buffer is enlarged, and the capacities the rerun (and the
+			// later stages of this context) should start with are left on the context -- the rerun used to start with the original
+			// capacities again, overflow again at the same place, and only then grow + replay
+			if (err & BT_ERR_ELEM_CAP) c->hint_elem_slack = std::max<size_t>(c->hint_elem_slack, 2 * ((size_t)cap_e - ne0_));
+			if (err & BT_ERR_NODE_CAP) c->hint_cap_n = std::max<size_t>(c->hint_cap_n, 2 * (size_t)cap_n);
+			throw RestartStage{};
+		}
 		hipStream_t s = c->stream;
 		if (err & BT_ERR_ELEM_CAP) {
 			size_t n = (size_t)cap_e * 2;
@@ -2531,14 +2540,18 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 	// run out of pool or arena space, an optimistic run that would need a roll-back -- is simply followed by the next one from the same input
 	ProgressFilter pf{progress, user};
 	sbl_progress_fn pfn = progress ? &ProgressFilter::relay : nullptr;
-	const bool optimistic = getenv("SBL_CHECKPOINTS") == nullptr;     // measurement / test switch: checkpoints from the first attempt on
+	// (SBL_CHECKPOINTS: measurement / test switch, checkpoints from the first attempt on; hint_checkpoints: the previous stage of this
+	// context had to be abandoned for an order violation -- inputs that do that once tend to do it again, and an abandoned attempt
+	// costs a whole stage, a checkpoint 2 - 4 %)
+	const bool optimistic = getenv("SBL_CHECKPOINTS") == nullptr && !c->hint_checkpoints;
 	int r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, true, optimistic);
 	if (r == RUN_DENSE_FAILED) r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, false, optimistic);
 	if (r == RUN_RESTART) {
-		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] optimistic attempt abandoned: the stage runs again with iteration checkpoints\n");
+		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] optimistic attempt abandoned: the stage runs again with iteration checkpoints (element slack hint %zu, node capacity hint %zu)\n", c->hint_elem_slack, c->hint_cap_n);
 		(void)simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, false, false);
 		c->stats.replays++;                                               // the abandoned attempt
-	}
+		c->hint_checkpoints = c->stats.replays > c->stats.grow_replays + 1;      // order violations (not just a pool that was too small): the next stage starts with checkpoints
+	} else if (!optimistic && r == RUN_DONE && c->stats.replays == c->stats.grow_replays) c->hint_checkpoints = false;      // a checkpointed stage that never rolled back
 }
 static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic)
 {
@@ -2554,6 +2567,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	size_t E = c->nelem, ne0 = (E + 31) / 32 * 32;
 	size_t cap_e = ne0 + E / 8 + (1u << 20);
 	if (const char *e = getenv("SBL_TEST_ELEM_SLACK")) cap_e = ne0 + (size_t)atoll(e);      // test hook: provoke the grow / restart paths
+	cap_e = std::max(cap_e, ne0 + c->hint_elem_slack);                // what an abandoned attempt of this context asked for (DeviceBackend::grow)
+	be.ne0_ = ne0;
 	SBL_CHECK(cap_e < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
 	sbl_run_enumeration(c, k, cap_e);
 	be.nid_ = c->bif_count;
@@ -2578,6 +2593,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	// (the one-launch path cannot grow a pool and replay: low-complexity input makes hundreds of nodes per collapse, and 16 M nodes are 270 MB)
 	size_t cap_n = dense ? std::max<size_t>(4 * ninst + (1u << 20), 16u << 20) : 4 * ninst + (1u << 20);
 	if (dense) if (const char *e = getenv("SBL_TEST_DENSE_NODE_SLACK")) cap_n = ninst + (size_t)atoll(e);      // test hook: provoke the fall-back
+	cap_n = std::max(cap_n, c->hint_cap_n);
 	SBL_CHECK(cap_n < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "node capacity overflow");
 	be.cap_n = (uint32_t)cap_n;
 	st->nslot.ensure(cap_n * 4); st->nnext.ensure(cap_n * 4); st->nidst.ensure(cap_n * 4); st->nclr.ensure(cap_n * 4); st->ndead.ensure(cap_n);

@@ -53,7 +53,9 @@ def main():
                       # gfx950: FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled (upper estimate for
                       # scattered 4-byte reads); WRITE_SIZE is uncalibrated (device-scope atomics count as fabric writes)
                       "hbm_bytes_per_launch_est": (2 * v / n + ((wv / wn) if wn else 0.0)) * 1024}
-    doc = {"round": tag,
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = {"round": tag, "source_digest": bench.W_source_digest(),
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
            "workload": "default bench workload (8 strains x 4.6 Mbp, k=25, D=150, 4 iterations)",
            "units": "counter unit KB; hbm_bytes_per_launch_est = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md HBM section)",

@@ -13,11 +13,12 @@ from sibelia_amd import BlockFinder, workloads as W        # noqa: E402
 from oracle.oracle import Oracle                            # noqa: E402
 
 
-def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print):
-    """draws cases from `seed` on for `budget` seconds; returns (cases, mismatching seeds)"""
+def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print, count=None):
+    """draws cases from `seed` on for `budget` seconds -- or exactly `count` cases when given (the GPU suite: no wall-clock dependence);
+    returns (cases, mismatching seeds)"""
     t0 = time.time()
     done, bad = 0, []
-    while time.time() - t0 < budget:
+    while (done < count) if count is not None else (time.time() - t0 < budget):
         rng = np.random.default_rng(seed)
         n = int(rng.integers(2, 13))
         L0 = int(rng.integers(3_000, 80_000))
