@@ -76,6 +76,10 @@ typedef struct {
 	 * HIP event pairs are recorded around every 4th launch of the commit kernel only (an event pair costs ~8 us of barrier packets): */
 	double commit_event_ms;          /* sum of those event-pair times */
 	uint64_t commit_event_launches;  /* ... and how many launches they cover */
+	/* SBL_CHECK_DICTIONARY=1 (k <= 32): the reference's _DEBUG invariant IndexedSequence::Test (src/indexedsequence.cpp:74-103) on the
+	 * stage's final graph -- windows whose stored mark was compared with the dictionary of the initial marking, and how many differed
+	 * (a stage with mismatches fails with SBL_ERR_INTERNAL) */
+	uint64_t dict_checked, dict_mismatches;
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -314,6 +314,7 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	const size_t E = c->nelem, n = 2 * E - 1, np = n + k;             // 2L + 2 nchr + 1 = 2E - 1; padded with k '#'
 	SBL_CHECK(np < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "input too large for 32-bit suffix ranks");
 	c->cur_k = k;
+	c->stats.exchange_bytes = 0; c->stats.exchange_ms = 0;             // (replicated: nothing leaves this GPU)
 	LongKScratch &L = lk_of(c);
 	lk_preflight(c, L, np);
 	for (int t = 0; t < 2; t++) L.rank[t].ensure((np + 1) * 4);

@@ -211,6 +211,7 @@ static void device_sort_records(sbl_ctx *c, unsigned long long *kin, unsigned lo
 void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
+	c->dict_keys = nullptr;
 	if (k > 32) {                                                                  // long k: rank doubling (longk.hip), split over the attached GPUs when there are any
 		if (c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr) sbl_run_enumeration_longk_sharded(c, k, elem_capacity);
 		else sbl_run_enumeration_longk(c, k, elem_capacity);
@@ -304,6 +305,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	c->stats.kmer_table_bytes = positions * 32 + E / 4;
 	c->stats.strand_kmers = 2 * positions;
 	c->stats.bif_count = nkeys;
+	c->dict_keys = c->d_skeys.as<unsigned long long>();
 }
 
 // ordered compaction of one strand's marks into (element, id) arrays

@@ -69,6 +69,7 @@ struct sbl_ctx {
 	uint32_t nmarks[2] = {0, 0};
 	uint32_t bif_count = 0;
 	uint32_t cur_k = 0;
+	const unsigned long long *dict_keys = nullptr;   // k <= 32: the sorted strand-specific bifurcation codes of the last enumeration (id = rank); nullptr for long k
 	DevBuf d_inst;                       // marshalling buffer
 	DevBuf d_edges, d_valid;             // sbl_list_edges staging
 

@@ -470,6 +470,7 @@ static void run_enumeration_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity
 			                                                    c->d_allkeys2.as<unsigned long long>(), (unsigned)nkeys, k, c->d_pairids.as<unsigned>());
 	}
 	c->bif_count = (uint32_t)nkeys;
+	c->dict_keys = c->d_allkeys2.as<unsigned long long>();
 
 	// ---- E: marks of my buckets' member positions, gathered and scattered into the dense arrays everywhere
 	for (int st = 0; st < 2; st++) {

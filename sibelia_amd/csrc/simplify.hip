@@ -2107,6 +2107,45 @@ __global__ void k_sep_positions(const unsigned *__restrict__ sepidx, unsigned nc
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < nchr) op[sepidx[i + 1]] = (sepidx[i + 1] - sepidx[i] - 1u) & BT_POS_MASK;
 }
+// IndexedSequence::Test() (reference src/indexedsequence.cpp:74-103, compiled under _DEBUG only): after any number of collapses, at every
+// window position the stored mark equals what the dictionary of the INITIAL marking (k-mer string -> id, FormDictionary) says about the
+// k characters spelled there NOW -- "same k-mer => same id everywhere" -- and a position whose k-mer is not in the dictionary (or that
+// has no full window) carries no mark.  k <= 32: the dictionary is the sorted list of strand-specific bifurcation codes of the stage's
+// enumeration (id = rank).  Checked on the stage's final graph: marks by old slot, characters of the copy-back's linear order.
+// out: [0] windows checked, [1] mismatches, [2..5] first mismatch (slot, strand, stored, expected).   SBL_CHECK_DICTIONARY=1.
+__device__ __forceinline__ unsigned dict_lookup(const unsigned long long *__restrict__ dict, unsigned nd, unsigned long long code)
+{
+	unsigned lo = 0, hi = nd;
+	while (lo < hi) { unsigned mid = (lo + hi) >> 1; if (dict[mid] < code) lo = mid + 1; else hi = mid; }
+	return lo < nd && dict[lo] == code ? lo : BT_NONE;
+}
+__global__ void __launch_bounds__(256) k_dict_check(const uint8_t *__restrict__ ch, unsigned ne, const unsigned *__restrict__ newidx, const uint8_t *__restrict__ ch_out, unsigned long long total,
+                                                    const unsigned *__restrict__ bif0, const unsigned *__restrict__ bif1, const unsigned long long *__restrict__ dict, unsigned nd, unsigned k,
+                                                    unsigned long long *__restrict__ out)
+{
+	const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned checked = 0, bad = 0;
+	if (e < ne && ch[e] != BT_DEAD_CHAR && ch[e] != BT_SEP) {
+		const unsigned long long p = newidx[e];
+		auto base = [](uint8_t c) { unsigned x = (c >> 1) & 3u; return x ^ (x >> 1); };      // A0 C1 G2 T3 (k_pack2bit)
+		unsigned exp0 = BT_NONE, exp1 = BT_NONE;
+		if (p + k <= total) {
+			unsigned long long code = 0; bool full = true;
+			for (unsigned i = 0; i < k; i++) { const uint8_t c = ch_out[p + i]; if (c == BT_SEP) { full = false; break; } code = (code << 2) | base(c); }
+			if (full) { exp0 = dict_lookup(dict, nd, code); checked++; }
+		}
+		if (p + 1 >= k) {
+			unsigned long long code = 0; bool full = true;
+			for (unsigned i = 0; i < k; i++) { const uint8_t c = ch_out[p - i]; if (c == BT_SEP) { full = false; break; } code = (code << 2) | (3u - base(c)); }
+			if (full) { exp1 = dict_lookup(dict, nd, code); checked++; }
+		}
+		const unsigned s0 = bif0[e], s1 = bif1[e];
+		if (s0 != exp0) { bad++; if (atomicCAS(&out[2], ~0ull, (unsigned long long)e) == ~0ull) { out[3] = 0; out[4] = s0; out[5] = exp0; } }
+		if (s1 != exp1) { bad++; if (atomicCAS(&out[2], ~0ull, (unsigned long long)e) == ~0ull) { out[3] = 1; out[4] = s1; out[5] = exp1; } }
+	}
+	for (int d = 32; d > 0; d >>= 1) { checked += __shfl_down(checked, d); bad += __shfl_down(bad, d); }
+	if ((threadIdx.x & 63) == 0) { if (checked) atomicAdd(&out[0], (unsigned long long)checked); if (bad) atomicAdd(&out[1], (unsigned long long)bad); }
+}
 __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_t from, size_t to)
 {
 	size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2780,6 +2819,29 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	k_remap_seps<<<nblocks(c->nchr + 1, 64), 64, 0, s>>>(st->newidx.as<unsigned>(), c->d_sepidx.as<unsigned>(), c->nchr + 1);
 	k_sep_positions<<<nblocks(c->nchr, 64), 64, 0, s>>>(c->d_sepidx.as<unsigned>(), c->nchr, st->op_out.as<unsigned>());
 	HIP_TRY(hipGetLastError());
+	c->stats.dict_checked = 0; c->stats.dict_mismatches = 0;
+	if (getenv("SBL_CHECK_DICTIONARY") && c->dict_keys && k <= 32) {
+		// the reference's own invariant (IndexedSequence::Test) on the stage's final graph, see k_dict_check
+		st->scantmp.ensure(64);
+		unsigned long long init[6] = {0, 0, ~0ull, 0, 0, 0}, res[6];
+		HIP_TRY(hipMemcpyAsync(st->scantmp.p, init, sizeof init, hipMemcpyHostToDevice, s));
+		if (getenv("SBL_TEST_CORRUPT_MARK")) {                              // test hook: the check must notice ONE wrong mark among hundreds of millions
+			const unsigned wrong = 0;
+			HIP_TRY(hipMemcpyAsync(c->d_bif[0].as<unsigned>() + (c->sepidx[0] + 1 + (size_t)atoll(getenv("SBL_TEST_CORRUPT_MARK"))), &wrong, 4, hipMemcpyHostToDevice, s));
+		}
+		k_dict_check<<<nblocks(ne, 256), 256, 0, s>>>(st->ch.as<uint8_t>(), ne, st->newidx.as<unsigned>(), st->ch_out.as<uint8_t>(), total, c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(),
+		                                             c->dict_keys, be.nid_, k, st->scantmp.as<unsigned long long>());
+		HIP_TRY(hipMemcpyAsync(res, st->scantmp.p, sizeof res, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		c->stats.dict_checked = res[0]; c->stats.dict_mismatches = res[1];
+		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] dictionary invariant (IndexedSequence::Test): %llu windows checked, %llu mismatches\n", res[0], res[1]);
+		if (res[1] && !getenv("SBL_TEST_CORRUPT_MARK")) {
+			char b[256];
+			snprintf(b, sizeof b, "dictionary invariant violated (IndexedSequence::Test): %llu of %llu windows; first at slot %llu strand %llu: stored id %llu, the dictionary says %llu",
+			         res[1], res[0], res[2], res[3], res[4], res[5]);
+			throw SblError{SBL_ERR_INTERNAL, b};
+		}
+	}
 	std::swap(c->d_ch, st->ch_out);
 	std::swap(c->d_op, st->op_out);
 	HIP_TRY(hipMemcpyAsync(c->sepidx.data(), c->d_sepidx.p, (size_t)(c->nchr + 1) * 4, hipMemcpyDeviceToHost, s));

@@ -359,7 +359,7 @@ def test_config5_full_size_properties():
     bf.close()
 
 
-def test_config4_shape_full_size_is_reproducible():
+def test_config4_shape_full_size_is_reproducible(monkeypatch):
     # BASELINE.json config 4 shape at full size on one GPU: 62 strains x 4.6 Mbp (285 Mbp, 570 M strand-k-mers, ids with 124
     # instances), k = 25.  No CPU implementation finishes it in test time (the reference is superlinear in the number of
     # strains): the result must be reproducible and independent of the speculation window, and its first two strains are the
@@ -368,12 +368,14 @@ def test_config4_shape_full_size_is_reproducible():
     from sibelia_amd import workloads as W, formats as F
     seqs = W.gen_strains(L0=4_600_000, n=62, seed=1)
     digests, counts = [], []
+    monkeypatch.setenv("SBL_CHECK_DICTIONARY", "1")      # the reference's own invariant (IndexedSequence::Test) on the final graph of the full-size run
     for window in (0, 5000):
         bf = _bf(seqs)
         if window:
             bf.set_window(window)
         bulges = bf.simplify_stage(25, 150, 4)
         st = bf.stats()
+        assert st["dict_mismatches"] == 0 and st["dict_checked"] > 500_000_000
         counts.append((bulges, st["bif_count"], st["instances"], st["replays"] - st["grow_replays"]))
         s, p = bf.state()
         digests.append(hashlib.sha256(F.state_bytes(bulges, s, p)).hexdigest())
@@ -381,6 +383,118 @@ def test_config4_shape_full_size_is_reproducible():
         bf.close()
     assert digests[0] == digests[1] and counts[0][:3] == counts[1][:3]
     assert counts[0][0] > 2_000_000 and counts[0][1] > 1_000_000
+
+
+# ---- full-size reference pins of configs 4 and 5 (tests/golden/big_vectors.json: sha256 + size + counts of what the UNMODIFIED reference
+# wrote, generated once by tests/golden/gen/make_big_golden.py -- 30 min to hours of reference time and up to ~35 GB of host memory per
+# input; the outputs themselves are gigabytes and are hashed as a stream on both sides)
+def _big_vector(name):
+    import json
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_vectors.json")
+    if not os.path.exists(p):
+        pytest.skip("tests/golden/big_vectors.json not generated")
+    vs = [v for v in json.load(open(p))["vectors"] if v["name"] == name]
+    if not vs:
+        pytest.skip("no full-size reference fixture for " + name + " (make_big_golden.py " + name + ")")
+    return vs[0]
+
+
+def _big_input(v):
+    from sibelia_amd import workloads as W
+    spec = v["input"]
+    seqs = W.gen_strains(**spec["args"]) if spec["kind"] == "gen_strains" else W.longk_case(spec["args"]["total"], spec["args"]["nrec"])
+    assert W.input_digest(seqs) == v["input_sha256"], "input generator drifted for " + v["name"]
+    return seqs
+
+
+def _enum_digest(bf, k):
+    import hashlib, struct
+    bc, pos, neg = bf.enumerate(k)
+    h = hashlib.sha256(struct.pack("<I", bc))
+    size = 4
+    for a in (pos, neg):
+        cols = np.stack([a["id"], a["chr"], a["pos"]], axis=1).astype("<u4") if len(a) else np.zeros((0, 3), "<u4")
+        h.update(struct.pack("<Q", len(a))); h.update(cols.tobytes())
+        size += 8 + cols.nbytes
+    return h.hexdigest(), size, bc
+
+
+def _stage_digest(bf, k, D, it):
+    import hashlib, struct
+    bulges = bf.simplify_stage(k, D, it)
+    vs, vp = bf.state_views()
+    h = hashlib.sha256(struct.pack("<QI", bulges, len(vs)))
+    size = 12
+    for x, y in zip(vs, vp):
+        h.update(struct.pack("<Q", len(x))); h.update(x); h.update(y)
+        size += 8 + 5 * len(x)
+    return h.hexdigest(), size, bulges
+
+
+def _replay_big(name, check_dictionary=False, monkeypatch=None):
+    v = _big_vector(name)
+    seqs = _big_input(v)
+    if check_dictionary:
+        monkeypatch.setenv("SBL_CHECK_DICTIONARY", "1")
+    bf = _bf(seqs)
+    del seqs
+    try:
+        for o in v["outputs"]:
+            p = o["cmd"].split(":")
+            if p[0] == "enum":
+                sha, size, bc = _enum_digest(bf, int(p[1]))
+                assert (bc, size) == (o["bif_count"], o["size"]), "%s %s: %d ids / %d bytes, the reference has %d / %d" % (name, o["cmd"], bc, size, o["bif_count"], o["size"])
+            else:
+                sha, size, bulges = _stage_digest(bf, int(p[1]), int(p[2]), int(p[3]))
+                assert (bulges, size) == (o["bulges"], o["size"]), "%s %s: %d bulges / %d bytes, the reference has %d / %d" % (name, o["cmd"], bulges, size, o["bulges"], o["size"])
+                if check_dictionary:
+                    st = bf.stats()
+                    assert st["dict_mismatches"] == 0 and st["dict_checked"] == 2 * sum(max(0, len(x) - int(p[1]) + 1) for x in bf.state_views()[0])
+            assert sha == o["sha256"], "%s: %s differs from the unmodified reference's output" % (name, o["cmd"])
+    finally:
+        bf.close()
+
+
+def test_config4_62_strains_460k_matches_reference(monkeypatch):
+    # BASELINE.json config 4 (62 strains, k = 25) at a tenth of the record length: enumeration and post-stage state sha256-identical to
+    # the unmodified reference's (~30 min there), with the reference's own _DEBUG invariant checked on the final graph on the way
+    _replay_big("synth/strains62_460k", check_dictionary=True, monkeypatch=monkeypatch)
+
+
+def test_config4_full_size_matches_reference():
+    # ... and at full size (62 x 4.6 Mbp: hours of reference time) when that fixture has been generated
+    _replay_big("synth/strains62_4600k")
+
+
+def test_config5_full_size_matches_reference():
+    # BASELINE.json config 5 at full size: 4 x 225 Mbp of random DNA, k = 5000, D = 15000 -- enumeration before, the stage, enumeration
+    # after, each sha256-identical to the unmodified reference's (int32 suffix array of 1.8 G suffixes, ~30 GB, about an hour)
+    _replay_big("synth/random4x225M_k5000")
+
+
+def test_dictionary_invariant_of_the_reference_holds_and_is_sharp(monkeypatch):
+    """IndexedSequence::Test() (reference src/indexedsequence.cpp:74-103, _DEBUG builds only): after every collapse, at every window position
+    the stored bifurcation id is what the dictionary of the initial marking says about the k-mer spelled there now.  With
+    SBL_CHECK_DICTIONARY=1 the stage checks it on its final graph (k_dict_check): every window of the post-stage sequences is
+    covered, none differs -- and ONE mark changed behind the stage's back (SBL_TEST_CORRUPT_MARK) is noticed."""
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=300_000, n=8, seed=12, inv_min=3000, inv_max=12000)
+    monkeypatch.setenv("SBL_CHECK_DICTIONARY", "1")
+    bf = _bf(seqs)
+    try:
+        bf.save_state()
+        for k, D in ((25, 150), (16, 100), (32, 200)):
+            bf.restore_state()
+            assert bf.simplify_stage(k, D, 4) > 0
+            st = bf.stats()
+            assert st["dict_mismatches"] == 0
+            assert st["dict_checked"] == 2 * sum(max(0, len(x) - k + 1) for x in bf.state()[0]) > 0
+        monkeypatch.setenv("SBL_TEST_CORRUPT_MARK", "12345")
+        bf.restore_state()
+        bf.simplify_stage(25, 150, 4)
+        assert 1 <= bf.stats()["dict_mismatches"] <= 2
+    finally:
+        bf.close()
 
 
 def test_config3_full_size_fine_cascade_matches_reference():

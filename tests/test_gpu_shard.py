@@ -57,12 +57,71 @@ def test_sharded_equals_single_gpu_and_reports_exchange():
     assert sum(s["exchange_bytes"] for s in st) < 16 * (N // 2) + 40 * st[0]["instances"] + (1 << 20)
 
 
-def test_long_k_is_replicated_not_sharded():
+LONGK = [v for v in VECS if v["name"] in ("real/hpylori_loose", "real/hpylori_fine", "synth/strains4_100k_fine")]
+LONGK_SMALL = [v for v in VECS if v["name"].startswith("small/") and _max_k(v) > 32 and _bulges(v) < 400][:12]
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+@pytest.mark.parametrize("v", LONGK, ids=[v["name"] for v in LONGK])
+def test_sharded_long_k_matches_reference_genomes(v, nranks):
+    """k > 32 (exact rank doubling) split over the attached GPUs (csrc/longk.hip: sharded rank doubling): the -s loose / -s fine
+    cascades of the reference (k = 100 .. 5000) through 2, 3 and 5 virtual ranks, every output identical on every rank"""
+    V.replay(v, _sharded(nranks))
+
+
+@pytest.mark.parametrize("v", LONGK_SMALL, ids=[v["name"] for v in LONGK_SMALL])
+def test_sharded_long_k_matches_reference_small(v):
+    # tiny inputs: slices shorter than the halo, empty slices, records shorter than k
+    V.replay(v, _sharded(3))
+    V.replay(v, _sharded(5))
+
+
+def test_long_k_is_sharded_not_replicated(monkeypatch):
+    """With a communicator attached the k > 32 enumeration is ONE distributed job: every rank sorts about 1 / R of the suffixes and the
+    ranks exchange 12 + 8 B per active suffix and round; SBL_LONGK_REPLICATED=1 brings back the replicated run (same result, no bytes)."""
     from sibelia_amd import BlockFinder, workloads as W
     seqs = W.gen_strains(L0=30_000, n=3, seed=4, inv_min=500, inv_max=2000)
-    one, many = BlockFinder(seqs, device=0), _sharded(2)(seqs)
+    one, many = BlockFinder(seqs, device=0), _sharded(4)(seqs)
+    for k in (33, 64, 100, 500):
+        a, b = one.enumerate(k), many.enumerate(k)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        st = many.stats()
+        assert all(s["exchange_bytes"] > 0 for s in st), "the long-k enumeration did not exchange anything: replicated?"
+        nsuf = 2 * (sum(len(s) for s in seqs) + len(seqs) + 1) - 1 + k
+        rounds = max(1, int(np.log2(k)) - 3)
+        assert sum(s["exchange_bytes"] for s in st) < (20 * rounds + 12 + 8) * nsuf + (1 << 16)      # 20 B per suffix and round at most
+    assert one.simplify_stage(100, 500, 4) == many.simplify_stage(100, 500, 4)
+    (sa, pa), (sb, pb) = one.state(), many.state()
+    assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    monkeypatch.setenv("SBL_LONGK_REPLICATED", "1")
     a, b = one.enumerate(64), many.enumerate(64)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(s["exchange_bytes"] == 0 for s in many.stats())
+
+
+def test_sharded_config5_shape_matches_oracle():
+    # config 5 shape (random DNA in 4 records, k = 5000: nearly every suffix is unique after h = 16) through 3 virtual ranks
+    from sibelia_amd import workloads as W
+    from oracle.oracle import Oracle
+    seqs = W.longk_case(4_000_000, 4)
+    many, orc = _sharded(3)(seqs), Oracle(seqs)
+    a, b = many.enumerate(5000), orc.enumerate(5000)
+    assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert many.simplify_stage(5000, 15000, 4) == orc.simplify_stage(5000, 15000, 4) == 1
+    (sa, pa), (sb, pb) = many.state(), orc.state()
+    assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+
+
+def test_rccl_transport_single_rank_long_k():
+    # the RCCL code path of the sharded rank doubling (grouped ncclSend / ncclRecv to self) on the one GPU available here
+    from sibelia_amd import BlockFinder, workloads as W
+    from sibelia_amd.api import comm_unique_id
+    seqs = W.gen_strains(L0=60_000, n=4, seed=8, inv_min=2000, inv_max=8000)
+    one, rc = BlockFinder(seqs, device=0), BlockFinder(seqs, device=0)
+    rc.attach_rccl(0, 1, comm_unique_id())
+    a, b = one.enumerate(100), rc.enumerate(100)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    rc.detach()
 
 
 def test_rccl_transport_single_rank():
