@@ -278,7 +278,7 @@ def main():
             "config": {"workload": "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1, 1%% SNP, indels, inversions), "
                                    "k=%d D=%d maxIterations=%d, one full stage" % (a.strains, a.L0 / 1e6, a.k, a.D, a.iters),
                        "strand_kmers_per_gpu": N,
-                       "parallelism": ("1 job: enumeration sharded by k-mer hash prefix over %d GPU(s) (RCCL all-to-all), simplification replicated" % world)
+                       "parallelism": ("1 job: enumeration sharded by k-mer hash prefix over %d GPU(s) (RCCL all-to-all), read-only simplification phases (snapshots, probes) shared out with all-gathered verdict bytes, commits replicated" % world)
                        if a.shard_enum else ("replicas (x%d), one job per GPU" % world if world > 1 else "1 GPU"),
                        "exchange_ms": st["exchange_ms"], "exchange_bytes_rank0": st["exchange_bytes"],
                        "bulges": bulges, "bif_ids": st["bif_count"], "instances": st["instances"],
@@ -303,6 +303,10 @@ def main():
             out["rccl_ranks"] = world
             out["exchange_ms"] = st["exchange_ms"]
             out["exchange_bytes"] = st["exchange_bytes"]
+            # read-only simplification phases (snapshots, probes) shared out over the ranks, verdict bytes all-gathered; commits replicated
+            out["simplification_split"] = {"ranks_sharing_read_only_phases": st["ro_ranks"], "verdict_allgather_ms": st["verdict_ms"], "verdict_bytes_rank0": st["verdict_bytes"],
+                                           "probe_ms_rank0": agg.get("probe_ms", 0.0) / a.steps, "snapshot_ms_rank0": agg.get("snapshot_ms", 0.0) / a.steps,
+                                           "commit_ms_rank0 (replicated)": agg.get("commit_ms", 0.0) / a.steps, "reserve_ms_rank0 (replicated)": agg.get("reserve_ms", 0.0) / a.steps}
         if replicas is not None:
             out["replicas"] = replicas
         if shard_error:

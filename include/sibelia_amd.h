@@ -80,6 +80,12 @@ typedef struct {
 	 * stage's final graph -- windows whose stored mark was compared with the dictionary of the initial marking, and how many differed
 	 * (a stage with mismatches fails with SBL_ERR_INTERNAL) */
 	uint64_t dict_checked, dict_mismatches;
+	/* read-only simplification phases split over the attached GPUs (snapshots by id range, probes by window share; commits replicated):
+	 * GPUs sharing them (1 = not split), host time inside the verdict all-gathers, bytes this GPU sent (1 B per id per snapshot,
+	 * 1 B per window entry per round) */
+	uint64_t ro_ranks;
+	double verdict_ms;
+	uint64_t verdict_bytes;
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+
 #include "sbl_ctx.h"
+#include "sbl_comm.h"
 #include "kmer_kernels.h"
 #include "simplify_driver.h"
 
@@ -468,13 +471,15 @@ struct MarkStream { const unsigned *elem[2], *id[2], *aux[2]; unsigned n[2]; };
 
 // AnyBulges verdict (see wave_verdict) of every id on the pristine graph; need[id] = 2 (known live) / 0 (clean) / 1 (the LDS
 // table could not decide: the probe of its round does).  Four instances per step, 16 lanes each.
-__global__ void __launch_bounds__(64) k_snapshot_first(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm)
+// plo / phi: the slice of the positional order this GPU looks at (everything, or its share when the read-only phases are split over
+// the attached GPUs: DeviceBackend::snapshot_all)
+__global__ void __launch_bounds__(64) k_snapshot_first(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm, unsigned plo, unsigned phi)
 {
 	__shared__ VerdictTable vt;
 	const unsigned lane = threadIdx.x, sub = lane >> 4, sl = lane & 15u;
 	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);      // XCD-aware positional order, as k_snapshot
-	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
-		if (base + slot >= g.nid) continue;
+	for (unsigned base = plo; base < phi; base += gridDim.x) {
+		if (base + slot >= phi) continue;
 		const unsigned id = perm[base + slot];
 		const unsigned n0 = g.lsize[0][id], n1 = g.lsize[1][id], n = n0 + n1;
 		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
@@ -596,14 +601,14 @@ __global__ void __launch_bounds__(256) k_mark_aux_lin(const unsigned *__restrict
 #define SNAP_MAX_INST 256u
 // AnyBulges verdict of the touched ids (incremental) on the linearised marks; ids with more than SNAP_MAX_INST instances or too
 // many distinct marks for the LDS table get need = 1 (the probe of their round decides).
-__global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm, int incremental)
+__global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream ms, const unsigned *__restrict__ nmark, const unsigned *__restrict__ perm, int incremental, unsigned plo, unsigned phi)
 {
 	__shared__ VerdictTable vt;
 	__shared__ unsigned s_inst[SNAP_MAX_INST];                    // (mark index << 1) | strand of every live instance, list order
 	const unsigned lane = threadIdx.x, sub = lane >> 4, sl = lane & 15u;
 	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
-		if (base + slot >= g.nid) continue;
+	for (unsigned base = plo; base < phi; base += gridDim.x) {
+		if (base + slot >= phi) continue;
 		const unsigned id = perm[base + slot];
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }      // nobody touched it since its verdict was taken: still clean
 		__syncthreads();
@@ -662,7 +667,7 @@ __global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream 
 
 // AnyBulges verdict of every id against the graph at iteration start: one wave per id (64 lanes scan the windows,
 // lane 0 evaluates the Boost-ordered map on the cached marks).
-__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental, const unsigned *__restrict__ perm)
+__global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, unsigned arena_bytes, int incremental, const unsigned *__restrict__ perm, unsigned plo, unsigned phi)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -674,8 +679,8 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 	// Workgroups are dealt to the 8 XCDs round robin (blockIdx & 7): every XCD takes a contiguous eighth of each chunk of
 	// gridDim.x positions of the positional order, so the overlapping windows of neighbouring ids share that XCD's L2.
 	const unsigned per = gridDim.x >> 3, slot = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-	for (unsigned base = 0; base < g.nid; base += gridDim.x) {
-		if (base + slot >= g.nid) continue;
+	for (unsigned base = plo; base < phi; base += gridDim.x) {
+		if (base + slot >= phi) continue;
 		const unsigned id = perm[base + slot];
 		// incremental: an id nobody touched since its verdict was last taken is still clean
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }
@@ -826,14 +831,15 @@ __device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, V
 }
 
 #define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
-__global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live)
+// w0: first window entry of this launch (0, or the start of this GPU's share when the read-only phases are split over the attached GPUs)
+__global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
 	__shared__ VerdictTable vt;
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
-	const unsigned wi = blockIdx.x, lane = threadIdx.x & 63u;
+	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x & 63u;
 	round_stamp(g, 0);
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
@@ -858,9 +864,35 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
 		if (!has) { g.need[id] = 0; g.touch[id] = 0; }             // verdict taken now: clean until somebody touches it again (counted by the next selection, k_select_count)
 		else if (!t.err) g.need[id] = 2;
-		live[wi] = has ? 1 : 0;
+		live[wi] = has ? (t.err ? 2 : 1) : 0;                      // (2: live because undecidable here -- need stays 1; k_apply_probe on the other GPUs)
 	}
 }
+// ---- read-only phases split over the attached GPUs (SURVEY.md 8e "Simplification": all GPUs work on disjoint id ranges against the
+// same snapshot; the commits stay replicated, so the state is identical everywhere and only VERDICTS travel).
+// Snapshot: need[] of a slice of the positional order, packed / unpacked around the all-gather (1 B per id).
+__global__ void __launch_bounds__(256) k_pack_need(const unsigned *__restrict__ perm, const uint8_t *__restrict__ need, unsigned lo, unsigned hi, uint8_t *__restrict__ buf)
+{
+	const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < hi) buf[j] = need[perm[j]];
+}
+__global__ void __launch_bounds__(256) k_unpack_need(const unsigned *__restrict__ perm, const uint8_t *__restrict__ buf, unsigned n, unsigned mylo, unsigned myhi, uint8_t *__restrict__ need)
+{
+	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n && (j < mylo || j >= myhi)) need[perm[j]] = buf[j];
+}
+// Probe: what k_probe did to need / touch for the entries the OTHER GPUs probed (live[] all-gathered, 1 B per window entry), and the
+// lowest order violation any of them saw (trail: one word per rank)
+__global__ void __launch_bounds__(256) k_apply_probe(GraphView g, unsigned nwin, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, const unsigned *__restrict__ trail, unsigned nranks)
+{
+	const unsigned wi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (wi == 0) { unsigned v = BT_NONE; for (unsigned p = 0; p < nranks; p++) v = trail[p] < v ? trail[p] : v; if (v != BT_NONE) atomicMin(&g.ctr[CTR_VIOL], v); }
+	if (wi >= nwin || (wi >= w0 && wi < w1)) return;
+	const unsigned id = g.win[wi];
+	const uint8_t l = live[wi];
+	if (l == 0) { g.need[id] = 0; g.touch[id] = 0; }
+	else if (l == 1 && g.need[id] != 2) g.need[id] = 2;
+}
+__global__ void k_probe_trail(const unsigned *__restrict__ ctr, unsigned *__restrict__ trail, unsigned rank) { trail[rank] = ctr[CTR_VIOL]; }
 
 // The lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window (and runs alone if it is the lowest).
 // out: win[], ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag).
@@ -2157,7 +2189,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
@@ -2329,26 +2361,67 @@ struct DeviceBackend {
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		return (unsigned long long)n * 16 < nid_;
 	}
+	// ---- read-only phases split over the attached GPUs (SURVEY.md 8e, row "Simplification"): the commits are replicated, so the graph is
+	// identical on every GPU before a snapshot and before a probe; each GPU takes the verdicts of ITS share (a slice of the positional
+	// order of the ids / of the window) and the verdict bytes are all-gathered: 1 B per id per snapshot, 1 B per window entry per round.
+	// SBL_REPLICATED_PHASES=1: measurement / test switch, every GPU computes everything (the round-3 behaviour).
+	bool split_ro() const { return c->comm && c->comm->n > 1 && getenv("SBL_REPLICATED_PHASES") == nullptr; }
+	double ro_ms = 0;                                                 // host time inside the verdict collectives
+	void share(uint32_t n, uint32_t *lo, uint32_t *hi) const
+	{
+		const uint32_t R = c->comm->n, r = c->comm->rank;
+		*lo = (uint32_t)((uint64_t)n * r / R); *hi = (uint32_t)((uint64_t)n * (r + 1) / R);
+	}
+	// buf[lo_r, hi_r) of every rank r (element size `es` bytes, n elements in all) to everybody, in place
+	void allgather_shares(char *buf, uint32_t n, size_t es)
+	{
+		SblComm *cm = c->comm;
+		const uint32_t R = cm->n, r = cm->rank;
+		std::vector<size_t> sb(R), so(R), rb(R), ro(R);
+		for (uint32_t p = 0; p < R; p++) {
+			const size_t plo = (size_t)((uint64_t)n * p / R) * es, phi = (size_t)((uint64_t)n * (p + 1) / R) * es;
+			const size_t mlo = (size_t)((uint64_t)n * r / R) * es, mhi = (size_t)((uint64_t)n * (r + 1) / R) * es;
+			sb[p] = p == r ? 0 : mhi - mlo; so[p] = mlo;
+			rb[p] = p == r ? 0 : phi - plo; ro[p] = plo;
+			if (p != r) c->stats.verdict_bytes += mhi - mlo;
+		}
+		const auto t0 = std::chrono::steady_clock::now();
+		try { cm->alltoallv(c, buf, sb.data(), so.data(), buf, rb.data(), ro.data()); }
+		catch (...) { cm->abort_peers(); throw; }
+		ro_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	}
 	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		HIP_TRY(hipEventRecord(ev[6], c->stream));
+		uint32_t plo = 0, phi = nid_;
+		const bool split = split_ro();
+		if (split) share(nid_, &plo, &phi);
 		if (!incremental && first_stream) {
 			// iteration 1 (also after a replay: the checkpoint restored is the pristine graph): stream over the position-ordered marks
 			MarkStream ms;
 			for (int t = 0; t < 2; t++) { ms.elem[t] = c->d_melem[t].as<unsigned>(); ms.id[t] = c->d_mid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = c->nmarks[t]; }
 			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
-			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>());
+			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), plo, phi);
 		} else if (incremental && later_stream && !few_touched()) {
 			// iterations 2 ..: the same stream over the marks of the current graph in list order
 			st->nmark.ensure((size_t)cap_n * 4);
 			MarkStream ms;
 			linearise_marks(ms);
-			k_snapshot_stream<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), 1);
+			k_snapshot_stream<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), 1, plo, phi);
 		} else
-		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>());
-		HIP_TRY(hipEventRecord(ev[7], c->stream));
+		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>(), plo, phi);
 		HIP_TRY(hipGetLastError());
+		if (split) {
+			// the verdict bytes of my share of the positional order to everybody; after a snapshot no id is "touched" any more, anywhere
+			st->robuf.ensure((size_t)nid_ + 64);
+			if (phi > plo) k_pack_need<<<(phi - plo + 255) / 256, 256, 0, c->stream>>>(st->perm.as<unsigned>(), st->need.as<uint8_t>(), plo, phi, st->robuf.as<uint8_t>());
+			allgather_shares(st->robuf.as<char>(), nid_, 1);
+			if (nid_) k_unpack_need<<<(nid_ + 255) / 256, 256, 0, c->stream>>>(st->perm.as<unsigned>(), st->robuf.as<uint8_t>(), nid_, plo, phi, st->need.as<uint8_t>());
+			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipEventRecord(ev[7], c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		float ms = 0;
 		HIP_TRY(hipEventElapsedTime(&ms, ev[6], ev[7]));
@@ -2439,7 +2512,20 @@ struct DeviceBackend {
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		begin_round();
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
-		k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>());
+		if (split_ro()) {
+			// my share of the window; live[] of the other shares and the lowest order violation anybody saw come back in two small all-gathers
+			uint32_t w0 = 0, w1 = nwin;
+			share(nwin, &w0, &w1);
+			const uint32_t R = c->comm->n;
+			st->robuf.ensure((size_t)R * 4 + 64);
+			if (w1 > w0) k_probe<<<w1 - w0, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), w0);
+			k_probe_trail<<<1, 1, 0, c->stream>>>(st->ctr.as<unsigned>(), st->robuf.as<unsigned>(), c->comm->rank);
+			HIP_TRY(hipGetLastError());
+			allgather_shares(st->live.as<char>(), nwin, 1);
+			allgather_shares(st->robuf.as<char>(), R, 4);
+			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<unsigned>(), R);
+		} else
+			k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), 0u);
 		probed_nwin = nwin;                                          // (the next selection counts what this probe retired)
 		HIP_TRY(hipGetLastError());
 	}
@@ -2529,7 +2615,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -2858,6 +2944,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	c->stats.bulges = rep.bulges; c->stats.iterations = rep.iterations; c->stats.rounds = rep.rounds; c->stats.replays = rep.replays; c->stats.grow_replays = rep.grow_replays;
 	c->stats.snapshot_ms = be.snapshot_ms; c->stats.reserve_ms = be.reserve_ms; c->stats.commit_ms = be.commit_ms; c->stats.probe_ms = be.probe_ms;
 	c->stats.commit_event_ms = be.commit_event_ms; c->stats.commit_event_launches = be.commit_event_launches;
+	c->stats.verdict_ms = be.ro_ms; c->stats.ro_ranks = be.split_ro() ? c->comm->n : 1;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
 	if (be.prof) {
 		unsigned long long z[16];

@@ -124,6 +124,35 @@ def test_rccl_transport_single_rank_long_k():
     rc.detach()
 
 
+def test_read_only_simplification_phases_are_split_over_the_ranks(monkeypatch):
+    """SURVEY.md 8e, row "Simplification": the commits of the ordered rounds stay replicated (bit-identical state everywhere), the
+    read-only phases -- the AnyBulges snapshots of an iteration and the probe of every round -- are shared out: each rank takes the
+    verdicts of its share of the ids / of the window and the verdict bytes are all-gathered (1 B per id per snapshot, 1 B per window
+    entry per round).  Same result as one GPU, on every rank; SBL_REPLICATED_PHASES=1 brings back round 3's behaviour."""
+    from sibelia_amd import BlockFinder, workloads as W
+    seqs = W.gen_strains(L0=300_000, n=6, seed=5, inv_min=3000, inv_max=12000)
+    one, many = BlockFinder(seqs, device=0), _sharded(4)(seqs)
+    one.save_state()
+    for bf in many.ranks:
+        bf.save_state()
+    want = one.simplify_stage(25, 150, 4)
+    assert many.simplify_stage(25, 150, 4) == want
+    (sa, pa), (sb, pb) = one.state(), many.state()
+    assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    st = many.stats()
+    assert all(s["ro_ranks"] == 4 and s["verdict_bytes"] > 0 and s["replays"] == 0 for s in st)
+    assert all(s["rounds"] == st[0]["rounds"] and s["transactions"] == st[0]["transactions"] for s in st)
+    # 1 B per id and snapshot + 1 B per window entry and round, sent to 3 peers
+    nid, rounds, iters = st[0]["bif_count"], st[0]["rounds"], st[0]["iterations"]
+    assert sum(s["verdict_bytes"] for s in st) <= 3 * (iters * (nid + 4) + rounds * (4 * 14336 + 4 * 4 + 4))
+    monkeypatch.setenv("SBL_REPLICATED_PHASES", "1")
+    for bf in many.ranks:
+        bf.restore_state()
+    assert many.simplify_stage(25, 150, 4) == want
+    assert many.state()[0] == sa
+    assert all(s["ro_ranks"] == 1 and s["verdict_bytes"] == 0 for s in many.stats())
+
+
 def test_rccl_transport_single_rank():
     # the RCCL code path (grouped ncclSend/ncclRecv to self + ncclAllGather) on the one GPU available here
     from sibelia_amd import BlockFinder, workloads as W
