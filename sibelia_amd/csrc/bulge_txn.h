@@ -62,6 +62,9 @@ struct GraphView {
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
+	uint32_t probe_pre;                 // the probe of a round first looks at the endChars alone (simplify.hip: probe_endchars)
+	uint32_t lazy_map;                  // the kernels' AnyBulges logs its map insertions and builds the Boost-ordered map only for calls with >= 2 groups (ABuild::lazy)
+	uint32_t test_lazy_map;             // tests/hostsim: bt_any_bulges (one thread) builds its map lazily too (ABuild::lazy), look-ups by linear search
 	// start stamps of the round kernels (device wall clock; simplify.hip: DeviceBackend::stamp_*): 4 slots per round, nullptr = off
 	unsigned long long *tstamp; uint32_t tslot;
 	// the separators' slots (ascending; they never move during a stage) and the number of original slots: a walk that starts at an
@@ -348,12 +351,18 @@ __host__ __device__ inline void bt_sort_u32(uint32_t *a, uint32_t n)
 struct AnyBulgesOut { uint32_t ngroups; uint32_t *grp_off; uint32_t *grp_mem; };
 
 // AnyBulges under construction: the Boost-ordered map + per-entry member lists (a log of instances chained per entry)
+// lazy: the iteration order of the reference's unordered_map only matters when a call has TWO OR MORE bulge groups (8.6 % of the
+// bulge-bearing calls on 8 strains, 0.2 % on two) -- a single group is a single group in any order.  A lazy build only logs the
+// operator[] insertions (entry index = position in the log, which is the node index bm_insert would hand out) and bt_ab_finish
+// replays them through the Boost restatement when there is more than one group: the same sequence of insertions, hence the same
+// bucket list, hence the same order.  (The map was 16 % of a transaction: ~25 insertions of ~40 dependent LDS operations each, on one lane.)
 struct ABuild {
 	BoostMap m;
 	char *echar;
 	uint32_t *mhead, *mtail, *mcnt, *log_inst, *log_next;
 	uint32_t logcap, nlog;
 	bool any;
+	bool lazy;
 };
 
 struct BulgeWork {
@@ -769,14 +778,16 @@ __host__ __device__ inline bool bt_ab_prepare(Txn &t, BulgeWork &w, uint32_t cap
 	a.log_inst = (uint32_t *)A(a.logcap * 4); a.log_next = (uint32_t *)A(a.logcap * 4);
 	if (t.err) return false;
 	m.size = 0; m.cap = cap; m.bc = 0; m.bcap = bcap; m.first = -1; m.started = false;
-	a.nlog = 0; a.any = false;
+	a.nlog = 0; a.any = false; a.lazy = false;
 	return true;
 }
 // id b is reached by instance i and has no entry yet: operator[] creates it.  Returns the entry or -1 (scratch exhausted).
 __host__ __device__ inline int32_t bt_ab_insert(Txn &t, BulgeWork &w, uint32_t i, uint32_t b)
 {
 	ABuild &a = w.abb;
-	int32_t kt = bm_insert(a.m, b);
+	int32_t kt;
+	if (a.lazy) { if (a.m.size >= a.m.cap) kt = -1; else { kt = (int32_t)a.m.size++; a.m.key[kt] = b; } }
+	else kt = bm_insert(a.m, b);
 	if (kt < 0 || a.nlog >= a.logcap) { t.err |= BT_ERR_SCRATCH; return -1; }
 	a.echar[kt] = w.endc[i];
 	a.log_inst[a.nlog] = i; a.log_next[a.nlog] = BT_NONE;
@@ -800,6 +811,17 @@ __host__ __device__ inline bool bt_ab_finish(Txn &t, BulgeWork &w)
 	BoostMap &m = a.m;
 	if (!a.any) return false;
 	uint32_t ng = 0, total = 0;
+	if (a.lazy) {
+		int32_t only = -1;
+		for (uint32_t p = 0; p < m.size; p++) if (a.mcnt[p] > 1) { ng++; total += a.mcnt[p]; only = (int32_t)p; }
+		if (ng >= 2) {                                    // the order matters: the logged insertions through the Boost restatement, in order
+			const uint32_t n = m.size;
+			m.size = 0;
+			for (uint32_t i = 0; i < n; i++) if (bm_insert(m, m.key[i]) != (int32_t)i) { t.err |= BT_ERR_SCRATCH; return false; }
+		} else { m.first = only; if (only >= 0) m.nxt[only] = -1; }
+		a.lazy = false;
+		ng = 0; total = 0;
+	}
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (a.mcnt[p] > 1) { ng++; total += a.mcnt[p]; }
 	w.ab.grp_off = (uint32_t *)t.alloc2((ng + 1) * 4);
 	w.ab.grp_mem = (uint32_t *)t.alloc2(total * 4);
@@ -823,6 +845,7 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	for (uint32_t i = 0; i < n; i++) marks += w.wmn[i];
 	if (!bt_ab_prepare(t, w, marks)) return false;
 	ABuild &a = w.abb;
+	a.lazy = t.g.test_lazy_map != 0 && !verdict_only;      // (tests/hostsim: the lazy build of the kernels' wave_any_bulges, with a linear search as its shadow table)
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
 		const uint64_t *mk = w.wmk + (size_t)i * w.mks;
@@ -830,7 +853,9 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 		for (uint32_t j = 0; j < nm; j++) {
 			uint32_t b = (uint32_t)mk[j];
 			if ((uint32_t)(mk[j] >> 32) >= lim || b == start) break;
-			int32_t kt = bm_find(a.m, b);
+			int32_t kt = -1;
+			if (a.lazy) { for (uint32_t x = 0; x < a.m.size; x++) if (a.m.key[x] == b) { kt = (int32_t)x; break; } }
+			else kt = bm_find(a.m, b);
 			if (kt < 0) { if (bt_ab_insert(t, w, i, b) < 0) return false; }
 			else if (a.echar[kt] != w.endc[i]) {
 				if (!bt_ab_append(t, w, i, kt)) return false;

@@ -109,6 +109,13 @@ __global__ void __launch_bounds__(256) k_max_instances(const unsigned *__restric
 	if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// WSYNC(): synchronising the lanes of a ONE-wave workgroup (every kernel of the ordered rounds except k_reserve runs one wave per
+// transaction).  Round 4 suspected the fence of __syncthreads() -- s_waitcnt vmcnt(0) lgkmcnt(0), a full memory round trip for stores nobody
+// else waits for -- behind the 583 vmcnt(0) waits of k_commit and replaced it by a wavefront-scope fence + lgkmcnt(0).  The ISA did not
+// change (593 -> 592): with __launch_bounds__(64) the compiler already knows that workgroup scope IS wavefront scope and emits neither a
+// barrier nor a wait for it.  The vmcnt(0) waits are data dependencies and FLAT accesses; the macro stays as a marker of intent.
+#define WSYNC() __syncthreads()
+
 // ------------------------------------------------------------------------------------------- SimplifyGraph kernels
 // Separators by SLOT.  A walk stops before a separator; it used to recognise one by its character -- a load of its own per element
 // (one in four or five of a neighbourhood walk's loads, and what a round kernel costs is the number of memory instructions it issues).
@@ -210,11 +217,11 @@ __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork
 {
 	const unsigned h0 = g.head[0][t.id], h1 = g.head[1][t.id];              // in flight while lane 0 lays the scratch out
 	if (lane == 0) ok = bt_setup(t, w, lite, false) && !t.err ? 1 : 0;
-	__syncthreads();
+	WSYNC();
 	if (!ok) return false;
 	unsigned m = wave_list_positions(g, h0, h1, w, lane);
 	if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; ok = 0; }          // cannot happen on a consistent graph
-	__syncthreads();
+	WSYNC();
 	return ok != 0;
 }
 
@@ -435,7 +442,7 @@ __device__ __forceinline__ int wave_verdict(const GraphView &g, const BulgeWork 
 {
 	if (!table_ready) {                                                // (multi-wave callers clear the table before their own barrier)
 		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-		__syncthreads();
+		WSYNC();
 	}
 	unsigned distinct = 0;                                             // occupied slots (homologous instances repeat the same ids)
 	for (unsigned i = 0; i < w.n; i++) {
@@ -484,9 +491,16 @@ __global__ void __launch_bounds__(64) k_snapshot_first(GraphView g, MarkStream m
 		const unsigned n0 = g.lsize[0][id], n1 = g.lsize[1][id], n = n0 + n1;
 		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
 		const unsigned h0 = g.head[0][id], h1 = g.head[1][id];                     // initial lists: runs of consecutive nodes (k_build_lists)
-		__syncthreads();
+		{	// a group only gets a second member from an instance with a DIFFERENT endChar (see probe_endchars): one character per instance first
+			unsigned bits = 0;
+			for (unsigned i = lane; i < n; i += 64) { const unsigned s = i >= n0 ? 1u : 0u, nd = s ? h1 + (i - n0) : h0 + i; bits |= ms.aux[s][nmark[nd]] >> 24; }
+#pragma unroll
+			for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d);
+			if (__popc(bits) <= 1) { if (lane == 0) g.need[id] = 0; continue; }
+		}
+		WSYNC();
 		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-		__syncthreads();
+		WSYNC();
 		bool found = false, undecided = false;
 		unsigned distinct = 0;
 		for (unsigned ib = 0; ib < n && !found && !undecided; ib += 4) {
@@ -611,7 +625,7 @@ __global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream 
 		if (base + slot >= phi) continue;
 		const unsigned id = perm[base + slot];
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }      // nobody touched it since its verdict was taken: still clean
-		__syncthreads();
+		WSYNC();
 		if (lane == 0) g.touch[id] = 0;
 		// ---- ListPositions: + list then - list, live nodes only (64 nodes per step where the list is a run of consecutive nodes)
 		const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nmark, [&](unsigned off, unsigned, unsigned s, unsigned, unsigned mj) {
@@ -619,8 +633,16 @@ __global__ void __launch_bounds__(64) k_snapshot_stream(GraphView g, MarkStream 
 		});
 		if (n < 2) { if (lane == 0) g.need[id] = 0; continue; }
 		if (n > SNAP_MAX_INST) { if (lane == 0) g.need[id] = 1; continue; }
+		WSYNC();
+		{	// endChars first (see probe_endchars): all the same, or none at all => clean
+			unsigned bits = 0;
+			for (unsigned i = lane; i < n; i += 64) { const unsigned packed = s_inst[i]; bits |= ms.aux[packed & 1u][packed >> 1] >> 24; }
+#pragma unroll
+			for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d);
+			if (__popc(bits) <= 1) { if (lane == 0) g.need[id] = 0; continue; }
+		}
 		for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-		__syncthreads();
+		WSYNC();
 		bool found = false, undecided = false;
 		unsigned distinct = 0;
 		for (unsigned ib = 0; ib < n && !found && !undecided; ib += 4) {
@@ -684,13 +706,13 @@ __global__ void __launch_bounds__(64) k_snapshot(GraphView g, uint8_t *arena, un
 		const unsigned id = perm[base + slot];
 		// incremental: an id nobody touched since its verdict was last taken is still clean
 		if (incremental && !g.touch[id]) { if (lane == 0) g.need[id] = 0; continue; }
-		__syncthreads();
+		WSYNC();
 		if (lane == 0) { g.touch[id] = 0; t.init(g, id, 0, 0, mine, arena_bytes); t.fscr = fast; t.fscr_cap = sizeof fast; }
-		__syncthreads();
+		WSYNC();
 		wave_setup(g, t, w, true, lane, ok);
 		if (ok) {
 			wave_scan_all(g, w, lane, 0, 0, 0, id);
-			__syncthreads();
+			WSYNC();
 		}
 		int verdict = ok ? wave_verdict(g, w, vt, lane) : 0;
 		if (lane == 0) {
@@ -820,7 +842,7 @@ __device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, V
 			int v = wave_probe_window(g, b[j], dir[j], ws, vt, lane, id, tid, distinct);
 			if (v == -2) {                                                  // a link break inside the window (an earlier collapse): the generic pair
 				wave_scan_instance(g, w, i + j, lane, 0, tid, 3, id, &b[j]);
-				__syncthreads();
+				WSYNC();
 				if (w.mk_overflow) return -1;                               // more marks than the LDS list holds: the generic path decides
 				v = wave_verdict_instance(g, w, vt, lane, i + j, distinct);
 			}
@@ -832,6 +854,53 @@ __device__ __forceinline__ int probe_windows(const GraphView &g, BulgeWork &w, V
 
 #define PROBE_WAVES 1u                       // waves per probed id (windows dealt out to them, wave 0 takes the verdict); more than one did not pay: most entries are cheap
 // w0: first window entry of this launch (0, or the start of this GPU's share when the read-only phases are split over the attached GPUs)
+// ---- endChar pre-pass of a probe.  AnyBulges can only give a group its second member when two instances of the id have DIFFERENT
+// endChars (bulgeremoval.cpp:192-199: a branch is appended where visit[b].endChar != endChar[i]); an id whose instances all continue
+// with the same character -- most ids next to a collapse do: the column at offset k carries no SNP in any strain 92 % of the time --
+// is clean whatever its windows hold.  endChar needs the first k + 1 steps of a window only: one block of 64 slots and two arrays
+// (+ the write stamps for the order check of what was read) instead of three blocks and four arrays per window, eight windows in flight.
+// Returns 1: provably clean; 0: the full probe decides (different endChars, a link break inside the first k + 1 steps, k >= 63).
+__device__ __forceinline__ int probe_endchars(const GraphView &g, const BulgeWork &w, unsigned lane, unsigned id, unsigned tid)
+{
+	const unsigned n = w.n, k = g.k;
+	if (k >= 63u) return 0;
+	const unsigned long long want = (1ull << (k + 1)) - 1ull;
+	unsigned mask = 0;
+	bool viol = false;
+	for (unsigned i0 = 0; i0 < n; i0 += 8) {
+		unsigned sel[8], dir[8], chv[8], lnk[8], wmv[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) { const unsigned x = i0 + j < n ? i0 + j : i0; sel[j] = ldx(&w.sel[x]); dir[j] = ldx(&w.start[x]) & 1u; }
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const bool inr = lane <= k && (dir[j] ? lane <= sel[j] : (unsigned long long)sel[j] + lane < g.cap_e);
+			const unsigned c = inr ? (dir[j] ? sel[j] - lane : sel[j] + lane) : sel[j];
+			chv[j] = g.ch[c]; lnk[j] = (dir[j] ? g.pv : g.nx)[c]; wmv[j] = g.wmax[c >> BT_BLOCK_SHIFT];
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			if (i0 + j >= n) break;
+			const bool inr = lane <= k && (dir[j] ? lane <= sel[j] : (unsigned long long)sel[j] + lane < g.cap_e);
+			const unsigned c = dir[j] ? sel[j] - lane : sel[j] + lane;
+			const unsigned prev = __shfl_up(lnk[j], 1);
+			const unsigned long long good = __ballot(inr && (lane == 0 || prev == c)) & want;
+			const unsigned long long sep = __ballot(inr && chv[j] == BT_SEP) & want;
+			const unsigned firstsep = sep ? (unsigned)__builtin_ctzll(sep) : 64u, firstbad = good != want ? (unsigned)__builtin_ctzll(~good) : 64u;
+			const unsigned upto = firstsep < k + 1 ? firstsep : k + 1;      // steps of the walk that were read (the separator itself is never stamped)
+			if (firstbad < upto || (firstbad == firstsep && firstsep < 64u)) return 0;      // the walk leaves consecutive slots before its endChar is known
+			viol |= lane < upto && wmv[j] > tid;
+			if (firstsep <= k) continue;                                    // fewer than k + 1 characters: endChar ' ', the instance takes no part
+			const unsigned craw = __shfl(chv[j], k);
+			const char ec = dir[j] ? bt_comp((char)craw) : (char)craw;
+			mask |= ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
+		}
+	}
+	if (__popc(mask) > 1) return 0;
+	if (__any(viol)) wave_stamp(g, 0, tid, 3, id, 0, tid + 1);
+	return 1;
+}
+
+static_assert(PROBE_WAVES == 1u, "k_probe synchronises its lanes with WSYNC(): one wave per workgroup");
 __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0)
 {
 	__shared__ Txn t;
@@ -845,17 +914,18 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
 	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }
-	__syncthreads();
+	WSYNC();
 	wave_setup(g, t, w, true, lane, ok);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
-	__syncthreads();
+	WSYNC();
 	// the windows go straight into the verdict table, a batch at a time (probe_windows)
 	int verdict = 0;
+	if (ok && g.probe_pre && probe_endchars(g, w, lane, id, tid)) ok = 0;      // every instance continues with the same character: clean (verdict stays 0)
 	if (ok) {
 		verdict = probe_windows(g, w, vt, lane, id, tid);
 		if (verdict < 0) {                                                // undecided by the table: every window is needed
 			for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, 0, tid, 3, id);
-			__syncthreads();
+			WSYNC();
 		}
 	}
 	if (lane == 0) {
@@ -948,8 +1018,11 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsig
 	__syncthreads();
 	if (threadIdx.x == 0) { sel[8 + blockIdx.x] = s_cnt; if (s_ret) atomicAdd(&g.ctr[CTR_COMMITTED], s_ret); }
 }
+// post / post_seq: the last chunk also POSTS the counter block to the host (mapped pinned memory, fine-grained: plain stores cross
+// PCIe) followed by a sequence number the host polls -- the round's counters and the next window arrive without a device-to-host copy
+// kernel and without a stream synchronisation (the copy kernel was ~6 us and the wake-up after it ~23 us of idle GPU per round).
 __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsigned *__restrict__ sel, unsigned *__restrict__ win, unsigned lo, unsigned limit, unsigned W,
-                                                              unsigned chunk0, unsigned chunk, unsigned nchunks)
+                                                              unsigned chunk0, unsigned chunk, unsigned nchunks, volatile unsigned *post, unsigned post_seq)
 {
 	__shared__ unsigned s_wave[SEL_THREADS / 64], s_prefix, s_last;
 	const unsigned bigid = sel[0], per = chunk / SEL_THREADS, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1009,6 +1082,14 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
 		g.ctr[CTR_LO] = first == SBL_NONE ? lo : first;
 		g.ctr[CTR_PUSHED] = solo;
 		sel[0] = SBL_NONE; sel[1] = SBL_NONE; sel[2] = 0; sel[3] = 0;      // ready for the next selection (stream order)
+	}
+	if (s_last && post) {
+		__syncthreads();
+		__threadfence();
+		for (unsigned i = threadIdx.x; i < CTR_COUNT; i += SEL_THREADS) post[i] = __hip_atomic_load(&g.ctr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__threadfence_system();
+		__syncthreads();
+		if (threadIdx.x == 0) { post[CTR_COUNT] = post_seq; __threadfence_system(); }
 	}
 }
 
@@ -1324,8 +1405,16 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 	if (b < g.nid) { g.touch[b] = 1; if (b > t.id) g.need[b] = 1; }
 }
 
-__device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv)
+__device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
+__device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
+__device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
+#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
+#define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
+#define PC_T0() unsigned long long pc_t = prof ? __builtin_readcyclecounter() : 0ull
+#define PC_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - pc_t); pc_t = n_; } } while (0)
+__device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv, const int prof = 0)
 {
+	PC_T0();
 	const unsigned k = g.k, ws = w.ws;
 	const unsigned src = w.c_src, dS = w.c_dS, tgt = w.c_tgt, dT = w.c_dT;
 	const unsigned d = w.start[tgt] & 1u, opp = d ^ 1u, ds = w.start[src] & 1u;
@@ -1345,7 +1434,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		if (bb != BT_NONE) { unsigned o = nlf + __popcll(mb & lt); w.lf[2 * o] = i; w.lf[2 * o + 1] = bb; wave_erase(g, t, d, eb, stampv, bb, nb2); }
 		nlb += __popcll(ma); nlf += __popcll(mb);
 	}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(9);
 	// ---- second loop: every own-strand mark after the target start and every opposite-strand mark over k + dT elements
 	for (unsigned i0 = 0; i0 < k + dT; i0 += 64) {
 		unsigned i = i0 + lane;
@@ -1356,7 +1446,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			wave_erase(g, t, opp, e, stampv, b1, n1);
 		}
 	}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(10);
 	// ---- DNASequence::Replace in + coordinates: P(j) = j-th element of the old span, C(j) = j-th new character.
 	// All lanes: character writes, the new elements of an insertion and the position interpolation (the sequence
 	// acc += ssize of dnasequence.cpp:221-227 is replayed in registers, every lane keeps the value of its own step).
@@ -1377,7 +1468,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		}
 		s_newbase = newbase;
 	}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(11);
 	if (t.err) return;
 	{
 		const unsigned nb = s_newbase;
@@ -1418,7 +1510,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			}
 		}
 	}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(12);
 	if (t.err) return;
 	const unsigned newbase = s_newbase;
 	// element at step s of the target walk AFTER the replacement
@@ -1441,7 +1534,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		if (b2 != BT_NONE) { w.act[3 * o] = opp; w.act[3 * o + 1] = newT(dS + k - 1 - i); w.act[3 * o + 2] = b2; }
 		nact += __popcll(m1) + __popcll(m2);
 	}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(13);
 	// nodes for every AddPoint below in one allocation; the ids they touch are stamped by all lanes at once
 	__shared__ unsigned s_nodebase;
 	const unsigned total = nlb + nlf + nact;
@@ -1455,7 +1549,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			unsigned b = x < nlb ? w.lb[2 * x + 1] : x < nlb + nlf ? w.lf[2 * (x - nlb) + 1] : w.act[3 * (x - nlb - nlf) + 2];
 			wave_stamp_id_write(g, stampv, t.tid, t.id, b);
 		}
-	__syncthreads();
+	WSYNC();
+	PC_ADD(14);
 	if (t.err) return;
 	if (total > 64) {
 		if (lane == 0) {
@@ -1516,7 +1611,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 		}
 	}
 	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
-	__syncthreads();
+	WSYNC();
+	PC_ADD(15);
 }
 
 // ---- the caller side of BulgeWork::jscan: next member of [idJ, group end) that is still valid and whose endChar differs from I's
@@ -1526,7 +1622,7 @@ __device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, un
 	const unsigned ge = w.ab.grp_off[w.gi + 1];
 	const char ecI = w.endc[w.ab.grp_mem[w.idI]];
 	unsigned j0 = w.idJ, found = ge;
-	__syncthreads();                                                       // (everybody has read idJ before lane 0 moves it)
+	WSYNC();                                                       // (everybody has read idJ before lane 0 moves it)
 	while (j0 < ge && found == ge) {
 		unsigned m[4], st[4]; char ec[4]; bool in[4];
 #pragma unroll
@@ -1542,7 +1638,7 @@ __device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, un
 		j0 += 256;
 	}
 	if (lane == 0) { w.idJ = found; w.jready = true; }
-	__syncthreads();
+	WSYNC();
 }
 
 // ---- marks-only window scan, one LANE per instance (64 instances in flight): what AnyBulges needs of a window -- mark at step 0,
@@ -1591,11 +1687,11 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 		sh.skey = count_tab ? count_tab : (unsigned *)t.falloc(count_slots * 4);
 		sh.mode = sh.skey ? 1 : 0;
 	}
-	__syncthreads();
+	WSYNC();
 	if (sh.mode) {
 		// ---- pass 1: number of distinct ids that can get an entry
 		for (unsigned i = lane; i < count_slots; i += 64) sh.skey[i] = BT_NONE;
-		__syncthreads();
+		WSYNC();
 		unsigned distinct = 0;
 		bool full = false;
 		for (unsigned i = 0; i < n && !full; i++) {
@@ -1623,7 +1719,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 				if (upto < 64) break;
 			}
 		}
-		__syncthreads();
+		WSYNC();
 		if (lane == 0) {
 			t.fscr_used = mark;                                        // the counting set is done
 			if (full) sh.mode = 0;
@@ -1634,20 +1730,21 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 				sh.skey = (unsigned *)t.alloc2((2u << bits) * 4);
 				sh.sval = sh.skey ? sh.skey + (1u << bits) : nullptr;
 				if (!sh.skey || !bt_ab_prepare(t, w, distinct)) sh.mode = -1;
+				else w.abb.lazy = g.lazy_map != 0;                    // log the insertions, build the Boost map only if the call has >= 2 groups (bulge_txn.h: ABuild::lazy)
 			}
 		}
-		__syncthreads();
+		WSYNC();
 	}
 	if (sh.mode < 0) return 0;                                             // t.err is set
 	if (sh.mode == 0) {                                                    // tables do not fit: one thread, map sized by the total number of marks
 		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
-		__syncthreads();
+		WSYNC();
 		return sh.mode == 3;
 	}
 	// ---- pass 2: build the map; lanes skip what changes nothing
 	const unsigned slots = 1u << sh.bits, shift = 32 - sh.bits;
 	for (unsigned i = lane; i < slots; i += 64) { sh.skey[i] = BT_NONE; sh.sval[i] = BT_NONE; }
-	__syncthreads();
+	WSYNC();
 	bool bad = false;
 	for (unsigned i = 0; i < n && !bad; i++) {
 		const char ec = w.endc[i];
@@ -1680,7 +1777,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			unsigned long long ins = __ballot(ev == 1u) >> f;
 			unsigned run = eev == 1u ? (ins == ~0ull ? 64u - f : (unsigned)__builtin_ctzll(~ins)) : 0u;
 			if (lane >= f && lane < f + run) sh.batch[lane - f] = b;
-			__syncthreads();
+			WSYNC();
 			if (lane == 0) {
 				if (eev == 1u) {
 					for (unsigned x = 0; x < run && sh.mode > 0; x++) {
@@ -1693,7 +1790,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 					}
 				} else if (!bt_ab_append(t, w, i, (int)(evl >> 8))) sh.mode = -1;
 			}
-			__syncthreads();
+			WSYNC();
 			if (sh.mode < 0) { bad = true; break; }
 			if (eev == 2u) break;                                          // the instance joined a group: next instance
 			pos += f + run;
@@ -1701,15 +1798,10 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	}
 	if (bad) return 0;
 	if (lane == 0) sh.mode = bt_ab_finish(t, w) ? 3 : 2;
-	__syncthreads();
+	WSYNC();
 	return sh.mode == 3;
 }
 
-__device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
-__device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
-__device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
-#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
-#define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
 
 // One wave per window entry: ownership check on the claim list (64 lanes), then RemoveBulges with lane 0 taking
 // the decisions on the cached windows and all lanes rescanning them after every collapse.
@@ -1729,11 +1821,11 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
 	if (prepass) {
 		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; t.chain = stampv == BT_NONE; }
-		__syncthreads();
+		WSYNC();
 		wave_setup(g, t, w, true, lane, flag);
 		if (flag) {
 			wave_scan_all(g, w, lane, stampv, tid, 1, id);
-			__syncthreads();
+			WSYNC();
 		}
 		int verdict = flag ? wave_verdict(g, w, *reinterpret_cast<VerdictTable *>(fast), lane) : 0;   // the fast scratch is idle in this pass
 		if (lane == 0) {
@@ -1743,24 +1835,24 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			flag = has ? 1 : 0;
 		}
 	}
-	__syncthreads();
+	WSYNC();
 	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0;
 	                 t.tc_cap = 1024; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true; }
-	__syncthreads();
+	WSYNC();
 	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
 	if (flag) {
 		wave_scan_all(g, w, lane, stampv, tid, 2, id);
-		__syncthreads();
+		WSYNC();
 		if (w.mk_overflow) {                                          // more marks in a window than the LDS lists hold: use the arena
-			__syncthreads();
+			WSYNC();
 			if (lane == 0) bt_marks_to_arena(t, w);
-			__syncthreads();
+			WSYNC();
 			if (!t.err) for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
-			__syncthreads();
+			WSYNC();
 		}
 		PH_ADD(1);
 		int any = wave_any_bulges(g, t, w, absh, lane);
@@ -1768,30 +1860,30 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
 		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy; }
-		__syncthreads();
+		WSYNC();
 		PH_ADD(2);
 		while (flag) {
 			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
-			__syncthreads();
+			WSYNC();
 			PH_ADD(3);
 			if (!flag) break;
 			if (flag == 3) { wave_next_j(g, w, lane); continue; }       // large group: the search for the next J, 256 members per step
 			if (flag == 2) {                                             // the loops need these windows as of now
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
-				__syncthreads();
+				WSYNC();
 				if (lane == 0) for (unsigned x = 0; x < nr; x++) w.wep[w.req[x]] = w.epoch;
-				__syncthreads();
+				WSYNC();
 				PH_ADD(8);
 				continue;
 			}
 			if (w.lazy) {
-				wave_collapse(g, t, w, lane, stampv);
+				wave_collapse(g, t, w, lane, stampv, prof);
 				PH_ADD(5);
 				if (t.err) break;
 				wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
 				if (lane == 0) w.epoch++;                                // every cached window is stale until the loops ask for it
-				__syncthreads();
+				WSYNC();
 				PH_ADD(6);
 				continue;
 			}
@@ -1814,7 +1906,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				}
 			}
 			PH_ADD(4);
-			wave_collapse(g, t, w, lane, stampv);
+			wave_collapse(g, t, w, lane, stampv, prof);
 			PH_ADD(5);
 			if (t.err) break;
 			if (lane == 0 && w.c_dT > w.c_dS) {
@@ -1833,20 +1925,20 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			PH_ADD(7);
 			for (unsigned i = 0; i < w.n; i++)
 				if (!selective || (((big ? w.dirty_big[i >> 6] : dirty[i >> 6]) >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
-			__syncthreads();
+			WSYNC();
 			if (w.mk_overflow) {
-				__syncthreads();
+				WSYNC();
 				if (lane == 0) bt_marks_to_arena(t, w);
-				__syncthreads();
+				WSYNC();
 				if (t.err) break;
 				for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
-				__syncthreads();
+				WSYNC();
 			}
 			PH_ADD(8);
 		}
 	}
 	// ---- Cleanup (bifurcationstorage.cpp:33-41) once the loops are over: the erased nodes leave their lists' sizes, all lanes
-	__syncthreads();
+	WSYNC();
 	if (!t.err && t.tc_n) {
 		if (t.tc_n <= t.tc_cap) {
 			for (unsigned x = lane; x < t.tc_n; x += 64) { unsigned v = g.nidst[t.tc_list[x]]; atomicSub(&g.lsize[v & 1u][v >> 1], 1u); }
@@ -1941,10 +2033,10 @@ __global__ void __launch_bounds__(64) k_chain(GraphView g, uint8_t *arena, unsig
 		// an id made pending by the chain itself ends the stretch: its verdict is taken by the next (parallel) probe
 		if (!known_live && done) break;
 		done++;
-		__syncthreads();
+		WSYNC();
 		if (lane == 0) g.big[id] = 0;                                   // the chain always runs in the big arena
 		commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, 0u, id, BT_NONE, 1, !known_live, arena, arena_bytes, prof);
-		__syncthreads();
+		WSYNC();
 		cur = (unsigned long long)id + 1;
 		__threadfence();
 		unsigned stop = lane == 0 ? (g.ctr[CTR_ERR] != 0 || g.ctr[CTR_VIOL] != BT_NONE || g.big[id] != 0) : 0u;   // big: did not even fit the big arena
@@ -1980,44 +2072,44 @@ __device__ __forceinline__ void dense_remove_bulges(const GraphView &g, Txn &t, 
 		t.fscr = fast + DENSE_COUNT_SLOTS * 4; t.fscr_cap = DENSE_FAST_BYTES - DENSE_COUNT_SLOTS * 4;
 		t.tc_cap = 4096; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true;
 	}
-	__syncthreads();
+	WSYNC();
 	wave_setup(g, t, w, false, lane, flag);
 	if (flag) {
 		if (lane == 0) w.epoch = 1;                                        // wep[] = 0: no window has been scanned in full yet
-		__syncthreads();
+		WSYNC();
 		if (w.n >= DENSE_LANE_SCAN_MIN) {
 			for (unsigned i0 = 0; i0 < w.n; i0 += 64) if (i0 + lane < w.n) lane_scan_marks(g, w, i0 + lane);
 		} else {
 			wave_scan_all(g, w, lane, BT_NONE, 0, 0, id);
-			__syncthreads();
+			WSYNC();
 			for (unsigned i = lane; i < w.n; i += 64) w.wep[i] = 1;
 			if (lane == 0) bt_end_chars(t, w);
 		}
-		__syncthreads();
+		WSYNC();
 		int any = wave_any_bulges(g, t, w, absh, lane, true, DENSE_COUNT_SLOTS, count_tab);
 		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = true; w.jscan = true; }
-		__syncthreads();
+		WSYNC();
 		while (flag) {
 			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
-			__syncthreads();
+			WSYNC();
 			if (!flag) break;
 			if (flag == 3) { wave_next_j(g, w, lane); continue; }
 			if (flag == 2) {
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, BT_NONE, 0, 0, id);
-				__syncthreads();
+				WSYNC();
 				if (lane == 0) for (unsigned x = 0; x < nr; x++) w.wep[w.req[x]] = w.epoch;
-				__syncthreads();
+				WSYNC();
 				continue;
 			}
 			wave_collapse(g, t, w, lane, BT_NONE);
 			if (t.err) break;
 			if (lane == 0) w.epoch++;
-			__syncthreads();
+			WSYNC();
 		}
 	}
 	// ---- Cleanup (bifurcationstorage.cpp:33-41)
-	__syncthreads();
+	WSYNC();
 	if (!t.err && t.tc_n) {
 		if (t.tc_n <= t.tc_cap) {
 			for (unsigned x = lane; x < t.tc_n; x += 64) { unsigned v = g.nidst[t.tc_list[x]]; atomicSub(&g.lsize[v & 1u][v >> 1], 1u); }
@@ -2044,9 +2136,9 @@ __global__ void __launch_bounds__(64) k_dense_stage(GraphView g, uint8_t *arena,
 		iter++;
 		for (unsigned id = 0; id < g.nid && !stop; id++) {
 			if (g.lsize[0][id] + g.lsize[1][id] < 2) continue;              // ListPositions < 2: nothing to do (bulgeremoval.cpp:336-337)
-			__syncthreads();
+			WSYNC();
 			dense_remove_bulges(g, t, w, flag, absh, fast, id, arena, arena_bytes);
-			__syncthreads();
+			WSYNC();
 			__threadfence();                                               // list sizes / marks changed through atomics: later plain loads must see them
 			stop = __shfl((int)(lane == 0 ? *(volatile unsigned *)&g.ctr[CTR_ERR] : 0u), 0) != 0;
 		}
@@ -2195,7 +2287,9 @@ struct SimplifyState {
 	DevBuf nmark, maux[2], iota, sel, tstamp;
 	DevBuf lin, elin, lmpos[2], lmid[2], cnt1k, off1k;      // linearised marks of the later snapshots
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
-	unsigned *h_ctr = nullptr;            // pinned
+	unsigned *h_ctr = nullptr;            // pinned, mapped: CTR_COUNT counters + the sequence number of the last post (k_select_write)
+	unsigned *d_hctr = nullptr;           // its device address
+	unsigned post_seq = 0;
 };
 
 struct RestartStage {};      // thrown out of an optimistic attempt that would need a roll-back (DeviceBackend::restore)
@@ -2246,8 +2340,22 @@ struct DeviceBackend {
 		st->rmax.ensure(nres * 4); st->wmax.ensure(nres * 4);
 		g.lock = nullptr; g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
 	}
+	bool posted = false;                                              // the selection in flight posts the counters itself (k_select_write)
 	void read_ctr()
 	{
+		if (posted && sel_pending && !sel_ready) {
+			// the counters of the round and the next window come with the selection's post: poll its sequence number
+			volatile unsigned *seq = st->h_ctr + CTR_COUNT;
+			for (unsigned long long spin = 0;; spin++) {
+				if (*seq == st->post_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); posted = false; return; }
+				if ((spin & 0xFFFF) == 0xFFFF) {                        // every ~65 k polls: is the stream still running?
+					hipError_t e = hipStreamQuery(c->stream);
+					if (e == hipSuccess && *seq != st->post_seq) break;      // finished without posting: fall back to the copy
+					if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(e);
+				}
+			}
+			posted = false;
+		}
 		HIP_TRY(hipMemcpyAsync(st->h_ctr, st->ctr.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
@@ -2459,7 +2567,9 @@ struct DeviceBackend {
 		sel_stamped = true;
 		k_select_count<<<nchunks, SEL_THREADS, 0, c->stream>>>(gs, st->sel.as<unsigned>(), lo, limit, chunk0, chunk, st->live.as<uint8_t>(), probed_nwin);
 		probed_nwin = 0;
-		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks);
+		posted = st->d_hctr != nullptr;
+		if (posted) st->post_seq++;
+		k_select_write<<<nchunks, SEL_THREADS, 0, c->stream>>>(g, st->sel.as<unsigned>(), st->win.as<unsigned>(), lo, limit, W, chunk0, chunk, nchunks, st->d_hctr, st->post_seq);
 		HIP_TRY(hipGetLastError());
 		sel_pending = true; sel_ready = false;
 	}
@@ -2569,7 +2679,12 @@ struct DeviceBackend {
 		read_ctr();
 		if (sel_pending) sel_ready = true;                          // the snapshot holds the selection launched before it as well
 		float ms = 0;
-		if (timed_commit) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); commit_event_ms += ms; commit_event_launches++; timed_commit = false; }
+		if (timed_commit) {
+			hipError_t e = hipEventElapsedTime(&ms, ev[2], ev[3]);      // (the post of the selection behind them has arrived: normally complete)
+			if (e == hipErrorNotReady) { HIP_TRY(hipEventSynchronize(ev[3])); e = hipEventElapsedTime(&ms, ev[2], ev[3]); }
+			HIP_TRY(e);
+			commit_event_ms += ms; commit_event_launches++; timed_commit = false;
+		}
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
 		return r;
@@ -2681,7 +2796,13 @@ void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl
 static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic)
 {
 	hipStream_t s = c->stream;
-	if (!c->simp) { c->simp = new SimplifyState(); HIP_TRY(hipHostMalloc((void **)&c->simp->h_ctr, CTR_COUNT * 4)); }
+	if (!c->simp) {
+		c->simp = new SimplifyState();
+		HIP_TRY(hipHostMalloc((void **)&c->simp->h_ctr, (CTR_COUNT + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+		memset(c->simp->h_ctr, 0, (CTR_COUNT + 16) * 4);
+		if (hipHostGetDevicePointer((void **)&c->simp->d_hctr, c->simp->h_ctr, 0) != hipSuccess) { (void)hipGetLastError(); c->simp->d_hctr = nullptr; }
+		if (getenv("SBL_NO_POST")) c->simp->d_hctr = nullptr;             // measurement switch: copy + synchronise as before
+	}
 	SimplifyState *st = c->simp;
 	DeviceBackend be;
 	be.c = c; be.st = st;
@@ -2830,6 +2951,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	be.g.probe_pre = getenv("SBL_NO_PROBE_PRE") ? 0u : 1u;              // measurement switch: the endChar pre-pass of the probe (probe_endchars)
+	be.g.lazy_map = getenv("SBL_EAGER_MAP") ? 0u : 1u;                  // measurement switch: the Boost-ordered map of AnyBulges built eagerly (round 3)
 	be.g.tstamp = nullptr; be.g.tslot = 0;
 	be.g.sep = c->d_sepidx.as<unsigned>(); be.g.nsep = c->nchr + 1; be.g.norig = (uint32_t)E;
 	if (getenv("SBL_SEP_BY_CHAR")) be.g.sep = nullptr;                   // measurement switch: separators recognised by their character everywhere
@@ -2949,8 +3072,9 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	if (be.prof) {
 		unsigned long long z[16];
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
-		const char *nm[9] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan"};
-		for (int i = 0; i < 9; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
+		const char *nm[16] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan",
+		                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints"};
+		for (int i = 0; i < 16; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 		unsigned long long hh[4][16], mx[2];
 		HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
 		HIP_TRY(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_txn_max), sizeof mx));

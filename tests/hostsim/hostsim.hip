@@ -232,6 +232,7 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 		be.bind();
 		be.g.k = k; be.g.D = D; be.g.nid = bif_count;
 		if (const char *e = getenv("HOSTSIM_LAZY_MIN")) be.g.lazy_min = (uint32_t)atoi(e);      // 1: lazy windows for every transaction
+		if (getenv("HOSTSIM_LAZY_MAP")) be.g.test_lazy_map = 1;                                 // AnyBulges logs its insertions, Boost map only for >= 2 groups
 		// marking loop (reference src/indexedsequence.cpp:49-67): (chr,pos) ascending, front insertion
 		uint32_t nn = 0;
 		for (int s = 0; s < 2; s++) {

@@ -59,6 +59,18 @@ def test_transactions_match_oracle_strains():
     _check(seqs, 25, 150, window=64, order=1)
 
 
+def test_lazy_boost_map_gives_the_same_order(monkeypatch):
+    """AnyBulges' unordered_map restated lazily (bulge_txn.h: ABuild::lazy, what the kernels' wave_any_bulges does): the insertions
+    are only logged and go through the Boost restatement when a call has two or more bulge groups -- cases with many such calls
+    (small alphabets, low k) must come out exactly as with the eager map"""
+    monkeypatch.setenv("HOSTSIM_LAZY_MAP", "1")
+    for seed in SEEDS[:6]:
+        seqs, k, D = W.small_case(seed)
+        _check(seqs, k, D, window=37, order=2)
+    seqs = W.gen_strains(L0=20_000, n=6, seed=17, snp=0.03, inv_min=500, inv_max=2000)
+    _check(seqs, 16, 120, window=512, order=1)
+
+
 def test_small_arena_goes_through_the_big_path():
     seqs, k, D = W.small_case(2)            # k=4: ids with many instances overflow a tiny arena
     st = _check(seqs, k, D, window=16, order=0, arena=1 << 12)
