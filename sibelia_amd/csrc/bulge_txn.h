@@ -32,6 +32,7 @@
 // stage and would otherwise burn the element pool 32 slots at a time (grow + replay of the iteration, again and again).
 #define BT_INSERT_ALIGN 1u
 #define BT_LAZY_MIN 64u           // see BulgeWork::lazy
+#define BT_MSCAN_MIN 6u           // see BulgeWork::mscan
 __host__ __device__ __forceinline__ uint32_t bt_insert_span(uint32_t m) { return (m + BT_INSERT_ALIGN - 1u) & ~(BT_INSERT_ALIGN - 1u); }
 
 // Counter block.  Every counter has a 128-byte line of its own: thousands of workgroups per launch bump them (retired entries,
@@ -62,6 +63,8 @@ struct GraphView {
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
+	uint32_t ab_estimate;               // AnyBulges of ids with more than 32 instances sizes its tables by an estimate instead of a counting pass (simplify.hip)
+	uint32_t jscan_rounds;              // ordered rounds: ids with more than 24 instances hand the search for the next J to 64 lanes (BulgeWork::jscan)
 	uint32_t probe_pre;                 // the probe of a round first looks at the endChars alone (simplify.hip: probe_endchars)
 	uint32_t lazy_map;                  // the kernels' AnyBulges logs its map insertions and builds the Boost-ordered map only for calls with >= 2 groups (ABuild::lazy)
 	uint32_t test_lazy_map;             // tests/hostsim: bt_any_bulges (one thread) builds its map lazily too (ABuild::lazy), look-ups by linear search
@@ -119,14 +122,14 @@ struct Txn {
 		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; tc_list = nullptr; tc_cap = 0; tc_n = 0; defer_cleanup = false; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0;
 	}
 	// ---- scratch
-	__host__ __device__ void *alloc(uint32_t bytes)
+	__host__ __device__ __forceinline__ void *alloc(uint32_t bytes)
 	{
 		uint32_t a = (scr_used + 7u) & ~7u;
 		if (a + bytes > scr_cap || a + bytes < a) { err |= BT_ERR_SCRATCH; return nullptr; }
 		scr_used = a + bytes;
 		return scr + a;
 	}
-	__host__ __device__ void *falloc(uint32_t bytes)
+	__host__ __device__ __forceinline__ void *falloc(uint32_t bytes)
 	{
 		uint32_t a = (fscr_used + 7u) & ~7u;
 		if (!fscr || a + bytes > fscr_cap || a + bytes < a) return nullptr;
@@ -400,6 +403,12 @@ struct BulgeWork {
 	// bt_rb_run hands that search to the caller (returns 3: move idJ to the next candidate of [idJ, group end), or to the end;
 	// then set jready), which the kernels do with 64 lanes x 4 members per step.
 	bool jscan, jready;
+	// MaxBifurcationMultiplicity of the two branches of a bulge (bulgeremoval.cpp:405-407) is one CountBifurcations per bifurcation
+	// INSIDE a branch: a handful of dependent look-ups where bifurcations are sparse, dozens where every other position is one (many
+	// strains).  With mscan set bt_rb_run hands branches with more than BT_MSCAN_MIN marks inside to the caller (returns 4: evaluate
+	// mq_* with all lanes -- one look-up per lane, the same stamps -- into mres[], set mready, call again).
+	bool mscan, mready;
+	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
 	uint32_t *lb, *lf;           // lookBack / lookForward (index, id) pairs
@@ -446,7 +455,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc2(n);
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mready = false;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
@@ -459,7 +468,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.wbf = (uint32_t *)t.alloc(n * w.ws * 4);
 		w.wch = (uint8_t *)t.alloc(n * w.ws);
 		w.wbk = (uint32_t *)t.alloc(n * BT_MAX_BREAKS * 4);
-		w.wnb = (uint32_t *)t.alloc(n * 4);
+		w.wnb = (uint32_t *)t.alloc2(n * 4);          // (fast scratch: the interval tests below start with it)
 		w.wdel = (uint32_t *)t.alloc2(n * 4);
 		if (w.wdel) for (uint32_t i = 0; i < n; i++) w.wdel[i] = 0;
 		w.visit = (uint64_t *)t.alloc2(w.visit_cap * 8);
@@ -556,10 +565,19 @@ __host__ __device__ inline bool bt_overlap_sets(Txn &t, BulgeWork &w, uint32_t i
 	return false;
 }
 // do the first ni steps of window i and the first nj steps of window j share an element?  (-1: too many breaks to tell)
+// two walks that never leave consecutive slots are two intervals that start at the instances' own elements: no look at the cache at all
+__host__ __device__ __forceinline__ bool bt_plain_intervals_meet(const BulgeWork &w, uint32_t i, uint32_t ni, uint32_t j, uint32_t nj)
+{
+	const uint32_t a0 = w.sel[i], b0 = w.sel[j];
+	const uint32_t alo = (w.start[i] & 1u) ? a0 - (ni - 1) : a0, ahi = (w.start[i] & 1u) ? a0 : a0 + (ni - 1);
+	const uint32_t blo = (w.start[j] & 1u) ? b0 - (nj - 1) : b0, bhi = (w.start[j] & 1u) ? b0 : b0 + (nj - 1);
+	return alo <= bhi && blo <= ahi;
+}
 __host__ __device__ inline int bt_windows_intersect(const BulgeWork &w, uint32_t i, uint32_t ni, uint32_t j, uint32_t nj)
 {
 	if (w.wnb[i] > BT_MAX_BREAKS || w.wnb[j] > BT_MAX_BREAKS) return -1;
 	if (!ni || !nj) return 0;
+	if (w.wnb[i] == 0 && w.wnb[j] == 0) return bt_plain_intervals_meet(w, i, ni, j, nj) ? 1 : 0;
 	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
 	const uint32_t *bi = w.wbk + i * BT_MAX_BREAKS, *bj = w.wbk + j * BT_MAX_BREAKS;
 	uint32_t xi = 0;
@@ -583,6 +601,7 @@ __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uin
 {
 	const uint32_t k = t.g.k, ni = di + k, nj = dj + k;
 	if (w.wnb[i] > BT_MAX_BREAKS || w.wnb[j] > BT_MAX_BREAKS) return bt_overlap_sets(t, w, i, di, j, dj);
+	if (w.wnb[i] == 0 && w.wnb[j] == 0) return bt_plain_intervals_meet(w, i, ni, j, nj);
 	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
 	const uint32_t *bi = w.wbk + i * BT_MAX_BREAKS, *bj = w.wbk + j * BT_MAX_BREAKS;
 	// runs of window i: [s0, s1) with s1 = next break (or ni)
@@ -615,6 +634,22 @@ __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i
 		if (c > r) r = c;
 	}
 	return r;
+}
+
+// number of marked steps strictly inside a branch of `distance` steps (what bt_max_mult would look up)
+__host__ __device__ inline uint32_t bt_marks_inside(const BulgeWork &w, uint32_t i, uint32_t distance)
+{
+	uint32_t c = 0, nm = w.wmn[i];
+	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
+	while (c < nm && (uint32_t)(mk[c] >> 32) < distance) c++;
+	return c;
+}
+// the evaluation bt_rb_run asks for with return code 4, one thread
+__host__ __device__ inline void bt_rb_mults(Txn &t, BulgeWork &w)
+{
+	w.mres[0] = bt_max_mult(t, w, w.mq_i, w.mq_di);
+	w.mres[1] = bt_max_mult(t, w, w.mq_j, w.mq_dj);
+	w.mready = true;
 }
 
 // DNASequence::ReplaceDirect, dnasequence.cpp:189-230 (target = first element of the old span in + direction)
@@ -894,10 +929,11 @@ __host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
 	w.jready = true;
 }
 
+// 4 (mscan only): see BulgeWork::mscan (bt_rb_mults is the one-thread form).
 // returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
 // the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards,
 // 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search).
-__host__ __device__ inline int bt_rb_run(Txn &t, BulgeWork &w)
+__host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // (always inline: as a call it takes t / w as generic pointers and spills around itself -- +5 ms per stage when the inliner gave up on it)
 {
 	const uint32_t D = t.g.D;
 	while (w.gi < w.ab.ngroups) {
@@ -935,9 +971,15 @@ __host__ __device__ inline int bt_rb_run(Txn &t, BulgeWork &w)
 						uint32_t dJ = step, dI = (uint32_t)w.visit[lo];
 						if (bt_overlap(t, w, kmerI, dI, kmerJ, dJ)) break;
 						if (t.err) return 0;
+						if (w.mscan && !w.mready && bt_marks_inside(w, kmerI, dI) + bt_marks_inside(w, kmerJ, dJ) > BT_MSCAN_MIN) {
+							w.mq_i = kmerI; w.mq_di = dI; w.mq_j = kmerJ; w.mq_dj = dJ;
+							w.idJ--; w.jready = true;                    // this J again once the caller has the multiplicities (nothing has been decided or counted yet)
+							return 4;
+						}
 						++w.ret;
-						uint32_t imlp = bt_max_mult(t, w, kmerI, dI);
-						uint32_t jmlp = bt_max_mult(t, w, kmerJ, dJ);
+						uint32_t imlp = w.mready ? w.mres[0] : bt_max_mult(t, w, kmerI, dI);
+						uint32_t jmlp = w.mready ? w.mres[1] : bt_max_mult(t, w, kmerJ, dJ);
+						w.mready = false;
 						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
 							w.endc[kmerJ] = w.endc[kmerI];
 							w.c_src = kmerI; w.c_dS = dI; w.c_tgt = kmerJ; w.c_dT = dJ;

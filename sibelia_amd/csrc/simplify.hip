@@ -351,7 +351,7 @@ __device__ __forceinline__ void wave_scan_instance_t(const GraphView &g, const B
 		scan_burst_load(g, s.cur, dir, s.done, ws, lane, bst, mode);
 		scan_consume(g, w, i, lane, stampv, tid, mode, id, bst, s, dir, ws, lite, mks, wel, wbf, wch, wmk);
 	}
-	if (lane == 0) { stx(&w.wlen[i], s.wl < ws ? s.wl : ws); stx(&w.wmn[i], s.nm); if (!lite) stg(&w.wnb[i], nb); if (s.nm > mks) *const_cast<bool *>(&w.mk_overflow) = true; }
+	if (lane == 0) { stx(&w.wlen[i], s.wl < ws ? s.wl : ws); stx(&w.wmn[i], s.nm); if (!lite) stx(&w.wnb[i], nb); if (s.nm > mks) *const_cast<bool *>(&w.mk_overflow) = true; }
 }
 
 __device__ __forceinline__ void wave_scan_instance(const GraphView &g, const BulgeWork &w, unsigned i, unsigned lane,
@@ -1410,6 +1410,9 @@ __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
 #define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
+#ifndef AP_CHUNKS
+#define AP_CHUNKS 4                          // AddPoints of a collapse handled one per lane: up to AP_CHUNKS x 64 (more: one lane, one after the other)
+#endif
 #define PC_T0() unsigned long long pc_t = prof ? __builtin_readcyclecounter() : 0ull
 #define PC_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - pc_t); pc_t = n_; } } while (0)
 __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv, const int prof = 0)
@@ -1552,7 +1555,7 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 	WSYNC();
 	PC_ADD(14);
 	if (t.err) return;
-	if (total > 64) {
+	if (total > 64u * AP_CHUNKS) {
 		if (lane == 0) {
 			unsigned nd = s_nodebase;
 			// first loop: restore the flanks (merge of the two index-sorted lists, look-back before look-forward at equal index)
@@ -1566,46 +1569,79 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
 		}
 	} else {
-		// One AddPoint per lane.  seq = its place in the reference's order (flanks merged by index, look-back first at equal
-		// index, then the copied source marks); an element that already carries a mark ignores later AddPoints, and the
-		// insertions into one list chain up in seq order (front insertion: the last one becomes the head).
-		unsigned seq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
-		if (lane < nlb) {
-			unsigned idx = w.lb[2 * lane], c = 0;
-			for (unsigned y = 0; y < nlf; y++) c += w.lf[2 * y] < idx;
-			seq = lane + c; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * lane + 1];
-		} else if (lane < nlb + nlf) {
-			unsigned bi = lane - nlb, idx = w.lf[2 * bi], c = 0;
-			for (unsigned y = 0; y < nlb; y++) c += w.lb[2 * y] <= idx;
-			seq = bi + c; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
-		} else if (lane < total) {
-			unsigned x = lane - nlb - nlf;
-			seq = lane; ad = w.act[3 * x]; ae = w.act[3 * x + 1]; ab = w.act[3 * x + 2];
+		// One AddPoint per lane and chunk of 64 (up to AP_CHUNKS x 64 of them: with dozens of strains half of all positions are
+		// bifurcations and a collapse copies 60 - 150 marks -- one lane doing them one after the other was 12 % of k_commit at 62 strains).
+		// seq = its place in the reference's order (flanks merged by index, look-back first at equal index, then the copied source
+		// marks); an element that already carries a mark ignores later AddPoints, and the insertions into one list chain up in seq
+		// order (front insertion: the last one becomes the head).
+		const unsigned nch = (total + 63u) >> 6;
+		unsigned seq[AP_CHUNKS], ekey[AP_CHUNKS], lkey[AP_CHUNKS], cur[AP_CHUNKS];
+		bool valid[AP_CHUNKS];
+#pragma unroll
+		for (int c = 0; c < AP_CHUNKS; c++) {
+			const unsigned x = lane + 64u * c;
+			unsigned sq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
+			if (x < nlb) {
+				unsigned idx = w.lb[2 * x], cc = 0;
+				for (unsigned y = 0; y < nlf; y++) cc += w.lf[2 * y] < idx;
+				sq = x + cc; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * x + 1];
+			} else if (x < nlb + nlf) {
+				unsigned bi = x - nlb, idx = w.lf[2 * bi], cc = 0;
+				for (unsigned y = 0; y < nlb; y++) cc += w.lb[2 * y] <= idx;
+				sq = bi + cc; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
+			} else if (x < total) {
+				unsigned xa = x - nlb - nlf;
+				sq = x; ad = w.act[3 * xa]; ae = w.act[3 * xa + 1]; ab = w.act[3 * xa + 2];
+			}
+			seq[c] = sq; ekey[c] = (ae << 1) | ad; lkey[c] = (ab << 1) | ad;
+			cur[c] = sq != BT_NONE && ab != BT_NONE ? g.bif[ad][ae] : 0u;
 		}
-		bool valid = seq != BT_NONE && ab != BT_NONE && g.bif[ad][ae] == BT_NONE;
-		const unsigned ekey = (ae << 1) | ad;
-		for (unsigned y = 0; y < total; y++) {                        // an earlier AddPoint on the same (strand, element) wins
-			unsigned ky = __shfl(ekey, y), sy = __shfl(seq, y);
-			if (valid && y != lane && ky == ekey && sy < seq) valid = false;
-		}
-		const unsigned lkey = (ab << 1) | ad;
-		unsigned pred = BT_NONE, cnt = 0;
-		bool last = true;
-		for (unsigned y = 0; y < total; y++) {
-			unsigned ky = __shfl(lkey, y), sy = __shfl(seq, y);
-			bool vy = __shfl((int)valid, y) != 0;
-			if (vy && ky == lkey) {
-				cnt++;
-				if (sy < seq && (pred == BT_NONE || sy > pred)) pred = sy;
-				if (sy > seq) last = false;
+#pragma unroll
+		for (int c = 0; c < AP_CHUNKS; c++) valid[c] = seq[c] != BT_NONE && (lkey[c] >> 1) != BT_NONE && cur[c] == BT_NONE;
+		// an earlier AddPoint on the same (strand, element) wins
+#pragma unroll
+		for (int c = 0; c < AP_CHUNKS; c++) {
+			if ((unsigned)c >= nch) break;
+#pragma unroll
+			for (int c2 = 0; c2 < AP_CHUNKS; c2++) {
+				if ((unsigned)c2 >= nch) break;
+				const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
+				for (unsigned y = 0; y < upto; y++) {
+					const unsigned ky = __shfl(ekey[c2], y), sy = __shfl(seq[c2], y);
+					if (valid[c] && !(c2 == c && y == lane) && ky == ekey[c] && sy < seq[c]) valid[c] = false;
+				}
 			}
 		}
-		if (valid) {
-			const unsigned nd = s_nodebase + seq;
-			const unsigned h = g.head[ad][ab], ls = g.lsize[ad][ab];
+		unsigned pred[AP_CHUNKS], cnt[AP_CHUNKS], hd[AP_CHUNKS], ls[AP_CHUNKS];
+		bool last[AP_CHUNKS];
+#pragma unroll
+		for (int c = 0; c < AP_CHUNKS; c++) {
+			pred[c] = BT_NONE; cnt[c] = 0; last[c] = true; hd[c] = 0; ls[c] = 0;
+			if ((unsigned)c >= nch) continue;
+			if (valid[c]) { hd[c] = g.head[lkey[c] & 1u][lkey[c] >> 1]; ls[c] = g.lsize[lkey[c] & 1u][lkey[c] >> 1]; }      // (every look at a head before any of them is rewritten)
+#pragma unroll
+			for (int c2 = 0; c2 < AP_CHUNKS; c2++) {
+				if ((unsigned)c2 >= nch) break;
+				const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
+				for (unsigned y = 0; y < upto; y++) {
+					const unsigned ky = __shfl(lkey[c2], y), sy = __shfl(seq[c2], y);
+					const bool vy = __shfl((int)valid[c2], y) != 0;
+					if (vy && ky == lkey[c]) {
+						cnt[c]++;
+						if (sy < seq[c] && (pred[c] == BT_NONE || sy > pred[c])) pred[c] = sy;
+						if (sy > seq[c]) last[c] = false;
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < AP_CHUNKS; c++) {
+			if ((unsigned)c >= nch || !valid[c]) continue;
+			const unsigned ad = lkey[c] & 1u, ab = lkey[c] >> 1, ae = ekey[c] >> 1;
+			const unsigned nd = s_nodebase + seq[c];
 			g.nslot[nd] = ae; g.ndead[nd] = 0; g.nidst[nd] = (ab << 1) | ad;
-			g.nnext[nd] = pred != BT_NONE ? s_nodebase + pred : h;
-			if (last) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls + cnt; }
+			g.nnext[nd] = pred[c] != BT_NONE ? s_nodebase + pred[c] : hd[c];
+			if (last[c]) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls[c] + cnt[c]; }
 			g.bif[ad][ae] = ab; g.nodeof[ad][ae] = nd;
 			if (ab < g.nid) { g.touch[ab] = 1; if (ab > t.id) g.need[ab] = 1; }
 		}
@@ -1638,6 +1674,34 @@ __device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, un
 		j0 += 256;
 	}
 	if (lane == 0) { w.idJ = found; w.jready = true; }
+	WSYNC();
+}
+
+// ---- the caller side of BulgeWork::mscan: MaxBifurcationMultiplicity of the two branches, one CountBifurcations per lane (bt_rb_mults
+// with 64 lanes; Txn::count_bif stamps the id exactly as the one-thread form does)
+__device__ __attribute__((noinline)) void wave_mults(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane)      // (out of line: it runs once per dense branch and must not cost the common path its registers)
+{
+	(void)g;
+	unsigned res[2];
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const unsigned i = q ? w.mq_j : w.mq_i, dist = q ? w.mq_dj : w.mq_di, nm = w.wmn[i];
+		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
+		unsigned r = 0;
+		for (unsigned j0 = 0; j0 < nm; j0 += 64) {
+			const unsigned j = j0 + lane;
+			const unsigned long long v = j < nm ? ldx(&mk[j]) : ~0ull;
+			const bool in = j < nm && (unsigned)(v >> 32) < dist;
+			const unsigned c = in ? t.count_bif((unsigned)v) : 0u;
+			r = c > r ? c : r;
+			if (!__all(in)) break;                                      // marks are in step order
+		}
+#pragma unroll
+		for (int dd = 32; dd > 0; dd >>= 1) { const unsigned v = __shfl_xor(r, dd); r = v > r ? v : r; }
+		res[q] = r;
+	}
+	WSYNC();
+	if (lane == 0) { w.mres[0] = res[0]; w.mres[1] = res[1]; w.mready = true; }
 	WSYNC();
 }
 
@@ -1688,7 +1752,30 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 		sh.mode = sh.skey ? 1 : 0;
 	}
 	WSYNC();
-	if (sh.mode) {
+	// Ids with dozens of instances (many strains): the counting pass is a walk over all their marks of its own.  Homologous instances
+	// reach the same ids, so the number of distinct ids is estimated from the longest mark list instead (x 2 + 32: a second endChar class
+	// and strain-specific marks); the map-building pass counts what it really inserts and falls back to the one-thread form if the
+	// estimate was too low (correct either way; never seen on the 62-strain workload).
+	const bool estimate = n > 32u && g.ab_estimate;
+	if (sh.mode && estimate) {
+		unsigned mx = 0;
+		for (unsigned i = lane; i < n; i += 64) { const unsigned v = w.endc[i] == ' ' ? 0u : w.wmn[i]; mx = v > mx ? v : mx; }
+#pragma unroll
+		for (int dd = 32; dd > 0; dd >>= 1) { const unsigned v = __shfl_xor(mx, dd); mx = v > mx ? v : mx; }
+		WSYNC();
+		if (lane == 0) {
+			t.fscr_used = mark;
+			const unsigned distinct = 2 * mx + 32;
+			unsigned bits = 6;
+			while ((1u << bits) < 2 * distinct + 2) bits++;
+			sh.bits = bits; sh.distinct = distinct;
+			sh.skey = (unsigned *)t.alloc2((2u << bits) * 4);
+			sh.sval = sh.skey ? sh.skey + (1u << bits) : nullptr;
+			if (!sh.skey || !bt_ab_prepare(t, w, distinct)) sh.mode = -1;
+			else w.abb.lazy = g.lazy_map != 0;
+		}
+		WSYNC();
+	} else if (sh.mode) {
 		// ---- pass 1: number of distinct ids that can get an entry
 		for (unsigned i = lane; i < count_slots; i += 64) sh.skey[i] = BT_NONE;
 		WSYNC();
@@ -1796,6 +1883,11 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			pos += f + run;
 		}
 	}
+	if (bad && sh.mode == -2) {
+		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
+		WSYNC();
+		return sh.mode == 3;
+	}
 	if (bad) return 0;
 	if (lane == 0) sh.mode = bt_ab_finish(t, w) ? 3 : 2;
 	WSYNC();
@@ -1859,7 +1951,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
-		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy; }
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = w.n > 24u && g.jscan_rounds; }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
 		while (flag) {
@@ -1868,6 +1960,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			PH_ADD(3);
 			if (!flag) break;
 			if (flag == 3) { wave_next_j(g, w, lane); continue; }       // large group: the search for the next J, 256 members per step
+			if (flag == 4) { wave_mults(g, t, w, lane); continue; }     // branches with many bifurcations inside: their multiplicities, one look-up per lane
 			if (flag == 2) {                                             // the loops need these windows as of now
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
@@ -2951,6 +3044,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	be.g.ab_estimate = getenv("SBL_NO_AB_ESTIMATE") ? 0u : 1u;         // measurement switch: AnyBulges of big ids without its counting pass
+	be.g.jscan_rounds = getenv("SBL_NO_JSCAN_ROUNDS") ? 0u : 1u;       // measurement switch
 	be.g.probe_pre = getenv("SBL_NO_PROBE_PRE") ? 0u : 1u;              // measurement switch: the endChar pre-pass of the probe (probe_endchars)
 	be.g.lazy_map = getenv("SBL_EAGER_MAP") ? 0u : 1u;                  // measurement switch: the Boost-ordered map of AnyBulges built eagerly (round 3)
 	be.g.tstamp = nullptr; be.g.tslot = 0;
