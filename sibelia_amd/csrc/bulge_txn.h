@@ -329,9 +329,24 @@ __host__ __device__ inline int32_t bm_insert(BoostMap &m, uint32_t key)
 	return n;
 }
 
+// The per-transaction scratch (BulgeWork's arrays) lives in LDS when it fits and in the arena otherwise, so the pointers kept in
+// BulgeWork are GENERIC and every access through them is a FLAT instruction -- several hundred cycles even when it resolves to LDS, and
+// the decision loops of RemoveBulges are one lane chasing such accesses.  The loops therefore exist twice (template <bool L>): with L
+// the caller has checked (bt_scratch_in_lds) that every array they touch IS in LDS and says so to the compiler, which then emits DS
+// instructions; without it the generic form.  Host builds (tests/hostsim) see no difference.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT_ASSUME_LDS(L, p) do { if (L) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p))); } while (0)
+#define BT_IS_LDS(p) __builtin_amdgcn_is_shared((const void *)(p))
+#else
+#define BT_ASSUME_LDS(L, p) ((void)0)
+#define BT_IS_LDS(p) false
+#endif
+
 // ------------------------------------------------------------------------------------------- small sorts
+template <bool L = false>
 __host__ __device__ inline void bt_sort_u64(uint64_t *a, uint32_t n)
 {
+	BT_ASSUME_LDS(L, a);
 	for (uint32_t gap = n / 2; gap > 0; gap /= 2)                 // shell sort
 		for (uint32_t i = gap; i < n; i++) {
 			uint64_t v = a[i]; uint32_t j = i;
@@ -532,18 +547,22 @@ __host__ __device__ inline void bt_end_chars(Txn &t, BulgeWork &w)
 }
 
 // FillVisit, bulgeremoval.cpp:122-146
+template <bool L = false>
 __host__ __device__ inline void bt_fill_visit(Txn &t, BulgeWork &w, uint32_t i)
 {
 	uint32_t D = t.g.D, n = 0;
 	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
-	uint32_t start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+	uint64_t *visit = w.visit;
+	const uint32_t *wst = w.wst, *wlen = w.wlen, *wmn = w.wmn;
+	BT_ASSUME_LDS(L, mk); BT_ASSUME_LDS(L, visit); BT_ASSUME_LDS(L, wst); BT_ASSUME_LDS(L, wlen); BT_ASSUME_LDS(L, wmn);
+	uint32_t start = wst[i], lim = wlen[i] < D ? wlen[i] : D, nm = wmn[i];
 	for (uint32_t j = 0; j < nm; j++) {
 		uint32_t step = (uint32_t)(mk[j] >> 32), b = (uint32_t)mk[j];
 		if (step >= lim || b == start) break;
 		if (n >= w.visit_cap) { t.err |= BT_ERR_SCRATCH; break; }
-		w.visit[n++] = ((uint64_t)b << 32) | step;
+		visit[n++] = ((uint64_t)b << 32) | step;
 	}
-	bt_sort_u64(w.visit, n);
+	bt_sort_u64<L>(visit, n);
 	w.nvisit = n;
 }
 
@@ -566,11 +585,14 @@ __host__ __device__ inline bool bt_overlap_sets(Txn &t, BulgeWork &w, uint32_t i
 }
 // do the first ni steps of window i and the first nj steps of window j share an element?  (-1: too many breaks to tell)
 // two walks that never leave consecutive slots are two intervals that start at the instances' own elements: no look at the cache at all
+template <bool L = false>
 __host__ __device__ __forceinline__ bool bt_plain_intervals_meet(const BulgeWork &w, uint32_t i, uint32_t ni, uint32_t j, uint32_t nj)
 {
-	const uint32_t a0 = w.sel[i], b0 = w.sel[j];
-	const uint32_t alo = (w.start[i] & 1u) ? a0 - (ni - 1) : a0, ahi = (w.start[i] & 1u) ? a0 : a0 + (ni - 1);
-	const uint32_t blo = (w.start[j] & 1u) ? b0 - (nj - 1) : b0, bhi = (w.start[j] & 1u) ? b0 : b0 + (nj - 1);
+	const uint32_t *sel = w.sel, *start = w.start;
+	BT_ASSUME_LDS(L, sel); BT_ASSUME_LDS(L, start);
+	const uint32_t a0 = sel[i], b0 = sel[j];
+	const uint32_t alo = (start[i] & 1u) ? a0 - (ni - 1) : a0, ahi = (start[i] & 1u) ? a0 : a0 + (ni - 1);
+	const uint32_t blo = (start[j] & 1u) ? b0 - (nj - 1) : b0, bhi = (start[j] & 1u) ? b0 : b0 + (nj - 1);
 	return alo <= bhi && blo <= ahi;
 }
 __host__ __device__ inline int bt_windows_intersect(const BulgeWork &w, uint32_t i, uint32_t ni, uint32_t j, uint32_t nj)
@@ -597,11 +619,16 @@ __host__ __device__ inline int bt_windows_intersect(const BulgeWork &w, uint32_t
 	}
 	return 0;
 }
+template <bool L = false>
 __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj)
 {
 	const uint32_t k = t.g.k, ni = di + k, nj = dj + k;
+	{
+		const uint32_t *wnb = w.wnb;
+		BT_ASSUME_LDS(L, wnb);
+		if (wnb[i] == 0 && wnb[j] == 0) return bt_plain_intervals_meet<L>(w, i, ni, j, nj);
+	}
 	if (w.wnb[i] > BT_MAX_BREAKS || w.wnb[j] > BT_MAX_BREAKS) return bt_overlap_sets(t, w, i, di, j, dj);
-	if (w.wnb[i] == 0 && w.wnb[j] == 0) return bt_plain_intervals_meet(w, i, ni, j, nj);
 	const uint32_t *ei = w.wel + (size_t)i * w.ws, *ej = w.wel + (size_t)j * w.ws;
 	const uint32_t *bi = w.wbk + i * BT_MAX_BREAKS, *bj = w.wbk + j * BT_MAX_BREAKS;
 	// runs of window i: [s0, s1) with s1 = next break (or ni)
@@ -624,10 +651,13 @@ __host__ __device__ inline bool bt_overlap(Txn &t, BulgeWork &w, uint32_t i, uin
 }
 
 // MaxBifurcationMultiplicity, bulgeremoval.cpp:39-53
+template <bool L = false>
 __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i, uint32_t distance)
 {
-	uint32_t r = 0, nm = w.wmn[i];
+	const uint32_t *wmn = w.wmn;
 	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
+	BT_ASSUME_LDS(L, wmn); BT_ASSUME_LDS(L, mk);
+	uint32_t r = 0, nm = wmn[i];
 	for (uint32_t j = 0; j < nm; j++) {
 		if ((uint32_t)(mk[j] >> 32) >= distance) break;
 		uint32_t c = t.count_bif((uint32_t)mk[j]);
@@ -637,10 +667,13 @@ __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i
 }
 
 // number of marked steps strictly inside a branch of `distance` steps (what bt_max_mult would look up)
+template <bool L = false>
 __host__ __device__ inline uint32_t bt_marks_inside(const BulgeWork &w, uint32_t i, uint32_t distance)
 {
-	uint32_t c = 0, nm = w.wmn[i];
+	const uint32_t *wmn = w.wmn;
 	const uint64_t *mk = w.wmk + (size_t)i * w.mks;
+	BT_ASSUME_LDS(L, wmn); BT_ASSUME_LDS(L, mk);
+	uint32_t c = 0, nm = wmn[i];
 	while (c < nm && (uint32_t)(mk[c] >> 32) < distance) c++;
 	return c;
 }
@@ -933,21 +966,33 @@ __host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
 // returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
 // the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards,
 // 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search).
+// every array the decision loops (bt_rb_run) touch is in LDS: the caller may then use bt_rb_run<true>
+__host__ __device__ __forceinline__ bool bt_scratch_in_lds(const BulgeWork &w)
+{
+	return BT_IS_LDS(w.ab.grp_off) && BT_IS_LDS(w.ab.grp_mem) && BT_IS_LDS(w.start) && BT_IS_LDS(w.sel) && BT_IS_LDS(w.endc) && BT_IS_LDS(w.wmk) && BT_IS_LDS(w.wlen)
+	       && BT_IS_LDS(w.wmn) && BT_IS_LDS(w.wst) && BT_IS_LDS(w.visit) && BT_IS_LDS(w.wnb);
+}
+template <bool L = false>
 __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // (always inline: as a call it takes t / w as generic pointers and spills around itself -- +5 ms per stage when the inliner gave up on it)
 {
 	const uint32_t D = t.g.D;
+	const uint32_t *grp_off = w.ab.grp_off, *grp_mem = w.ab.grp_mem, *start = w.start, *wlen = w.wlen, *wmn = w.wmn;
+	char *endc = w.endc;
+	const uint64_t *wmk = w.wmk, *visit = w.visit;
+	BT_ASSUME_LDS(L, grp_off); BT_ASSUME_LDS(L, grp_mem); BT_ASSUME_LDS(L, start); BT_ASSUME_LDS(L, wlen); BT_ASSUME_LDS(L, wmn); BT_ASSUME_LDS(L, endc);
+	BT_ASSUME_LDS(L, wmk); BT_ASSUME_LDS(L, visit);
 	while (w.gi < w.ab.ngroups) {
-		const uint32_t ge = w.ab.grp_off[w.gi + 1];
+		const uint32_t ge = grp_off[w.gi + 1];
 		while (w.idI < ge) {
-			const uint32_t kmerI = w.ab.grp_mem[w.idI];
+			const uint32_t kmerI = grp_mem[w.idI];
 			if (!w.inI) {
-				if (!bt_pvalid(t, w.start[kmerI])) { w.idI++; continue; }
+				if (!bt_pvalid(t, start[kmerI])) { w.idI++; continue; }
 				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true; w.jready = false;
 			}
 			while (w.idJ < ge) {
 				if (w.jscan && !w.jready && ge - w.idJ > 8) return 3;  // the caller finds the next candidate J (see jscan); short tails are walked here
-				const uint32_t kmerJ = w.ab.grp_mem[w.idJ];
-				if (!bt_pvalid(t, w.start[kmerJ]) || w.endc[kmerI] == w.endc[kmerJ]) { w.idJ++; w.jready = false; continue; }
+				const uint32_t kmerJ = grp_mem[w.idJ];
+				if (!bt_pvalid(t, start[kmerJ]) || endc[kmerI] == endc[kmerJ]) { w.idJ++; w.jready = false; continue; }
 				if (w.lazy) {                                        // everything below reads the windows of I and J: as of NOW, like the reference's walks
 					uint32_t nr = 0;
 					if (w.wep[kmerI] != w.epoch) w.req[nr++] = kmerI;
@@ -957,34 +1002,34 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 				w.idJ++; w.jready = false;
 				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
 				// after a collapse that rewrote I's own window
-				if (w.need_fill) { bt_fill_visit(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }
-				const uint64_t *mkJ = w.wmk + (size_t)kmerJ * w.mks;
-				const uint32_t limJ = w.wlen[kmerJ] < D ? w.wlen[kmerJ] : D, nmJ = w.wmn[kmerJ];
+				if (w.need_fill) { bt_fill_visit<L>(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }
+				const uint64_t *mkJ = wmk + (size_t)kmerJ * w.mks;
+				const uint32_t limJ = wlen[kmerJ] < D ? wlen[kmerJ] : D, nmJ = wmn[kmerJ], nvisit = w.nvisit;
 				for (uint32_t j = 0; j < nmJ; j++) {
 					uint32_t step = (uint32_t)(mkJ[j] >> 32), nowBif = (uint32_t)mkJ[j];
 					if (step >= limJ) break;
 					if (nowBif == t.id) break;
-					uint32_t lo = 0, hi = w.nvisit;                  // lower_bound(BifurcationMark(nowBif, 0))
+					uint32_t lo = 0, hi = nvisit;                    // lower_bound(BifurcationMark(nowBif, 0))
 					uint64_t probe = (uint64_t)nowBif << 32;
-					while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (w.visit[mid] < probe) lo = mid + 1; else hi = mid; }
-					if (lo < w.nvisit && (uint32_t)(w.visit[lo] >> 32) == nowBif) {
-						uint32_t dJ = step, dI = (uint32_t)w.visit[lo];
-						if (bt_overlap(t, w, kmerI, dI, kmerJ, dJ)) break;
+					while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (visit[mid] < probe) lo = mid + 1; else hi = mid; }
+					if (lo < nvisit && (uint32_t)(visit[lo] >> 32) == nowBif) {
+						uint32_t dJ = step, dI = (uint32_t)visit[lo];
+						if (bt_overlap<L>(t, w, kmerI, dI, kmerJ, dJ)) break;
 						if (t.err) return 0;
-						if (w.mscan && !w.mready && bt_marks_inside(w, kmerI, dI) + bt_marks_inside(w, kmerJ, dJ) > BT_MSCAN_MIN) {
+						if (w.mscan && !w.mready && bt_marks_inside<L>(w, kmerI, dI) + bt_marks_inside<L>(w, kmerJ, dJ) > BT_MSCAN_MIN) {
 							w.mq_i = kmerI; w.mq_di = dI; w.mq_j = kmerJ; w.mq_dj = dJ;
 							w.idJ--; w.jready = true;                    // this J again once the caller has the multiplicities (nothing has been decided or counted yet)
 							return 4;
 						}
 						++w.ret;
-						uint32_t imlp = w.mready ? w.mres[0] : bt_max_mult(t, w, kmerI, dI);
-						uint32_t jmlp = w.mready ? w.mres[1] : bt_max_mult(t, w, kmerJ, dJ);
+						uint32_t imlp = w.mready ? w.mres[0] : bt_max_mult<L>(t, w, kmerI, dI);
+						uint32_t jmlp = w.mready ? w.mres[1] : bt_max_mult<L>(t, w, kmerJ, dJ);
 						w.mready = false;
 						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
-							w.endc[kmerJ] = w.endc[kmerI];
+							endc[kmerJ] = endc[kmerI];
 							w.c_src = kmerI; w.c_dS = dI; w.c_tgt = kmerJ; w.c_dT = dJ;
 						} else {
-							w.endc[kmerI] = w.endc[kmerJ];
+							endc[kmerI] = endc[kmerJ];
 							w.c_src = kmerJ; w.c_dS = dJ; w.c_tgt = kmerI; w.c_dT = dI;
 							w.need_fill = true;                      // FillVisit(I) again, on the rescanned window
 						}
@@ -995,7 +1040,7 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 			w.inI = false; w.idI++;
 		}
 		w.gi++;
-		if (w.gi < w.ab.ngroups) w.idI = w.ab.grp_off[w.gi];
+		if (w.gi < w.ab.ngroups) w.idI = grp_off[w.gi];
 	}
 	if (!t.defer_cleanup) t.cleanup();           // (simplify.hip: Cleanup by all lanes once the loops are over)
 	return 0;

@@ -1415,6 +1415,89 @@ __device__ unsigned long long g_txn_max[2];        // longest transaction: cycle
 #endif
 #define PC_T0() unsigned long long pc_t = prof ? __builtin_readcyclecounter() : 0ull
 #define PC_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - pc_t); pc_t = n_; } } while (0)
+// The AddPoints of a collapse, one per lane and chunk of 64 lanes (NC chunks: instantiated for 1 -- the usual few dozen -- and for AP_CHUNKS).
+template <int NC, class NewT>
+__device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, const unsigned *T, NewT newT, unsigned k, unsigned d, unsigned opp,
+                                                unsigned dS, unsigned nlb, unsigned nlf, unsigned total, unsigned s_nodebase)
+{
+	// One AddPoint per lane and chunk of 64 (up to NC x 64 of them: with dozens of strains half of all positions are
+	// bifurcations and a collapse copies 60 - 150 marks -- one lane doing them one after the other was 12 % of k_commit at 62 strains).
+	// seq = its place in the reference's order (flanks merged by index, look-back first at equal index, then the copied source
+	// marks); an element that already carries a mark ignores later AddPoints, and the insertions into one list chain up in seq
+	// order (front insertion: the last one becomes the head).
+	const unsigned nch = (total + 63u) >> 6;
+	unsigned seq[NC], ekey[NC], lkey[NC], cur[NC];
+	bool valid[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		const unsigned x = lane + 64u * c;
+		unsigned sq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
+		if (x < nlb) {
+			unsigned idx = w.lb[2 * x], cc = 0;
+			for (unsigned y = 0; y < nlf; y++) cc += w.lf[2 * y] < idx;
+			sq = x + cc; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * x + 1];
+		} else if (x < nlb + nlf) {
+			unsigned bi = x - nlb, idx = w.lf[2 * bi], cc = 0;
+			for (unsigned y = 0; y < nlb; y++) cc += w.lb[2 * y] <= idx;
+			sq = bi + cc; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
+		} else if (x < total) {
+			unsigned xa = x - nlb - nlf;
+			sq = x; ad = w.act[3 * xa]; ae = w.act[3 * xa + 1]; ab = w.act[3 * xa + 2];
+		}
+		seq[c] = sq; ekey[c] = (ae << 1) | ad; lkey[c] = (ab << 1) | ad;
+		cur[c] = sq != BT_NONE && ab != BT_NONE ? g.bif[ad][ae] : 0u;
+	}
+#pragma unroll
+	for (int c = 0; c < NC; c++) valid[c] = seq[c] != BT_NONE && (lkey[c] >> 1) != BT_NONE && cur[c] == BT_NONE;
+	// an earlier AddPoint on the same (strand, element) wins
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		if ((unsigned)c >= nch) break;
+#pragma unroll
+		for (int c2 = 0; c2 < NC; c2++) {
+			if ((unsigned)c2 >= nch) break;
+			const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
+			for (unsigned y = 0; y < upto; y++) {
+				const unsigned ky = __shfl(ekey[c2], y), sy = __shfl(seq[c2], y);
+				if (valid[c] && !(c2 == c && y == lane) && ky == ekey[c] && sy < seq[c]) valid[c] = false;
+			}
+		}
+	}
+	unsigned pred[NC], cnt[NC], hd[NC], ls[NC];
+	bool last[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		pred[c] = BT_NONE; cnt[c] = 0; last[c] = true; hd[c] = 0; ls[c] = 0;
+		if ((unsigned)c >= nch) continue;
+		if (valid[c]) { hd[c] = g.head[lkey[c] & 1u][lkey[c] >> 1]; ls[c] = g.lsize[lkey[c] & 1u][lkey[c] >> 1]; }      // (every look at a head before any of them is rewritten)
+#pragma unroll
+		for (int c2 = 0; c2 < NC; c2++) {
+			if ((unsigned)c2 >= nch) break;
+			const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
+			for (unsigned y = 0; y < upto; y++) {
+				const unsigned ky = __shfl(lkey[c2], y), sy = __shfl(seq[c2], y);
+				const bool vy = __shfl((int)valid[c2], y) != 0;
+				if (vy && ky == lkey[c]) {
+					cnt[c]++;
+					if (sy < seq[c] && (pred[c] == BT_NONE || sy > pred[c])) pred[c] = sy;
+					if (sy > seq[c]) last[c] = false;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		if ((unsigned)c >= nch || !valid[c]) continue;
+		const unsigned ad = lkey[c] & 1u, ab = lkey[c] >> 1, ae = ekey[c] >> 1;
+		const unsigned nd = s_nodebase + seq[c];
+		g.nslot[nd] = ae; g.ndead[nd] = 0; g.nidst[nd] = (ab << 1) | ad;
+		g.nnext[nd] = pred[c] != BT_NONE ? s_nodebase + pred[c] : hd[c];
+		if (last[c]) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls[c] + cnt[c]; }
+		g.bif[ad][ae] = ab; g.nodeof[ad][ae] = nd;
+		if (ab < g.nid) { g.touch[ab] = 1; if (ab > t.id) g.need[ab] = 1; }
+	}
+}
+
 __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv, const int prof = 0)
 {
 	PC_T0();
@@ -1569,82 +1652,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
 		}
 	} else {
-		// One AddPoint per lane and chunk of 64 (up to AP_CHUNKS x 64 of them: with dozens of strains half of all positions are
-		// bifurcations and a collapse copies 60 - 150 marks -- one lane doing them one after the other was 12 % of k_commit at 62 strains).
-		// seq = its place in the reference's order (flanks merged by index, look-back first at equal index, then the copied source
-		// marks); an element that already carries a mark ignores later AddPoints, and the insertions into one list chain up in seq
-		// order (front insertion: the last one becomes the head).
-		const unsigned nch = (total + 63u) >> 6;
-		unsigned seq[AP_CHUNKS], ekey[AP_CHUNKS], lkey[AP_CHUNKS], cur[AP_CHUNKS];
-		bool valid[AP_CHUNKS];
-#pragma unroll
-		for (int c = 0; c < AP_CHUNKS; c++) {
-			const unsigned x = lane + 64u * c;
-			unsigned sq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
-			if (x < nlb) {
-				unsigned idx = w.lb[2 * x], cc = 0;
-				for (unsigned y = 0; y < nlf; y++) cc += w.lf[2 * y] < idx;
-				sq = x + cc; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * x + 1];
-			} else if (x < nlb + nlf) {
-				unsigned bi = x - nlb, idx = w.lf[2 * bi], cc = 0;
-				for (unsigned y = 0; y < nlb; y++) cc += w.lb[2 * y] <= idx;
-				sq = bi + cc; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
-			} else if (x < total) {
-				unsigned xa = x - nlb - nlf;
-				sq = x; ad = w.act[3 * xa]; ae = w.act[3 * xa + 1]; ab = w.act[3 * xa + 2];
-			}
-			seq[c] = sq; ekey[c] = (ae << 1) | ad; lkey[c] = (ab << 1) | ad;
-			cur[c] = sq != BT_NONE && ab != BT_NONE ? g.bif[ad][ae] : 0u;
-		}
-#pragma unroll
-		for (int c = 0; c < AP_CHUNKS; c++) valid[c] = seq[c] != BT_NONE && (lkey[c] >> 1) != BT_NONE && cur[c] == BT_NONE;
-		// an earlier AddPoint on the same (strand, element) wins
-#pragma unroll
-		for (int c = 0; c < AP_CHUNKS; c++) {
-			if ((unsigned)c >= nch) break;
-#pragma unroll
-			for (int c2 = 0; c2 < AP_CHUNKS; c2++) {
-				if ((unsigned)c2 >= nch) break;
-				const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
-				for (unsigned y = 0; y < upto; y++) {
-					const unsigned ky = __shfl(ekey[c2], y), sy = __shfl(seq[c2], y);
-					if (valid[c] && !(c2 == c && y == lane) && ky == ekey[c] && sy < seq[c]) valid[c] = false;
-				}
-			}
-		}
-		unsigned pred[AP_CHUNKS], cnt[AP_CHUNKS], hd[AP_CHUNKS], ls[AP_CHUNKS];
-		bool last[AP_CHUNKS];
-#pragma unroll
-		for (int c = 0; c < AP_CHUNKS; c++) {
-			pred[c] = BT_NONE; cnt[c] = 0; last[c] = true; hd[c] = 0; ls[c] = 0;
-			if ((unsigned)c >= nch) continue;
-			if (valid[c]) { hd[c] = g.head[lkey[c] & 1u][lkey[c] >> 1]; ls[c] = g.lsize[lkey[c] & 1u][lkey[c] >> 1]; }      // (every look at a head before any of them is rewritten)
-#pragma unroll
-			for (int c2 = 0; c2 < AP_CHUNKS; c2++) {
-				if ((unsigned)c2 >= nch) break;
-				const unsigned upto = total - 64u * c2 < 64u ? total - 64u * c2 : 64u;
-				for (unsigned y = 0; y < upto; y++) {
-					const unsigned ky = __shfl(lkey[c2], y), sy = __shfl(seq[c2], y);
-					const bool vy = __shfl((int)valid[c2], y) != 0;
-					if (vy && ky == lkey[c]) {
-						cnt[c]++;
-						if (sy < seq[c] && (pred[c] == BT_NONE || sy > pred[c])) pred[c] = sy;
-						if (sy > seq[c]) last[c] = false;
-					}
-				}
-			}
-		}
-#pragma unroll
-		for (int c = 0; c < AP_CHUNKS; c++) {
-			if ((unsigned)c >= nch || !valid[c]) continue;
-			const unsigned ad = lkey[c] & 1u, ab = lkey[c] >> 1, ae = ekey[c] >> 1;
-			const unsigned nd = s_nodebase + seq[c];
-			g.nslot[nd] = ae; g.ndead[nd] = 0; g.nidst[nd] = (ab << 1) | ad;
-			g.nnext[nd] = pred[c] != BT_NONE ? s_nodebase + pred[c] : hd[c];
-			if (last[c]) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls[c] + cnt[c]; }
-			g.bif[ad][ae] = ab; g.nodeof[ad][ae] = nd;
-			if (ab < g.nid) { g.touch[ab] = 1; if (ab > t.id) g.need[ab] = 1; }
-		}
+		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase);
+		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase);
 	}
 	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
 	WSYNC();
@@ -1955,7 +1964,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		WSYNC();
 		PH_ADD(2);
 		while (flag) {
-			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
+			if (lane == 0) { const int r = bt_scratch_in_lds(w) ? bt_rb_run<true>(t, w) : bt_rb_run<false>(t, w); flag = t.err ? 0 : r; }      // (<true>: DS instead of FLAT accesses, bulge_txn.h: BT_ASSUME_LDS)
 			WSYNC();
 			PH_ADD(3);
 			if (!flag) break;
