@@ -1753,19 +1753,25 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 {
 	const unsigned D = g.D, n = w.n;
 	const unsigned cshift = 32u - (unsigned)__builtin_ctz(count_slots);
-	unsigned mark = 0;
+	unsigned mark = 0, amark = 0;
 	if (lane == 0) {
 		if (!endc_ready) bt_end_chars(t, w);
-		mark = t.fscr_used;
+		mark = t.fscr_used; amark = t.scr_used;
+	}
+	for (int attempt = 0;; attempt++) {                                    // (a second attempt only after an estimate that was too low, see below)
+	if (lane == 0) {
+		t.fscr_used = mark; t.scr_used = amark;
 		sh.skey = count_tab ? count_tab : (unsigned *)t.falloc(count_slots * 4);
 		sh.mode = sh.skey ? 1 : 0;
 	}
 	WSYNC();
 	// Ids with dozens of instances (many strains): the counting pass is a walk over all their marks of its own.  Homologous instances
 	// reach the same ids, so the number of distinct ids is estimated from the longest mark list instead (x 2 + 32: a second endChar class
-	// and strain-specific marks); the map-building pass counts what it really inserts and falls back to the one-thread form if the
-	// estimate was too low (correct either way; never seen on the 62-strain workload).
-	const bool estimate = n > 32u && g.ab_estimate;
+	// and strain-specific marks); the map-building pass counts what it really inserts and starts over WITH the counting pass if
+	// the estimate was too low (ids of low-complexity sequence, whose instances are not homologous; never on the 62-strain workload).
+	// (Round 4's first version let the overflow surface as a scratch error: the id was sent to the big arena, overflowed there again,
+	// was sent again ... -- the `-s far` hierarchy case of the drop-in tests never came back.)
+	const bool estimate = attempt == 0 && n > 32u && g.ab_estimate;
 	if (sh.mode && estimate) {
 		unsigned mx = 0;
 		for (unsigned i = lane; i < n; i += 64) { const unsigned v = w.endc[i] == ' ' ? 0u : w.wmn[i]; mx = v > mx ? v : mx; }
@@ -1880,8 +1886,9 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 						unsigned bb = sh.batch[x], hh = (bb * 2654435761u) >> shift;
 						while (sh.skey[hh] != BT_NONE && sh.skey[hh] != bb) hh = (hh + 1) & (slots - 1);
 						if (sh.skey[hh] == bb) continue;                       // the id occurs twice in this window: second look-up finds the entry just made
-						int kt = bt_ab_insert(t, w, i, bb);
-						if (kt < 0) sh.mode = -1;
+						int kt = estimate && w.abb.m.size >= sh.distinct ? -2 : bt_ab_insert(t, w, i, bb);
+						if (kt == -2) sh.mode = -2;                               // more distinct ids than estimated: again, with the counting pass
+						else if (kt < 0) sh.mode = -1;
 						else { sh.skey[hh] = bb; sh.sval[hh] = ((unsigned)kt << 8) | (unsigned char)ec; }
 					}
 				} else if (!bt_ab_append(t, w, i, (int)(evl >> 8))) sh.mode = -1;
@@ -1892,15 +1899,12 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			pos += f + run;
 		}
 	}
-	if (bad && sh.mode == -2) {
-		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
-		WSYNC();
-		return sh.mode == 3;
-	}
+	if (bad && sh.mode == -2) { WSYNC(); continue; }
 	if (bad) return 0;
 	if (lane == 0) sh.mode = bt_ab_finish(t, w) ? 3 : 2;
 	WSYNC();
 	return sh.mode == 3;
+	}
 }
 
 

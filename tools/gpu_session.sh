@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
-if [ -n "$2" ]; then timeout 900 python -m pytest tests -m gpu -q -k "$2" > $out/first.log 2>&1; echo "rc $?" >> $out/first.log; tail -30 $out/first.log; fi
-if [ -z "$SKIP_SUITE" ]; then timeout 2400 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "pytest rc $?" >> $out/gpu_tests.log; tail -40 $out/gpu_tests.log; fi
+if [ -n "$2" ]; then timeout 900 python -m pytest tests -m gpu -q --timeout=600 -k "$2" > $out/first.log 2>&1; echo "rc $?" >> $out/first.log; tail -30 $out/first.log; fi
+if [ -z "$SKIP_SUITE" ]; then timeout 2400 python -m pytest tests -m gpu -q --timeout=900 > $out/gpu_tests.log 2>&1; echo "pytest rc $?" >> $out/gpu_tests.log; tail -40 $out/gpu_tests.log; fi
 timeout 600 python bench.py --no-cpu-full > $out/bench.log 2> $out/bench.err
 grep '^{' $out/bench.log | python -c "
 import json,sys
