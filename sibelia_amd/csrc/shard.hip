@@ -18,7 +18,7 @@
 //                identical id tables; k_rank_own_keys: binary search of the owner's own codes = their ids
 //   E  marks     k_member_marks turns the owner's member positions into (element, id) marks, which are all-gathered
 //                (16 B per member position) and scattered: the dense mark arrays end up complete and identical everywhere.
-// Simplification (globally ordered) then runs replicated.  k > 32 (exact rank doubling) is not sharded.
+// Simplification: commits replicated, read-only phases shared out (simplify.hip).  k > 32: sharded rank doubling (longk.hip).
 //
 // Transports: RCCL (dlopen'ed librccl: grouped ncclSend/ncclRecv + ncclAllGather on the context's stream) and a
 // local one (contexts of one process, one host thread each, device-to-device copies + a pthread barrier) that lets
