@@ -63,6 +63,7 @@ struct GraphView {
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
+	uint32_t collapse_g;                // ordered rounds / chain: the gather-first collapse (simplify.hip: wave_collapse_g)
 	uint32_t ab_estimate;               // AnyBulges of ids with more than 32 instances sizes its tables by an estimate instead of a counting pass (simplify.hip)
 	uint32_t jscan_rounds;              // ordered rounds: ids with more than 24 instances hand the search for the next J to 64 lanes (BulgeWork::jscan)
 	uint32_t probe_pre;                 // the probe of a round first looks at the endChars alone (simplify.hip: probe_endchars)

@@ -1660,6 +1660,270 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 	PC_ADD(15);
 }
 
+// ---- gather-first CollapseBulgeGreedily (round 4) ------------------------------------------------------------------------------------
+// wave_collapse above is a chain of ~14 dependent memory round trips: window elements from the arena, then their marks, then the stamps
+// of those marks -- twice, for the two loops of EraseBifurcations --, positions, allocation, the marks to copy, their stamps, the heads of
+// the lists.  A collapse is 38 % of a transaction and a round lasts as long as its slowest transaction, so the order is turned round:
+//   1  the steps of the target and of the source window the collapse looks at, one per lane and 64-step chunk, into REGISTERS;
+//   2  every graph value it needs about them in one batch (marks and nodes of both strands of the target range, opposite-strand marks
+//      of the source range, original positions);
+//   3  the stamp words of every id it will erase or copy, and the two pool allocations, in one batch;
+//   4  checks, then nothing but stores (erase, characters, links, new elements, positions), the AddPoint list, and the AddPoints.
+// Same effect as wave_collapse (the two erase loops fuse: the flank marks of the first are a subset of the range of the second, and
+// the order of erasure is unobservable -- lazy-erase chain and list sizes are order-free).  NC = 64-step chunks per window (1 or 3).
+template <int NC>
+__device__ __forceinline__ unsigned gsel(const unsigned (&r)[NC], unsigned x)      // r "at step x": every lane must take part
+{
+	unsigned v = __shfl(r[0], x & 63u);
+	if (NC > 1) { const unsigned v1 = __shfl(r[NC > 1 ? 1 : 0], x & 63u); v = (x >> 6) == 1u ? v1 : v; }
+	if (NC > 2) { const unsigned v2 = __shfl(r[NC > 2 ? 2 : 0], x & 63u); v = (x >> 6) >= 2u ? v2 : v; }
+	return v;
+}
+template <int NC>
+__device__ __forceinline__ void wave_collapse_g(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv, const int prof = 0)
+{
+	PC_T0();
+	const unsigned k = g.k, ws = w.ws, tid = t.tid, id = t.id;
+	const unsigned src = w.c_src, dS = w.c_dS, tgt = w.c_tgt, dT = w.c_dT;
+	const unsigned d = w.start[tgt] & 1u, opp = d ^ 1u, ds = w.start[src] & 1u;
+	const unsigned *T = w.wel + (size_t)tgt * ws, *S = w.wel + (size_t)src * ws, *SB = w.wbf + (size_t)src * ws;
+	const uint8_t *SCH = w.wch + (size_t)src * ws;
+	const unsigned nT = k + dT + 1, nS = dS + k, nE = k + dT;             // target steps looked at (incl. the element after the span) / source steps / erase range
+	const unsigned long long lt = (1ull << lane) - 1ull, gt = lane == 63u ? 0ull : (~0ull << (lane + 1u));
+	const bool stamped = t.mode != 0;
+	// ---- 1: the two walks into registers
+	unsigned Tv[NC], Sv[NC], Sb[NC], Sc[NC];
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned x = lane + 64u * u;
+		Tv[u] = ldg(&T[x < nT ? x : 0u]); Sv[u] = ldg(&S[x < nS ? x : 0u]);
+		Sb[u] = ldg(&SB[x <= dS ? x : 0u]); Sc[u] = ldg(&SCH[x < nS ? x : 0u]);
+	}
+#pragma unroll
+	for (int u = 0; u < NC; u++) if (lane + 64u * u > dS) Sb[u] = BT_NONE;
+	// ---- 2: everything the graph knows about them
+	unsigned bd[NC], bo[NC], nd[NC], no[NC], bs2[NC], opv[NC];
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned e = Tv[u], es = Sv[u];                              // (lanes beyond the ranges hold step 0: loads are unconditional, results masked)
+		bd[u] = g.bif[d][e]; bo[u] = g.bif[opp][e]; nd[u] = g.nodeof[d][e]; no[u] = g.nodeof[opp][e]; opv[u] = g.op[e];
+		bs2[u] = g.bif[ds ^ 1u][es];
+	}
+	unsigned long long mA[NC], mB[NC], m1[NC], m2[NC];
+	bool ed[NC], eo[NC];
+	unsigned b2[NC];
+	unsigned nlb = 0, nlf = 0, nact = 0;
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned x = lane + 64u * u;
+		if (x >= nE) { bd[u] = BT_NONE; bo[u] = BT_NONE; }
+		if (x < k - 1u || x >= nS) bs2[u] = BT_NONE;
+		ed[u] = x >= 1u && bd[u] != BT_NONE;                               // own-strand marks after the target start, opposite-strand marks from it on
+		eo[u] = bo[u] != BT_NONE;
+		mA[u] = __ballot(x < k && bo[u] != BT_NONE);                      // lookBack: opposite strand over the first k steps, index k - 1 - x
+		mB[u] = __ballot(x >= dT && x < dT + k && bd[u] != BT_NONE);      // lookForward: own strand from step dT on, index x - dT
+		nlb += (unsigned)__popcll(mA[u]); nlf += (unsigned)__popcll(mB[u]);
+	}
+#pragma unroll
+	for (int u = 0; u < NC; u++) {                                         // source marks to copy at index i = x: own strand at step i, opposite strand at step dS + k - 1 - i
+		const unsigned x = lane + 64u * u;
+		const unsigned v = gsel<NC>(bs2, x <= dS ? dS + k - 1u - x : 0u);
+		b2[u] = x <= dS ? v : BT_NONE;
+		m1[u] = __ballot(Sb[u] != BT_NONE); m2[u] = __ballot(b2[u] != BT_NONE);
+		nact += (unsigned)__popcll(m1[u]) + (unsigned)__popcll(m2[u]);
+	}
+	// the two flank lists in index order (LDS)
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned x = lane + 64u * u;
+		if (x < k && bo[u] != BT_NONE) {
+			unsigned o = (unsigned)__popcll(mA[u] & gt);
+			for (int v = u + 1; v < NC; v++) o += (unsigned)__popcll(mA[v]);
+			w.lb[2 * o] = k - 1u - x; w.lb[2 * o + 1] = bo[u];
+		}
+		if (x >= dT && x < dT + k && bd[u] != BT_NONE) {
+			unsigned o = (unsigned)__popcll(mB[u] & lt);
+			for (int v = 0; v < u; v++) o += (unsigned)__popcll(mB[v]);
+			w.lf[2 * o] = x - dT; w.lf[2 * o + 1] = bd[u];
+		}
+	}
+	PC_ADD(9);
+	// ---- 3: allocations and the stamp words of every id touched, in one batch
+	__shared__ unsigned s_newbase_g, s_nodebase_g;
+	const unsigned total = nlb + nlf + nact;
+	if (lane == 0) {
+		t.wrote = true;
+		unsigned newbase = BT_NONE;
+		if (dS > dT) {
+			const unsigned span = bt_insert_span(dS - dT);
+			const unsigned base = atomicAdd(&g.ctr[CTR_NE], span);
+			if (base + span > g.cap_e) t.err |= BT_ERR_ELEM_CAP; else newbase = base;
+		}
+		s_newbase_g = newbase;
+		const unsigned nbase = total ? atomicAdd(&g.ctr[CTR_NN], total) : 0u;
+		if (total && nbase + total > g.cap_n) t.err |= BT_ERR_NODE_CAP;
+		s_nodebase_g = nbase;
+	}
+	unsigned sw[NC][4][3];                                                 // own / wmax / rmax of: erased own-strand id, erased opposite-strand id, copied own-strand id, copied opposite-strand id
+	if (stamped) {
+#pragma unroll
+		for (int u = 0; u < NC; u++) {
+			const unsigned ids[4] = { ed[u] ? bd[u] : 0u, eo[u] ? bo[u] : 0u, Sb[u] != BT_NONE ? Sb[u] : 0u, b2[u] != BT_NONE ? b2[u] : 0u };
+#pragma unroll
+			for (int q = 0; q < 4; q++) { sw[u][q][0] = g.own[ids[q]]; sw[u][q][1] = g.wmax[g.nblk + ids[q]]; sw[u][q][2] = g.rmax[g.nblk + ids[q]]; }
+		}
+#pragma unroll
+		for (int u = 0; u < NC; u++) {
+			const bool has[4] = { ed[u], eo[u], Sb[u] != BT_NONE, b2[u] != BT_NONE };
+			const unsigned ids[4] = { bd[u], bo[u], Sb[u], b2[u] };
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				if (!has[q]) continue;
+				const unsigned r = g.nblk + ids[q], ow = sw[u][q][0], wm = sw[u][q][1], rm = sw[u][q][2];
+				const bool bad = (stampv != BT_NONE && ow != stampv) || wm > tid || rm > tid;      // not in its claims, or a higher id was here first
+				atomicMax(&g.wmax[r], tid);
+				if (bad) {
+					atomicMin(&g.ctr[CTR_VIOL], id);
+					if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 3u) == 0u) { g.ctr[CTR_DETAIL + 1] = r; g.ctr[CTR_DETAIL + 2] = (wm > rm ? wm : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (wm > tid ? 1u : 0u) | (rm > tid ? 2u : 0u) | (ow != stampv ? 4u : 0u); }
+				}
+			}
+		}
+	}
+	WSYNC();
+	PC_ADD(10);
+	if (t.err) return;
+	const unsigned newbase = s_newbase_g;
+	// scalars of the replacement (every lane takes part in the shuffles)
+	const unsigned common = dS < dT ? dS : dT;
+	const unsigned Eafter = gsel<NC>(Tv, d == 0 ? k + dT : k - 1u);
+	const unsigned firstPos = gsel<NC>(opv, d == 0 ? k : k + dT - 1u) & BT_POS_MASK, lastPos = gsel<NC>(opv, d == 0 ? k + dT : k - 1u) & BT_POS_MASK;
+	const unsigned jb = dS ? dS - 1u : 0u, jb0 = dT ? dT - 1u : 0u;
+	const unsigned before = gsel<NC>(Tv, d == 0 ? k + jb : k + dT - 1u - jb), before0 = gsel<NC>(Tv, d == 0 ? k + jb0 : k + dT - 1u - jb0);      // P(dS - 1), P(dT - 1)
+	// ---- 4a: erase (ErasePoint for one (strand, element) per lane and chunk; the marks were stamped above)
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned e = Tv[u];
+#pragma unroll
+		for (int q = 0; q < 2; q++) {
+			const bool has = q ? eo[u] : ed[u];
+			if (!has) continue;
+			const unsigned strand = q ? opp : d, b = q ? bo[u] : bd[u], node = q ? no[u] : nd[u];
+			g.bif[strand][e] = BT_NONE;
+			g.ndead[node] = 1;
+			g.nclr[node] = atomicExch(&t.tc_head, node);
+			{ const unsigned ix = atomicAdd(&t.tc_n, 1u); if (ix < t.tc_cap) t.tc_list[ix] = node; }
+			if (b < g.nid) { g.touch[b] = 1; if (b > id) g.need[b] = 1; }
+		}
+	}
+	// ---- 4b: DNASequence::Replace in + coordinates (wave_collapse explains P / C and the replayed double accumulation)
+	{
+		const unsigned nb = newbase;
+		for (unsigned j0 = 0; j0 < (dS < dT ? dT : common); j0 += 64) {
+			const unsigned jx = j0 + lane, jc = jx < dT ? jx : 0u;
+			const unsigned Pj = gsel<NC>(Tv, d == 0 ? k + jc : k + dT - 1u - jc);
+			const unsigned sx = jx < common ? (d == 0 ? k + jx : k + dS - 1u - jx) : 0u;
+			char c = (char)gsel<NC>(Sc, sx);
+			c = ds ? bt_comp(c) : c;
+			c = d == 0 ? c : bt_comp(c);
+			if (jx < common) g.ch[Pj] = (uint8_t)c;
+			else if (jx < dT) g.ch[Pj] = BT_DEAD_CHAR;                   // deletion: the tail of the old span dies
+		}
+		if (dS < dT) {
+			if (lane == 0) { g.nx[before] = Eafter; g.pv[Eafter] = before; }
+		} else if (dS > dT) {
+			const unsigned m = dS - dT, span = bt_insert_span(m);
+			for (unsigned i0 = 0; i0 < span; i0 += 64) {
+				const unsigned i = i0 + lane;
+				const unsigned jx = dT + (i < m ? i : 0u), sx = d == 0 ? k + jx : k + dS - 1u - jx;
+				char c = (char)gsel<NC>(Sc, sx);
+				c = ds ? bt_comp(c) : c;
+				c = d == 0 ? c : bt_comp(c);
+				if (i >= span) continue;
+				const unsigned ne = nb + i;
+				g.bif[0][ne] = BT_NONE; g.bif[1][ne] = BT_NONE;
+				if (i < m) {
+					g.ch[ne] = (uint8_t)c; g.op[ne] = 0;
+					g.pv[ne] = i ? ne - 1 : before0;
+					g.nx[ne] = i + 1 < m ? ne + 1 : Eafter;
+				} else g.ch[ne] = BT_DEAD_CHAR;
+			}
+			if (lane == 0) { g.nx[before0] = nb; g.pv[Eafter] = nb + m - 1; }
+		}
+		double acc = (double)firstPos;
+		const double ssize = (double)dT / (double)dS;
+		for (unsigned j0 = 0; j0 < dS; j0 += 64) {
+			const unsigned cnt = dS - j0 < 64u ? dS - j0 : 64u;
+			double mine = 0.0;
+			for (unsigned jj = 0; jj < cnt; jj++) { if (jj == lane) mine = acc; acc += ssize; }
+			const unsigned jx = j0 + lane, jc = jx < common ? jx : 0u;
+			const unsigned Pj = gsel<NC>(Tv, d == 0 ? k + jc : k + dT - 1u - jc);
+			if (jx < dS) {
+				unsigned long long pp = (unsigned long long)mine;
+				if (pp > lastPos) pp = lastPos;
+				const unsigned e = jx < common ? Pj : nb + (jx - dT);
+				g.op[e] = (unsigned)pp & BT_POS_MASK;
+			}
+		}
+	}
+	PC_ADD(12);
+	// element at step s of the target walk AFTER the replacement (every lane takes part)
+	auto newTg = [&](unsigned s) -> unsigned {
+		const unsigned idx = s >= k ? s - k : 0u, fj = d == 0 ? idx : dS - 1u - (idx < dS ? idx : 0u);
+		const unsigned inside = fj < common ? (d == 0 ? k + fj : k + dT - 1u - fj) : 0u;
+		const unsigned at = s < k ? s : s >= k + dS ? s - dS + dT : inside;
+		const unsigned v = gsel<NC>(Tv, at < nT ? at : 0u);
+		return (s >= k && s < k + dS && fj >= common) ? newbase + (fj - dT) : v;
+	};
+	// ---- 4c: the AddPoint actions of the copied source marks, in the reference's order (own strand, then opposite, per index)
+#pragma unroll
+	for (int u = 0; u < NC; u++) {
+		const unsigned x = lane + 64u * u, i = x <= dS ? x : 0u;
+		const unsigned e1 = newTg(i), e2 = newTg(dS + k - 1u - i);
+		unsigned o = (unsigned)__popcll(m1[u] & lt) + (unsigned)__popcll(m2[u] & lt);
+		for (int v = 0; v < u; v++) o += (unsigned)__popcll(m1[v]) + (unsigned)__popcll(m2[v]);
+		if (Sb[u] != BT_NONE) { w.act[3 * o] = d; w.act[3 * o + 1] = e1; w.act[3 * o + 2] = Sb[u]; o++; }
+		if (b2[u] != BT_NONE) { w.act[3 * o] = opp; w.act[3 * o + 1] = e2; w.act[3 * o + 2] = b2[u]; }
+	}
+	WSYNC();
+	PC_ADD(13);
+	// ---- 4d: the AddPoints (restored flanks merged by index, then the copied marks)
+	const unsigned nodebase = s_nodebase_g;
+	auto newT = [&](unsigned s) -> unsigned {                              // (pointer form, for the divergent code of wave_add_points)
+		if (s < k) return T[s];
+		if (s >= k + dS) return T[s - dS + dT];
+		unsigned idx = s - k, fj = d == 0 ? idx : dS - 1 - idx;
+		return fj < common ? (d == 0 ? T[k + fj] : T[k + dT - 1 - fj]) : newbase + (fj - dT);
+	};
+	if (total > 64u * AP_CHUNKS) {
+		if (lane == 0) {
+			unsigned node = nodebase;
+			unsigned a = 0, b = 0;
+			while (a < nlb || b < nlf) {
+				bool takeA = b >= nlf || (a < nlb && w.lb[2 * a] <= w.lf[2 * b]);
+				SIt p;
+				if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point_prepared(p, w.lb[2 * a + 1], node++); a++; }
+				else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point_prepared(p, w.lf[2 * b + 1], node++); b++; }
+			}
+			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], node++); }
+		}
+	} else {
+		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase);
+		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase);
+	}
+	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
+	WSYNC();
+	PC_ADD(15);
+}
+// the collapse of an ordered round / chain transaction: gather-first where the walks fit the register chunks
+__device__ __forceinline__ void wave_collapse_any(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, unsigned stampv, const int prof)
+{
+	const unsigned span = (w.c_dT > w.c_dS ? w.c_dT : w.c_dS) + g.k + 1u;
+	// (one chunk only: the three-chunk instantiation needs ~60 more registers, and inlined into k_commit it made EVERY transaction spill --
+	// 504 B of scratch, commit 40 -> 52 ms; longer branches keep the round-3 form)
+	if (!g.collapse_g || span > 64u) wave_collapse(g, t, w, lane, stampv, prof);
+	else wave_collapse_g<1>(g, t, w, lane, stampv, prof);
+}
+
 // ---- the caller side of BulgeWork::jscan: next member of [idJ, group end) that is still valid and whose endChar differs from I's
 // (bt_rb_next_j with 64 lanes x 4 members per step: member -> instance -> node -> dead flag is three dependent look-ups)
 __device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, unsigned lane)
@@ -1984,7 +2248,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				continue;
 			}
 			if (w.lazy) {
-				wave_collapse(g, t, w, lane, stampv, prof);
+				wave_collapse_any(g, t, w, lane, stampv, prof);
 				PH_ADD(5);
 				if (t.err) break;
 				wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
@@ -2012,7 +2276,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				}
 			}
 			PH_ADD(4);
-			wave_collapse(g, t, w, lane, stampv, prof);
+			wave_collapse_any(g, t, w, lane, stampv, prof);
 			PH_ADD(5);
 			if (t.err) break;
 			if (lane == 0 && w.c_dT > w.c_dS) {
@@ -3057,6 +3321,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	be.g.collapse_g = getenv("SBL_OLD_COLLAPSE") ? 0u : 1u;            // measurement switch: the round-3 collapse (a chain of dependent round trips) instead of the gather-first one
 	be.g.ab_estimate = getenv("SBL_NO_AB_ESTIMATE") ? 0u : 1u;         // measurement switch: AnyBulges of big ids without its counting pass
 	be.g.jscan_rounds = getenv("SBL_NO_JSCAN_ROUNDS") ? 0u : 1u;       // measurement switch
 	be.g.probe_pre = getenv("SBL_NO_PROBE_PRE") ? 0u : 1u;              // measurement switch: the endChar pre-pass of the probe (probe_endchars)
