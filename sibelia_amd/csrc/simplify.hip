@@ -1420,6 +1420,7 @@ template <int NC, class NewT>
 __device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, const unsigned *T, NewT newT, unsigned k, unsigned d, unsigned opp,
                                                 unsigned dS, unsigned nlb, unsigned nlf, unsigned total, unsigned s_nodebase)
 {
+	const unsigned t0 = T[0];
 	// One AddPoint per lane and chunk of 64 (up to NC x 64 of them: with dozens of strains half of all positions are
 	// bifurcations and a collapse copies 60 - 150 marks -- one lane doing them one after the other was 12 % of k_commit at 62 strains).
 	// seq = its place in the reference's order (flanks merged by index, look-back first at equal index, then the copied source
@@ -1445,7 +1446,10 @@ __device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, Bulg
 			sq = x; ad = w.act[3 * xa]; ae = w.act[3 * xa + 1]; ab = w.act[3 * xa + 2];
 		}
 		seq[c] = sq; ekey[c] = (ae << 1) | ad; lkey[c] = (ab << 1) | ad;
-		cur[c] = sq != BT_NONE && ab != BT_NONE ? g.bif[ad][ae] : 0u;
+		// what the element carries NOW is known without a look: EraseBifurcations has just cleared both strands over the whole range the
+		// AddPoints fall into (flanks and replaced span; new elements start unmarked) -- except the own-strand mark of the target instance
+		// itself (step 0 is never erased, bulgeremoval.cpp:87-93), which the copy of the source's own mark at step 0 runs into
+		cur[c] = sq != BT_NONE && ab != BT_NONE ? (ad == d && ae == t0 ? 0u : BT_NONE) : 0u;
 	}
 #pragma unroll
 	for (int c = 0; c < NC; c++) valid[c] = seq[c] != BT_NONE && (lkey[c] >> 1) != BT_NONE && cur[c] == BT_NONE;
