@@ -32,6 +32,7 @@
 // stage and would otherwise burn the element pool 32 slots at a time (grow + replay of the iteration, again and again).
 #define BT_INSERT_ALIGN 1u
 #define BT_LAZY_MIN 64u           // see BulgeWork::lazy
+#define BT_ACT_FAST 64u           // see BulgeWork::act_fast
 #define BT_MSCAN_MIN 6u           // see BulgeWork::mscan
 __host__ __device__ __forceinline__ uint32_t bt_insert_span(uint32_t m) { return (m + BT_INSERT_ALIGN - 1u) & ~(BT_INSERT_ALIGN - 1u); }
 
@@ -63,6 +64,8 @@ struct GraphView {
 	uint32_t round_bits;                // (ROUND_MAX - round) << 20
 	const uint32_t *win;                // ids of the current window
 	uint32_t lazy_min;                  // a run with more instances than this that has the graph to itself rescans windows on demand (0: default, BT_LAZY_MIN)
+	uint32_t test_flags;                // A/B switches of experiments (SBL_TEST_FLAGS)
+	uint32_t lazy_rescan;               // ordered rounds: dirty windows are marked stale instead of rescanned at once (BulgeWork::use_stale)
 	uint32_t collapse_g;                // ordered rounds / chain: the gather-first collapse (simplify.hip: wave_collapse_g)
 	uint32_t ab_estimate;               // AnyBulges of ids with more than 32 instances sizes its tables by an estimate instead of a counting pass (simplify.hip)
 	uint32_t jscan_rounds;              // ordered rounds: ids with more than 24 instances hand the search for the next J to 64 lanes (BulgeWork::jscan)
@@ -412,6 +415,12 @@ struct BulgeWork {
 	// few hundred bases (dense regime) make nearly every cached window see every collapse: eager is O(instances) per collapse,
 	// lazy two window scans.  bt_rb_run returns 2 with the windows it needs in req[].
 	bool lazy;
+	// ... or, in an ordered round (where the set of windows a collapse dirties is computed anyway): those windows are only MARKED stale and
+	// rescanned when the loops next read them (bt_rb_run returns 2).  The usual dirty window is the target's own, which nobody reads
+	// again once its endChar equals the source's -- a transaction that collapses seven instances onto one rescanned seven windows for nothing,
+	// and such transactions are what a round waits for.  Up to 256 instances (bit per window); visit(I) is NOT refreshed, as in the reference.
+	bool use_stale;
+	unsigned long long stale[4];
 	uint32_t epoch, *wep;
 	uint32_t req[2], nreq;
 	// The J loop of a group skips members that are no longer valid or share I's endChar (bulgeremoval.cpp:383-386): one look per
@@ -423,6 +432,7 @@ struct BulgeWork {
 	// INSIDE a branch: a handful of dependent look-ups where bifurcations are sparse, dozens where every other position is one (many
 	// strains).  With mscan set bt_rb_run hands branches with more than BT_MSCAN_MIN marks inside to the caller (returns 4: evaluate
 	// mq_* with all lanes -- one look-up per lane, the same stamps -- into mres[], set mready, call again).
+	uint32_t nold;               // SBL_PHASES=1: collapses of this transaction that took the round-3 form
 	bool mscan, mready;
 	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
@@ -436,6 +446,7 @@ struct BulgeWork {
 	// the collapse bt_rb_run has decided on (performed by the caller: bt_collapse on one thread, or 64 lanes in simplify.hip)
 	uint32_t c_src, c_dS, c_tgt, c_dT;
 	uint32_t *act;               // scratch for the wave-wide collapse: (strand, element, id) AddPoint actions
+	uint32_t *act_fast;          // ... up to BT_ACT_FAST of them in the fast scratch
 };
 
 __host__ __device__ __forceinline__ SIt bt_deref(Txn &t, uint32_t packed) { SIt a; a.e = t.g.nslot[packed >> 1]; a.d = packed & 1; return a; }
@@ -471,13 +482,14 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	w.wck = (char *)t.alloc2(n);
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mready = false;
+	w.use_stale = false; w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mready = false; w.nold = 0;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
 	if (!w.wmk) { w.wmk = (uint64_t *)t.alloc(n * w.ws * 8); w.mks = w.ws; }
 	w.lite = lite;
-	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr; w.dirty_big = nullptr;
+	w.wel = w.wbf = nullptr; w.wch = nullptr; w.wbk = w.wnb = w.wdel = nullptr; w.visit = nullptr; w.occ = nullptr; w.lb = w.lf = nullptr; w.act = nullptr; w.act_fast = nullptr; w.dirty_big = nullptr;
 	w.visit_cap = D; w.occ_cap = D + k;
 	if (!lite) {
 		w.wel = (uint32_t *)t.alloc(n * w.ws * 4);
@@ -491,6 +503,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 		w.occ = (uint32_t *)t.alloc(w.occ_cap * 4);
 		w.lb = (uint32_t *)t.alloc2(k * 8); w.lf = (uint32_t *)t.alloc2(k * 8);   // flank lists of a collapse: read back by other lanes, LDS when it fits
 		w.act = (uint32_t *)t.alloc((2 * D + 4) * 12);
+		w.act_fast = g.test_flags & 1u ? (uint32_t *)t.falloc(BT_ACT_FAST * 12) : nullptr;      // the usual few dozen AddPoint actions of a collapse stay in the fast scratch (nullptr: no room)
 		if (n > 256) w.dirty_big = (unsigned long long *)t.alloc(((n + 63) / 64) * 8);
 		if (n > lazy_min) { w.wep = (uint32_t *)t.alloc(n * 4); if (w.wep) for (uint32_t i = 0; i < n; i++) w.wep[i] = 0; }
 	}
@@ -998,6 +1011,11 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 					uint32_t nr = 0;
 					if (w.wep[kmerI] != w.epoch) w.req[nr++] = kmerI;
 					if (w.wep[kmerJ] != w.epoch) w.req[nr++] = kmerJ;
+					if (nr) { w.nreq = nr; return 2; }
+				} else if (w.use_stale) {
+					uint32_t nr = 0;
+					if ((w.stale[kmerI >> 6] >> (kmerI & 63u)) & 1ull) w.req[nr++] = kmerI;
+					if ((w.stale[kmerJ >> 6] >> (kmerJ & 63u)) & 1ull) w.req[nr++] = kmerJ;
 					if (nr) { w.nreq = nr; return 2; }
 				}
 				w.idJ++; w.jready = false;

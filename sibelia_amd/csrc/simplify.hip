@@ -864,6 +864,45 @@ __device__ __forceinline__ int probe_endchars(const GraphView &g, const BulgeWor
 {
 	const unsigned n = w.n, k = g.k;
 	if (k >= 63u) return 0;
+	if (k <= 31u) {
+		// k + 1 <= 32 steps: TWO windows per wave instruction (lanes 0 - 31 / 32 - 63), sixteen windows in flight -- the probe is issue-bound
+		const unsigned half = lane >> 5, hl = lane & 31u;
+		const unsigned wantm = k == 31u ? 0xFFFFFFFFu : (1u << (k + 1)) - 1u;
+		unsigned hmask = 0;
+		bool hviol = false;
+		for (unsigned i0 = 0; i0 < n; i0 += 16) {
+			unsigned sel[8], dir[8], chv[8], lnk[8], wmv[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) { const unsigned x = i0 + 2 * j + half, xx = x < n ? x : i0; sel[j] = ldx(&w.sel[xx]); dir[j] = ldx(&w.start[xx]) & 1u; }
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const bool inr = hl <= k && (dir[j] ? hl <= sel[j] : (unsigned long long)sel[j] + hl < g.cap_e);
+				const unsigned c = inr ? (dir[j] ? sel[j] - hl : sel[j] + hl) : sel[j];
+				chv[j] = g.ch[c]; lnk[j] = (dir[j] ? g.pv : g.nx)[c]; wmv[j] = g.wmax[c >> BT_BLOCK_SHIFT];
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				if (i0 + 2 * j >= n) break;
+				const bool mine = i0 + 2 * j + half < n;
+				const bool inr = hl <= k && (dir[j] ? hl <= sel[j] : (unsigned long long)sel[j] + hl < g.cap_e);
+				const unsigned c = dir[j] ? sel[j] - hl : sel[j] + hl;
+				const unsigned prev = __shfl_up(lnk[j], 1);
+				const unsigned good = (unsigned)(__ballot(inr && (hl == 0 || prev == c)) >> (32u * half)) & wantm;
+				const unsigned sep = (unsigned)(__ballot(inr && chv[j] == BT_SEP) >> (32u * half)) & wantm;
+				const unsigned firstsep = sep ? (unsigned)__builtin_ctz(sep) : 64u, firstbad = good != wantm ? (unsigned)__builtin_ctz(~good) : 64u;
+				const unsigned upto = firstsep < k + 1 ? firstsep : k + 1;
+				if (__any(mine && (firstbad < upto || (firstbad == firstsep && firstsep < 64u)))) return 0;
+				hviol |= mine && hl < upto && wmv[j] > tid;
+				const unsigned craw = __shfl(chv[j], 32u * half + k);
+				const char ec = dir[j] ? bt_comp((char)craw) : (char)craw;
+				if (mine && firstsep > k) hmask |= ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u;
+			}
+		}
+		hmask |= __shfl_xor(hmask, 32);
+		if (__popc(hmask) > 1) return 0;
+		if (__any(hviol)) wave_stamp(g, 0, tid, 3, id, 0, tid + 1);
+		return 1;
+	}
 	const unsigned long long want = (1ull << (k + 1)) - 1ull;
 	unsigned mask = 0;
 	bool viol = false;
@@ -1408,6 +1447,8 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 __device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
 __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
+__device__ unsigned long long g_round_max[4096];   // SBL_PHASES=1: per launch of k_commit (slot = round stamp slot / 4), the slowest transaction: (cycles << 24) | min(instances, 255) << 16 | old-form collapses << 8 | collapses
+__device__ unsigned g_old_collapses;
 #define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
 #ifndef AP_CHUNKS
@@ -1418,9 +1459,15 @@ __device__ unsigned long long g_txn_max[2];        // longest transaction: cycle
 // The AddPoints of a collapse, one per lane and chunk of 64 lanes (NC chunks: instantiated for 1 -- the usual few dozen -- and for AP_CHUNKS).
 template <int NC, class NewT>
 __device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane, const unsigned *T, NewT newT, unsigned k, unsigned d, unsigned opp,
-                                                unsigned dS, unsigned nlb, unsigned nlf, unsigned total, unsigned s_nodebase)
+                                                unsigned dS, unsigned nlb, unsigned nlf, unsigned total, unsigned s_nodebase, const unsigned *actp)
 {
 	const unsigned t0 = T[0];
+	// place of a restored flank mark in the reference's order = its place in its own list + the entries of the OTHER list it comes after:
+	// with both lists in one wave's registers (k <= 64) that count is a loop of shuffles, not a walk over the list in memory per lane
+	const bool inreg = nlb <= 64u && nlf <= 64u && (g.test_flags & 2u);
+	const unsigned my_lb = inreg && lane < nlb ? w.lb[2 * lane] : ~0u, my_lf = inreg && lane < nlf ? w.lf[2 * lane] : ~0u;
+	unsigned cnt_lb = 0;                                                   // lookForward entries with a smaller index than my lookBack entry
+	if (inreg) for (unsigned y = 0; y < nlf; y++) cnt_lb += __shfl(my_lf, y) < my_lb ? 1u : 0u;
 	// One AddPoint per lane and chunk of 64 (up to NC x 64 of them: with dozens of strains half of all positions are
 	// bifurcations and a collapse copies 60 - 150 marks -- one lane doing them one after the other was 12 % of k_commit at 62 strains).
 	// seq = its place in the reference's order (flanks merged by index, look-back first at equal index, then the copied source
@@ -1433,17 +1480,22 @@ __device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, Bulg
 	for (int c = 0; c < NC; c++) {
 		const unsigned x = lane + 64u * c;
 		unsigned sq = BT_NONE, ad = 0, ae = 0, ab = BT_NONE;
+		// (uniform part: the index of my lookForward entry and how many lookBack entries come before it)
+		const unsigned bi_u = x >= nlb && x < nlb + nlf ? x - nlb : 0u;
+		const unsigned idx_lf = inreg ? __shfl(my_lf, bi_u & 63u) : 0u;
+		unsigned cnt_lf = 0;
+		if (inreg) for (unsigned y = 0; y < nlb; y++) cnt_lf += __shfl(my_lb, y) <= idx_lf ? 1u : 0u;
 		if (x < nlb) {
-			unsigned idx = w.lb[2 * x], cc = 0;
-			for (unsigned y = 0; y < nlf; y++) cc += w.lf[2 * y] < idx;
+			unsigned idx = inreg ? my_lb : w.lb[2 * x], cc = cnt_lb;
+			if (!inreg) for (unsigned y = 0; y < nlf; y++) cc += w.lf[2 * y] < idx;
 			sq = x + cc; ad = opp; ae = T[k - 1 - idx]; ab = w.lb[2 * x + 1];
 		} else if (x < nlb + nlf) {
-			unsigned bi = x - nlb, idx = w.lf[2 * bi], cc = 0;
-			for (unsigned y = 0; y < nlb; y++) cc += w.lb[2 * y] <= idx;
+			unsigned bi = x - nlb, idx = inreg ? idx_lf : w.lf[2 * bi], cc = cnt_lf;
+			if (!inreg) for (unsigned y = 0; y < nlb; y++) cc += w.lb[2 * y] <= idx;
 			sq = bi + cc; ad = d; ae = newT(dS + idx); ab = w.lf[2 * bi + 1];
 		} else if (x < total) {
 			unsigned xa = x - nlb - nlf;
-			sq = x; ad = w.act[3 * xa]; ae = w.act[3 * xa + 1]; ab = w.act[3 * xa + 2];
+			sq = x; ad = actp[3 * xa]; ae = actp[3 * xa + 1]; ab = actp[3 * xa + 2];
 		}
 		seq[c] = sq; ekey[c] = (ae << 1) | ad; lkey[c] = (ab << 1) | ad;
 		// what the element carries NOW is known without a look: EraseBifurcations has just cleared both strands over the whole range the
@@ -1656,8 +1708,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], nd++); }
 		}
 	} else {
-		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase);
-		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase);
+		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase, w.act);
+		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, s_nodebase, w.act);
 	}
 	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
 	WSYNC();
@@ -1675,6 +1727,9 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 //   4  checks, then nothing but stores (erase, characters, links, new elements, positions), the AddPoint list, and the AddPoints.
 // Same effect as wave_collapse (the two erase loops fuse: the flank marks of the first are a subset of the range of the second, and
 // the order of erasure is unobservable -- lazy-erase chain and list sizes are order-free).  NC = 64-step chunks per window (1 or 3).
+#ifndef GATHER_CHUNKS_MAX
+#define GATHER_CHUNKS_MAX 1
+#endif
 template <int NC>
 __device__ __forceinline__ unsigned gsel(const unsigned (&r)[NC], unsigned x)      // r "at step x": every lane must take part
 {
@@ -1879,14 +1934,15 @@ __device__ __forceinline__ void wave_collapse_g(const GraphView &g, Txn &t, Bulg
 		return (s >= k && s < k + dS && fj >= common) ? newbase + (fj - dT) : v;
 	};
 	// ---- 4c: the AddPoint actions of the copied source marks, in the reference's order (own strand, then opposite, per index)
+	unsigned *const act = w.act_fast && nact <= BT_ACT_FAST ? w.act_fast : w.act;      // (the usual few dozen: through LDS, not through the arena)
 #pragma unroll
 	for (int u = 0; u < NC; u++) {
 		const unsigned x = lane + 64u * u, i = x <= dS ? x : 0u;
 		const unsigned e1 = newTg(i), e2 = newTg(dS + k - 1u - i);
 		unsigned o = (unsigned)__popcll(m1[u] & lt) + (unsigned)__popcll(m2[u] & lt);
 		for (int v = 0; v < u; v++) o += (unsigned)__popcll(m1[v]) + (unsigned)__popcll(m2[v]);
-		if (Sb[u] != BT_NONE) { w.act[3 * o] = d; w.act[3 * o + 1] = e1; w.act[3 * o + 2] = Sb[u]; o++; }
-		if (b2[u] != BT_NONE) { w.act[3 * o] = opp; w.act[3 * o + 1] = e2; w.act[3 * o + 2] = b2[u]; }
+		if (Sb[u] != BT_NONE) { act[3 * o] = d; act[3 * o + 1] = e1; act[3 * o + 2] = Sb[u]; o++; }
+		if (b2[u] != BT_NONE) { act[3 * o] = opp; act[3 * o + 1] = e2; act[3 * o + 2] = b2[u]; }
 	}
 	WSYNC();
 	PC_ADD(13);
@@ -1908,11 +1964,11 @@ __device__ __forceinline__ void wave_collapse_g(const GraphView &g, Txn &t, Bulg
 				if (takeA) { p.e = T[k - 1 - w.lb[2 * a]]; p.d = opp; t.add_point_prepared(p, w.lb[2 * a + 1], node++); a++; }
 				else { p.e = newT(dS + w.lf[2 * b]); p.d = d; t.add_point_prepared(p, w.lf[2 * b + 1], node++); b++; }
 			}
-			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = w.act[3 * x]; p.e = w.act[3 * x + 1]; t.add_point_prepared(p, w.act[3 * x + 2], node++); }
+			for (unsigned x = 0; x < nact; x++) { SIt p; p.d = act[3 * x]; p.e = act[3 * x + 1]; t.add_point_prepared(p, act[3 * x + 2], node++); }
 		}
 	} else {
-		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase);
-		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase);
+		if (total <= 64u) wave_add_points<1>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase, act);
+		else wave_add_points<AP_CHUNKS>(g, t, w, lane, T, newT, k, d, opp, dS, nlb, nlf, total, nodebase, act);
 	}
 	if (lane == 0) { t.push_e = T[0]; t.push_d = d; t.push_len = dS; }
 	WSYNC();
@@ -1924,8 +1980,10 @@ __device__ __forceinline__ void wave_collapse_any(const GraphView &g, Txn &t, Bu
 	const unsigned span = (w.c_dT > w.c_dS ? w.c_dT : w.c_dS) + g.k + 1u;
 	// (one chunk only: the three-chunk instantiation needs ~60 more registers, and inlined into k_commit it made EVERY transaction spill --
 	// 504 B of scratch, commit 40 -> 52 ms; longer branches keep the round-3 form)
-	if (!g.collapse_g || span > 64u) wave_collapse(g, t, w, lane, stampv, prof);
-	else wave_collapse_g<1>(g, t, w, lane, stampv, prof);
+	if (prof && lane == 0 && (!g.collapse_g || span > 64u * GATHER_CHUNKS_MAX)) w.nold++;
+	if (!g.collapse_g || span > 64u * GATHER_CHUNKS_MAX) wave_collapse(g, t, w, lane, stampv, prof);
+	else if (span <= 64u) wave_collapse_g<1>(g, t, w, lane, stampv, prof);
+	else wave_collapse_g<GATHER_CHUNKS_MAX>(g, t, w, lane, stampv, prof);
 }
 
 // ---- the caller side of BulgeWork::jscan: next member of [idJ, group end) that is still valid and whose endChar differs from I's
@@ -2232,7 +2290,8 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
-		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = w.n > 24u && g.jscan_rounds; }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = w.n > 24u && g.jscan_rounds;
+			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
 		while (flag) {
@@ -2246,8 +2305,16 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
 				WSYNC();
-				if (lane == 0) for (unsigned x = 0; x < nr; x++) w.wep[w.req[x]] = w.epoch;
+				if (lane == 0) for (unsigned x = 0; x < nr; x++) { if (w.lazy) w.wep[w.req[x]] = w.epoch; else w.stale[w.req[x] >> 6] &= ~(1ull << (w.req[x] & 63u)); }
 				WSYNC();
+				if (!w.lazy && w.mk_overflow) {                              // (stale-marking rounds: more marks than the LDS lists hold)
+					if (lane == 0) bt_marks_to_arena(t, w);
+					WSYNC();
+					if (t.err) break;
+					for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+					if (lane == 0) w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
+					WSYNC();
+				}
 				PH_ADD(8);
 				continue;
 			}
@@ -2267,13 +2334,43 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			const bool big = w.n > 256, selective = !big || w.dirty_big != nullptr;
 			if (selective) {
 				const unsigned tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
+				if (w.use_stale && (w.stale[0] | w.stale[1] | w.stale[2] | w.stale[3])) {
+					// stale windows the collapse might reach (their old reach + what was deleted inside it since, or a walk with link breaks)
+					// are brought up to date FIRST: the test below then only ever sees fresh summaries, exactly as with eager rescans
+					bool any = false;
+					for (unsigned i0 = 0; i0 < w.n; i0 += 64) {
+						const unsigned i = i0 + lane;
+						bool f = false;
+						if (i < w.n && ((w.stale[i >> 6] >> (i & 63u)) & 1ull)) {
+							const unsigned len = (w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws) + w.wdel[i] + (w.c_dT > w.c_dS ? w.c_dT - w.c_dS : 0u);
+							const unsigned tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
+							f = w.wnb[i] != 0 || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0;
+						}
+						unsigned long long fresh = __ballot(f);
+						if (!fresh) continue;
+						any = true;
+						WSYNC();
+						if (lane == 0) w.stale[i0 >> 6] &= ~fresh;
+						for (; fresh; fresh &= fresh - 1) wave_scan_instance(g, w, i0 + (unsigned)__builtin_ctzll(fresh), lane, stampv, tid, 2, id);
+						WSYNC();
+					}
+					if (any && w.mk_overflow) {
+						if (lane == 0) bt_marks_to_arena(t, w);
+						WSYNC();
+						if (t.err) break;
+						for (unsigned i = 0; i < w.n; i++) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
+						if (lane == 0) w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
+						WSYNC();
+					}
+				}
 				for (unsigned i0 = 0; i0 < w.n; i0 += 64) {
 					unsigned i = i0 + lane;
 					bool d = false;
 					if (i < w.n) {
 						unsigned len = w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws;       // cached steps incl. the separator step
 						unsigned tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
-						d = i == tg || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0;
+						const bool st = w.use_stale && ((w.stale[i >> 6] >> (i & 63u)) & 1ull);      // (still stale = provably out of reach, see above)
+						d = i == tg || (!st && bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0);
 					}
 					const unsigned long long bits = __ballot(d);
 					if (!big) dirty[i0 >> 6] = bits; else if (lane == 0) w.dirty_big[i0 >> 6] = bits;
@@ -2297,6 +2394,12 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
 			PH_ADD(6);
 			PH_ADD(7);
+			if (w.use_stale) {                                              // marked, not rescanned: whoever reads one of them next asks for it (bt_rb_run returns 2)
+				if (lane == 0) for (unsigned q = 0; q < 4; q++) w.stale[q] |= dirty[q];
+				WSYNC();
+				PH_ADD(8);
+				continue;
+			}
 			for (unsigned i = 0; i < w.n; i++)
 				if (!selective || (((big ? w.dirty_big[i >> 6] : dirty[i >> 6]) >> (i & 63)) & 1ull)) wave_scan_instance(g, w, i, lane, stampv, tid, 2, id);
 			WSYNC();
@@ -2325,6 +2428,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			while (bin < 15 && (dur >> (13 + bin))) bin++;
 			atomicAdd(&g_txn_hist[w.ret < 3 ? w.ret : 3][bin], 1ull);
 			if (atomicMax(&g_txn_max[0], dur) < dur) g_txn_max[1] = ((unsigned long long)w.n << 32) | w.ret;
+			atomicMax(&g_round_max[(g.tslot >> 2) & 4095u], (dur << 24) | ((unsigned long long)(w.n < 255u ? w.n : 255u) << 16) | ((unsigned long long)(w.nold < 255u ? w.nold : 255u) << 8) | (w.ret < 255u ? w.ret : 255u));
 		}
 		if (t.err) {
 			if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
@@ -3322,9 +3426,12 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 16 * 8));
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_hist), z, 64 * 8));
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_max), z, 16));
+		{ std::vector<unsigned long long> zz(4096, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_max), zz.data(), 4096 * 8)); }
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	be.g.test_flags = getenv("SBL_TEST_FLAGS") ? (unsigned)atoi(getenv("SBL_TEST_FLAGS")) : 0u;
+	be.g.lazy_rescan = getenv("SBL_EAGER_RESCAN") ? 0u : 1u;            // measurement switch: dirty windows rescanned right after every collapse (round 3)
 	be.g.collapse_g = getenv("SBL_OLD_COLLAPSE") ? 0u : 1u;            // measurement switch: the round-3 collapse (a chain of dependent round trips) instead of the gather-first one
 	be.g.ab_estimate = getenv("SBL_NO_AB_ESTIMATE") ? 0u : 1u;         // measurement switch: AnyBulges of big ids without its counting pass
 	be.g.jscan_rounds = getenv("SBL_NO_JSCAN_ROUNDS") ? 0u : 1u;       // measurement switch
@@ -3461,6 +3568,13 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 			fprintf(stderr, "\n");
 		}
 		fprintf(stderr, "[sbl] longest transaction: %llu cycles, %llu instances, %llu collapses\n", mx[0], mx[1] >> 32, mx[1] & 0xFFFFFFFFull);
+		{
+			std::vector<unsigned long long> rm(4096);
+			HIP_TRY(hipMemcpyFromSymbol(rm.data(), HIP_SYMBOL(g_round_max), 4096 * 8));
+			fprintf(stderr, "[sbl] slowest transaction of every launch (kcycles/instances/old-form collapses/collapses):");
+			for (unsigned r = 0; r < 4096 && r < be.ts_round; r++) if (rm[r]) fprintf(stderr, " %llu/%llu/%llu/%llu", (rm[r] >> 24) / 1000, (rm[r] >> 16) & 255, (rm[r] >> 8) & 255, rm[r] & 255);
+			fprintf(stderr, "\n");
+		}
 	}
 	*bulges = rep.bulges;
 	return RUN_DONE;

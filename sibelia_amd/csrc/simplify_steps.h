@@ -98,13 +98,22 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	// cache changes: like k_commit (simplify.hip), only those are rescanned -- normally just the target's own window
 	uint64_t *dirty = more && !w.lazy ? (uint64_t *)t.alloc(((w.n + 63) / 64) * 8) : nullptr;
 	if (more && !w.lazy && !dirty) more = 0;
+	w.use_stale = more && !w.lazy && g.test_lazy_map != 0 && w.n <= 256;      // (tests/hostsim, HOSTSIM_LAZY_MAP: ... and stale-marking instead of eager rescans)
 	while (more) {
 		more = bt_rb_run(t, w);
 		if (t.err) break;
 		if (more == 3) bt_rb_next_j(t, w);
 		else if (more == 4) bt_rb_mults(t, w);
 		else if (more == 2) {                                          // lazy run: the loops need these windows as of now
-			for (uint32_t x = 0; x < w.nreq; x++) { bt_scan_instance(t, w, w.req[x]); w.wep[w.req[x]] = w.epoch; }
+			for (uint32_t x = 0; x < w.nreq; x++) {
+				bt_scan_instance(t, w, w.req[x]);
+				if (w.lazy) w.wep[w.req[x]] = w.epoch; else w.stale[w.req[x] >> 6] &= ~(1ull << (w.req[x] & 63));
+			}
+			if (!w.lazy && w.mk_overflow) {
+				bt_marks_to_arena(t, w);
+				if (!t.err) for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i);
+				w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
+			}
 			if (t.err) break;
 		} else if (more && w.lazy) {
 			bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT);
@@ -113,13 +122,23 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 		} else if (more) {
 			const uint32_t tg = w.c_tgt, span = 2 * g.k + w.c_dT + 1;
 			const uint32_t tl = w.wlen[tg] + 1 < w.ws ? w.wlen[tg] + 1 : w.ws;
+			if (w.use_stale)                                                // stale windows the collapse might reach are brought up to date first (as k_commit does)
+				for (uint32_t i = 0; i < w.n; i++)
+					if ((w.stale[i >> 6] >> (i & 63)) & 1ull) {
+						const uint32_t len = (w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws) + w.wdel[i] + (w.c_dT > w.c_dS ? w.c_dT - w.c_dS : 0u);
+						if (w.wnb[i] != 0 || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0) { bt_scan_instance(t, w, i); w.stale[i >> 6] &= ~(1ull << (i & 63)); }
+					}
+			if (w.mk_overflow) { bt_marks_to_arena(t, w); if (!t.err) for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0; }
 			for (uint32_t i = 0; i < w.n; i++) {
 				if ((i & 63) == 0) dirty[i >> 6] = 0;
 				const uint32_t len = w.wlen[i] + 1 < w.ws ? w.wlen[i] + 1 : w.ws;      // cached steps incl. the separator step
-				if (i == tg || bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0) dirty[i >> 6] |= 1ull << (i & 63);
+				const bool st = w.use_stale && ((w.stale[i >> 6] >> (i & 63)) & 1ull);
+				if (i == tg || (!st && bt_windows_intersect(w, i, len, tg, span < tl ? span : tl) != 0)) dirty[i >> 6] |= 1ull << (i & 63);
 			}
 			bt_collapse(t, w, w.c_src, w.c_dS, w.c_tgt, w.c_dT);
 			if (t.err) break;
+			if (w.c_dT > w.c_dS) for (uint32_t i = 0; i < w.n; i++) if ((dirty[i >> 6] >> (i & 63)) & 1ull) w.wdel[i] += w.c_dT - w.c_dS;
+			if (w.use_stale) { for (uint32_t q = 0; q < 4 && q < (w.n + 63) / 64; q++) w.stale[q] |= dirty[q]; continue; }
 			for (uint32_t i = 0; i < w.n; i++) if ((dirty[i >> 6] >> (i & 63)) & 1ull) bt_scan_instance(t, w, i);
 			if (w.mk_overflow) { bt_marks_to_arena(t, w); if (!t.err) for (uint32_t i = 0; i < w.n; i++) bt_scan_instance(t, w, i); }
 		}
