@@ -1265,6 +1265,93 @@ __device__ __forceinline__ unsigned wave_walk_claim(const GraphView &g, unsigned
 	return wave_walk_marks(g, first, dir, maxcount, lane, strands, [&](unsigned b0, unsigned b1) { wave_claim(g, cl, st, b0, lane); wave_claim(g, cl, st, b1, lane); }, sb);
 }
 
+// ---- the reservation walks of an instance, all at once ---------------------------------------------------------------------------
+// wave_walk_marks advances 64 elements per memory round trip because the next 64 are only known once the links of these have arrived:
+// the neighbourhood of an instance (core D + 2k + 3, then 2(D + k + 2) + k + 1 ahead and D + k + 2 behind) was 7 dependent round trips,
+// 28 for the four instances a reservation wave handles, and k_reserve is exactly that chain.  The list is laid out consecutively
+// almost everywhere, so the loads of ALL chunks of a walk are issued together for the slots the walk would visit if it is, the links
+// that came back are checked against that assumption, and only a walk that meets a link break (or could meet a separator: its span is
+// compared with the two separators of its chromosome beforehand, SepBounds) is done again by the step-wise walk.  Same elements
+// visited, same claims made.
+// all of e, e +- 1, ... (n elements in direction dir) lie strictly between the separators of e's chromosome
+__device__ __forceinline__ bool span_inside(const SepBounds &sp, unsigned e, unsigned dir, unsigned n)
+{
+	if (!sp.by || e == BT_NONE || n == 0) return false;
+	if (!dir) return e > sp.lo && (unsigned long long)e + n - 1 < sp.hi;
+	return e < sp.hi && (unsigned long long)e > (unsigned long long)sp.lo + n - 1;
+}
+#define RSV_CORE_CHUNKS 4
+#define RSV_FLANK_CHUNKS 3
+// core walk with exclusive claims on the marks of both strands; returns the element after the last one visited.  false: not done (step-wise walk needed)
+__device__ __forceinline__ bool wave_core_claim_burst(const GraphView &g, unsigned e0, unsigned dir, unsigned core, unsigned lane, ClaimList &cl, unsigned st,
+                                                     const SepBounds &sp, unsigned &nxt)
+{
+	if (core > 64u * RSV_CORE_CHUNKS || !span_inside(sp, e0, dir, core)) return false;
+	const unsigned *__restrict__ link = dir ? g.pv : g.nx;
+	unsigned b0[RSV_CORE_CHUNKS], b1[RSV_CORE_CHUNKS], lk[RSV_CORE_CHUNKS];
+#pragma unroll
+	for (int u = 0; u < RSV_CORE_CHUNKS; u++) {
+		const unsigned off = lane + 64u * u, x = off < core ? (dir ? e0 - off : e0 + off) : e0;
+		b0[u] = g.bif[0][x]; b1[u] = g.bif[1][x]; lk[u] = link[x];
+	}
+	bool good = true;
+#pragma unroll
+	for (int u = 0; u < RSV_CORE_CHUNKS; u++) {
+		const unsigned off = lane + 64u * u, x = dir ? e0 - off : e0 + off;
+		if (off + 1 < core) good = good && lk[u] == (dir ? x - 1 : x + 1);
+	}
+	if (__ballot(!good)) return false;
+#pragma unroll
+	for (int u = 0; u < RSV_CORE_CHUNKS; u++) {
+		if (64u * u >= core) break;
+		const bool in = lane + 64u * u < core;
+		wave_claim(g, cl, st, in ? b0[u] : BT_NONE, lane);
+		wave_claim(g, cl, st, in ? b1[u] : BT_NONE, lane);
+	}
+	unsigned last = 0;
+#pragma unroll
+	for (int u = 0; u < RSV_CORE_CHUNKS; u++) if ((core - 1) >> 6 == (unsigned)u) last = __shfl(lk[u], (core - 1) & 63u);
+	nxt = last;
+	return true;
+}
+// the two ordering walks of an instance (wave_walk_marks2 of k_reserve): ahead from nxt on the opposite strand's marks, behind from the
+// element before e0 on the own strand's marks.  false: not done
+template <class Order>
+__device__ __forceinline__ bool wave_flank_order_burst(const GraphView &g, unsigned e0, unsigned s, unsigned nxt, unsigned na, unsigned nb, unsigned lane,
+                                                      const SepBounds &sp, Order order)
+{
+	const unsigned da = s, db = s ^ 1u;
+	const unsigned bfirst = db ? e0 - 1 : e0 + 1;                          // the element before e0 in its walking direction, if the layout is consecutive there
+	if (na > 64u * RSV_FLANK_CHUNKS || nb > 64u * RSV_FLANK_CHUNKS || e0 == 0) return false;
+	if ((na && !span_inside(sp, nxt, da, na)) || !span_inside(sp, bfirst, db, nb)) return false;
+	const unsigned *__restrict__ linka = da ? g.pv : g.nx, *__restrict__ linkb = db ? g.pv : g.nx;
+	unsigned ma[RSV_FLANK_CHUNKS], la[RSV_FLANK_CHUNKS], mb[RSV_FLANK_CHUNKS], lb[RSV_FLANK_CHUNKS];
+	const unsigned l0 = linkb[e0];
+#pragma unroll
+	for (int u = 0; u < RSV_FLANK_CHUNKS; u++) {
+		const unsigned off = lane + 64u * u;
+		const unsigned xa = na && off < na ? (da ? nxt - off : nxt + off) : e0, xb = off < nb ? (db ? bfirst - off : bfirst + off) : e0;
+		ma[u] = g.bif[s ^ 1u][xa]; la[u] = linka[xa];
+		mb[u] = g.bif[s][xb]; lb[u] = linkb[xb];
+	}
+	bool good = l0 == bfirst;
+#pragma unroll
+	for (int u = 0; u < RSV_FLANK_CHUNKS; u++) {
+		const unsigned off = lane + 64u * u;
+		const unsigned xa = da ? nxt - off : nxt + off, xb = db ? bfirst - off : bfirst + off;
+		if (off + 1 < na) good = good && la[u] == (da ? xa - 1 : xa + 1);
+		if (off + 1 < nb) good = good && lb[u] == (db ? xb - 1 : xb + 1);
+	}
+	if (__ballot(!good)) return false;
+#pragma unroll
+	for (int u = 0; u < RSV_FLANK_CHUNKS; u++) {
+		const unsigned off = lane + 64u * u;
+		if (64u * u < na) order(off < na ? ma[u] : BT_NONE);
+		if (64u * u < nb) order(off < nb ? mb[u] : BT_NONE);
+	}
+	return true;
+}
+
 // After a collapse: publish the writes of the transaction (everything from the target instance to the end of its
 // look-forward flank had marks, characters, positions or links rewritten), check that no higher id read or wrote them, and
 // make every id whose window can see the region and that is still ahead in the order pending (bt_push_neighbourhood with
@@ -1276,6 +1363,66 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 	const SepBounds sp = sep_bounds(g, sepl, e, lane);                      // the region and both walks stay in the chromosome of e
 	const unsigned reach = g.D + g.k + 2, tid = id + 1, nstamp = newlen + 2 * g.k, nreg = nstamp + 1;
 	auto push1 = [&](unsigned b) { if (b != BT_NONE && b < g.nid) { g.touch[b] = 1; if (b > id) g.need[b] = 1; } };
+	// ---- everything at once where the list is laid out consecutively (a collapse that replaced a branch by one of the same length: the
+	// usual SNP bulge): the region, the upstream and the downstream walk were up to seven dependent memory round trips of every collapse;
+	// the loads of all their chunks are issued together for the slots the walks would visit, and the links that come back say whether
+	// they did (see wave_core_claim_burst).  Anything else -- inserted elements, a separator in reach -- takes the step-wise walks below.
+	{
+		enum { RC = 4, FC = 3 };
+		const unsigned ub = d ? e + 1 : e - 1;                              // the element before e in its walking direction, if consecutive
+		if (!(g.test_flags & 8u) && nreg <= 64u * RC && reach <= 64u * FC && e != 0 && span_inside(sp, e, d, nreg + reach) && span_inside(sp, ub, d ^ 1u, reach)) {
+			const unsigned *__restrict__ lf = d ? g.pv : g.nx, *__restrict__ lb = d ? g.nx : g.pv;
+			unsigned r0[RC], r1[RC], rl[RC], um[FC], ul[FC], dm[FC], dl[FC];
+			const unsigned l0 = lb[e], dfirst = d ? e - nreg : e + nreg;
+#pragma unroll
+			for (int u = 0; u < RC; u++) {
+				const unsigned off = lane + 64u * u, x = off < nreg ? (d ? e - off : e + off) : e;
+				r0[u] = g.bif[0][x]; r1[u] = g.bif[1][x]; rl[u] = lf[x];
+			}
+#pragma unroll
+			for (int u = 0; u < FC; u++) {
+				const unsigned off = lane + 64u * u;
+				const unsigned xu = off < reach ? (d ? ub + off : ub - off) : e, xd = off < reach ? (d ? dfirst - off : dfirst + off) : e;
+				um[u] = g.bif[d][xu]; ul[u] = lb[xu];
+				dm[u] = g.bif[d ^ 1u][xd]; dl[u] = lf[xd];
+			}
+			bool good = l0 == ub;
+#pragma unroll
+			for (int u = 0; u < RC; u++) {
+				const unsigned off = lane + 64u * u, x = d ? e - off : e + off;
+				if (off < nreg) good = good && rl[u] == (d ? x - 1 : x + 1);          // (the last one leads to the first element downstream)
+			}
+#pragma unroll
+			for (int u = 0; u < FC; u++) {
+				const unsigned off = lane + 64u * u;
+				const unsigned xu = d ? ub + off : ub - off, xd = d ? dfirst - off : dfirst + off;
+				if (off + 1 < reach) good = good && ul[u] == (d ? xu + 1 : xu - 1) && dl[u] == (d ? xd - 1 : xd + 1);
+			}
+			if (!__ballot(!good)) {
+#pragma unroll
+				for (int u = 0; u < RC; u++) {
+					const unsigned off = lane + 64u * u, c = d ? e - off : e + off;
+					if (off < nreg) {
+						push1(r0[u]); push1(r1[u]);
+						if (off < nstamp) {
+							unsigned a = atomicMax(&g.wmax[c], tid);
+							unsigned rm = g.rmax[c];
+							if (a > tid || rm > tid) {
+								atomicMin(&g.ctr[CTR_VIOL], id);
+								if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 4u) == 0u) { g.ctr[CTR_DETAIL + 1] = c; g.ctr[CTR_DETAIL + 2] = (a > rm ? a : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
+							}
+						}
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < FC; u++) {
+					const unsigned off = lane + 64u * u;
+					if (off < reach) { push1(um[u]); push1(dm[u]); }
+				}
+				return;
+			}
+		}
+	}
 	// ---- the region
 	unsigned cur = e, done = 0;
 	bool open = true;
@@ -1376,17 +1523,24 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	// stale, which orders it against them (bt_footprint, bulge_txn.h); instances walking away cannot see or touch it.
 	auto order = [&](unsigned b0, unsigned b1) { wave_claim_order(g, cl, st, id, b0, lane); wave_claim_order(g, cl, st, id, b1, lane); };
 	const unsigned ninst = ninst_s;
+	const bool burst = !(g.test_flags & 4u);                          // (SBL_TEST_FLAGS=4: the step-wise walks everywhere, for A/B runs)
 	if (ninst <= RESUME_SLOTS) {
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
-			unsigned nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st, sep_bounds(g, sepl, inst[i] >> 1, lane));
+			const SepBounds sp = sep_bounds(g, sepl, inst[i] >> 1, lane);
+			unsigned nxt = BT_NONE;
+			if (!burst || !wave_core_claim_burst(g, inst[i] >> 1, inst[i] & 1u, core, lane, cl, st, sp, nxt))
+				nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st, sp);
 			if (lane == 0) resume[i] = nxt;
 		}
 		__syncthreads();
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {
 			const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
+			const SepBounds sp = sep_bounds(g, sepl, e0, lane);
 			// further downstream (opposite strand) and upstream (same strand) together; all three walks of an instance stay in its chromosome
+			if (burst && wave_flank_order_burst(g, e0, s, fwd + 1 > core ? nxt : BT_NONE, fwd + 1 > core ? fwd + 1 - core : 0u, back, lane, sp,
+			                                    [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) continue;
 			wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
-			                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sep_bounds(g, sepl, e0, lane));
+			                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sp);
 		}
 	} else {                                                          // more instances than the LDS list holds: walk the node lists
 		unsigned k1 = 0;
@@ -1449,7 +1603,9 @@ __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
 __device__ unsigned long long g_round_max[4096];   // SBL_PHASES=1: per launch of k_commit (slot = round stamp slot / 4), the slowest transaction: (cycles << 24) | min(instances, 255) << 16 | old-form collapses << 8 | collapses
 __device__ unsigned g_old_collapses;
-#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t
+__device__ unsigned long long g_round_span[4096 * 3];   // SBL_PHASES=1, per launch (wall clock, 10 ns ticks): earliest start of an owner, latest end, (duration << 32) | start of the slowest
+__device__ unsigned long long g_round_few[4096 * 2];    // ... and the slowest transaction with at most one / at most two collapses
+#define PH_T0() unsigned long long ph_t = prof ? __builtin_readcyclecounter() : 0ull; const unsigned long long ph_start = ph_t; const unsigned long long ph_wall = prof ? wall_clock64() : 0ull
 #define PH_ADD(i) do { if (prof && lane == 0) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - ph_t); ph_t = n_; } } while (0)
 #ifndef AP_CHUNKS
 #define AP_CHUNKS 4                          // AddPoints of a collapse handled one per lane: up to AP_CHUNKS x 64 (more: one lane, one after the other)
@@ -2428,6 +2584,13 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			while (bin < 15 && (dur >> (13 + bin))) bin++;
 			atomicAdd(&g_txn_hist[w.ret < 3 ? w.ret : 3][bin], 1ull);
 			if (atomicMax(&g_txn_max[0], dur) < dur) g_txn_max[1] = ((unsigned long long)w.n << 32) | w.ret;
+			{
+				const unsigned long long now = wall_clock64(), sl = (g.tslot >> 2) & 4095u;
+				atomicMin(&g_round_span[3 * sl], ph_wall); atomicMax(&g_round_span[3 * sl + 1], now);
+				atomicMax(&g_round_span[3 * sl + 2], ((now - ph_wall) << 32) | (ph_wall & 0xFFFFFFFFull));
+				if (w.ret <= 1) atomicMax(&g_round_few[2 * sl], now - ph_wall);
+				if (w.ret <= 2) atomicMax(&g_round_few[2 * sl + 1], now - ph_wall);
+			}
 			atomicMax(&g_round_max[(g.tslot >> 2) & 4095u], (dur << 24) | ((unsigned long long)(w.n < 255u ? w.n : 255u) << 16) | ((unsigned long long)(w.nold < 255u ? w.nold : 255u) << 8) | (w.ret < 255u ? w.ret : 255u));
 		}
 		if (t.err) {
@@ -3427,6 +3590,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_hist), z, 64 * 8));
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_max), z, 16));
 		{ std::vector<unsigned long long> zz(4096, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_max), zz.data(), 4096 * 8)); }
+		{ std::vector<unsigned long long> zz(4096 * 2, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_few), zz.data(), 4096 * 2 * 8)); }
+		{ std::vector<unsigned long long> zz(4096 * 3, 0); for (unsigned r = 0; r < 4096; r++) zz[3 * r] = ~0ull; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_span), zz.data(), 4096 * 3 * 8)); }
 	}
 	be.bind();
 	be.g.k = k; be.g.D = D;
@@ -3571,6 +3736,23 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		{
 			std::vector<unsigned long long> rm(4096);
 			HIP_TRY(hipMemcpyFromSymbol(rm.data(), HIP_SYMBOL(g_round_max), 4096 * 8));
+			{
+				// does a launch of k_commit wait for work that started late, or for one long transaction?  (round 4: the slowest transaction of a
+				// launch starts ~5 us after the first and IS the launch -- nothing to gain from dispatching long ones first)
+				std::vector<unsigned long long> sp(4096 * 3);
+				HIP_TRY(hipMemcpyFromSymbol(sp.data(), HIP_SYMBOL(g_round_span), 4096 * 3 * 8));
+				std::vector<unsigned long long> fw(4096 * 2);
+				HIP_TRY(hipMemcpyFromSymbol(fw.data(), HIP_SYMBOL(g_round_few), 4096 * 2 * 8));
+				double span = 0, slow = 0, off = 0, few1 = 0, few2 = 0; unsigned nl = 0;
+				for (unsigned r = 0; r < 4096; r++) {
+					if (sp[3 * r] == ~0ull || !sp[3 * r + 1]) continue;
+					nl++; span += (double)(sp[3 * r + 1] - sp[3 * r]) * 0.01; slow += (double)(sp[3 * r + 2] >> 32) * 0.01;
+					off += (double)(unsigned)((unsigned)sp[3 * r + 2] - (unsigned)sp[3 * r]) * 0.01;
+					few1 += (double)fw[2 * r] * 0.01; few2 += (double)fw[2 * r + 1] * 0.01;
+				}
+				fprintf(stderr, "[sbl] slowest transactions with at most one collapse %.1f us in total, with at most two %.1f us\n", few1, few2);
+				fprintf(stderr, "[sbl] %u commit launches: owners' span %.1f us in total, slowest transactions %.1f us, their start offsets %.1f us\n", nl, span, slow, off);
+			}
 			fprintf(stderr, "[sbl] slowest transaction of every launch (kcycles/instances/old-form collapses/collapses):");
 			for (unsigned r = 0; r < 4096 && r < be.ts_round; r++) if (rm[r]) fprintf(stderr, " %llu/%llu/%llu/%llu", (rm[r] >> 24) / 1000, (rm[r] >> 16) & 255, (rm[r] >> 8) & 255, rm[r] & 255);
 			fprintf(stderr, "\n");
