@@ -835,13 +835,19 @@ __host__ __device__ inline void bt_collapse(Txn &t, BulgeWork &w, uint32_t srcK,
 // the look-ups that change nothing); both go through bt_ab_prepare / bt_ab_insert / bt_ab_append / bt_ab_finish, so the
 // sequence of operator[] insertions -- and with it the iteration order -- is the same.
 // cap: upper bound of the number of distinct ids that get an entry (the total number of marks is always one).
-__host__ __device__ inline bool bt_ab_prepare(Txn &t, BulgeWork &w, uint32_t cap)
+// lazy: the insertions are only logged (ABuild::lazy); the node links and buckets of the Boost restatement are then allocated by
+// bt_ab_finish, and only for a call that ends with two or more groups.  Without them an entry takes 29 bytes instead of 45, and the map
+// of a typical id (50 - 60 reached ids) fits what a transaction has left of its LDS scratch: in the arena every append and every step of
+// bt_ab_finish's loops was a memory round trip of its own on lane 0 -- the larger part of the "rb_begin" phase of k_commit.
+__host__ __device__ inline bool bt_ab_prepare(Txn &t, BulgeWork &w, uint32_t cap, bool lazy = false)
 {
 	ABuild &a = w.abb;
 	uint32_t n = w.n;
 	if (cap < 16) cap = 16;
 	// the map goes to the fast scratch (LDS) when it fits there, otherwise it takes whatever arena is left
-	bool fast = t.fscr && (t.fscr_cap - ((t.fscr_used + 7u) & ~7u)) / 48 >= cap + n / 2 + 2;
+	// (lazy: key 4 + echar 1 + head / tail / cnt 12 per entry, the log 8 per entry and instance, 8 bytes of alignment for each of the 7 arrays)
+	const uint32_t ffree = t.fscr ? t.fscr_cap - ((t.fscr_used + 7u) & ~7u) : 0u;
+	bool fast = lazy ? ffree >= 17u * cap + 8u * (cap + n) + 64u : ffree / 48 >= cap + n / 2 + 2;
 	if (!fast) {
 		uint32_t left = t.scr_cap - ((t.scr_used + 7u) & ~7u);
 		uint32_t fit = left / 48;                    // key 4 + nxt 4 + echar 1 + head/tail/cnt 12 + buckets 2x4 + log 2x8 < 48
@@ -853,14 +859,16 @@ __host__ __device__ inline bool bt_ab_prepare(Txn &t, BulgeWork &w, uint32_t cap
 	if (bcap < 16) bcap = 16;
 	BoostMap &m = a.m;
 	auto A = [&](uint32_t bytes) { return fast ? t.alloc2(bytes) : t.alloc(bytes); };
-	m.key = (uint32_t *)A(cap * 4); m.nxt = (int32_t *)A(cap * 4); m.bprev = (int32_t *)A(bcap * 4);
+	m.key = (uint32_t *)A(cap * 4);
+	m.nxt = nullptr; m.bprev = nullptr;
+	if (!lazy) { m.nxt = (int32_t *)A(cap * 4); m.bprev = (int32_t *)A(bcap * 4); }
 	a.echar = (char *)A(cap);
 	a.mhead = (uint32_t *)A(cap * 4); a.mtail = (uint32_t *)A(cap * 4); a.mcnt = (uint32_t *)A(cap * 4);
 	a.logcap = cap + n;
 	a.log_inst = (uint32_t *)A(a.logcap * 4); a.log_next = (uint32_t *)A(a.logcap * 4);
 	if (t.err) return false;
 	m.size = 0; m.cap = cap; m.bc = 0; m.bcap = bcap; m.first = -1; m.started = false;
-	a.nlog = 0; a.any = false; a.lazy = false;
+	a.nlog = 0; a.any = false; a.lazy = lazy;
 	return true;
 }
 // id b is reached by instance i and has no entry yet: operator[] creates it.  Returns the entry or -1 (scratch exhausted).
@@ -896,12 +904,24 @@ __host__ __device__ inline bool bt_ab_finish(Txn &t, BulgeWork &w)
 	if (a.lazy) {
 		int32_t only = -1;
 		for (uint32_t p = 0; p < m.size; p++) if (a.mcnt[p] > 1) { ng++; total += a.mcnt[p]; only = (int32_t)p; }
-		if (ng >= 2) {                                    // the order matters: the logged insertions through the Boost restatement, in order
-			const uint32_t n = m.size;
-			m.size = 0;
-			for (uint32_t i = 0; i < n; i++) if (bm_insert(m, m.key[i]) != (int32_t)i) { t.err |= BT_ERR_SCRATCH; return false; }
-		} else { m.first = only; if (only >= 0) m.nxt[only] = -1; }
 		a.lazy = false;
+		if (ng < 2) {                                     // one group (the usual case): no iteration order to reproduce
+			w.ab.grp_off = (uint32_t *)t.alloc2(2 * 4);
+			w.ab.grp_mem = (uint32_t *)t.alloc2(total * 4);
+			if (t.err || only < 0) return false;
+			uint32_t o = 0;
+			w.ab.grp_off[0] = 0;
+			for (uint32_t l = a.mhead[only]; l != BT_NONE; l = a.log_next[l]) w.ab.grp_mem[o++] = a.log_inst[l];
+			w.ab.grp_off[1] = o;
+			w.ab.ngroups = 1;
+			return true;
+		}
+		// the order matters: the logged insertions through the Boost restatement, in order (its links and buckets are allocated now)
+		m.nxt = (int32_t *)t.alloc2(m.cap * 4); m.bprev = (int32_t *)t.alloc2(m.bcap * 4);
+		if (t.err) return false;
+		const uint32_t n = m.size;
+		m.size = 0;
+		for (uint32_t i = 0; i < n; i++) if (bm_insert(m, m.key[i]) != (int32_t)i) { t.err |= BT_ERR_SCRATCH; return false; }
 		ng = 0; total = 0;
 	}
 	for (int32_t p = m.first; p != -1; p = m.nxt[p]) if (a.mcnt[p] > 1) { ng++; total += a.mcnt[p]; }
@@ -925,9 +945,8 @@ __host__ __device__ inline bool bt_any_bulges(Txn &t, BulgeWork &w, bool verdict
 	uint32_t D = t.g.D, n = w.n;
 	uint32_t marks = 0;
 	for (uint32_t i = 0; i < n; i++) marks += w.wmn[i];
-	if (!bt_ab_prepare(t, w, marks)) return false;
+	if (!bt_ab_prepare(t, w, marks, t.g.test_lazy_map != 0 && !verdict_only)) return false;      // (tests/hostsim: the lazy build of the kernels' wave_any_bulges, with a linear search as its shadow table)
 	ABuild &a = w.abb;
-	a.lazy = t.g.test_lazy_map != 0 && !verdict_only;      // (tests/hostsim: the lazy build of the kernels' wave_any_bulges, with a linear search as its shadow table)
 	for (uint32_t i = 0; i < n; i++) {
 		if (w.endc[i] == ' ') continue;
 		const uint64_t *mk = w.wmk + (size_t)i * w.mks;

@@ -1598,7 +1598,7 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 	if (b < g.nid) { g.touch[b] = 1; if (b > t.id) g.need[b] = 1; }
 }
 
-__device__ unsigned long long g_phase_cycles[16];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
+__device__ unsigned long long g_phase_cycles[24];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
 __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
 __device__ unsigned long long g_round_max[4096];   // SBL_PHASES=1: per launch of k_commit (slot = round stamp slot / 4), the slowest transaction: (cycles << 24) | min(instances, 255) << 16 | old-form collapses << 8 | collapses
@@ -2228,18 +2228,69 @@ __device__ __forceinline__ void lane_scan_marks(const GraphView &g, const BulgeW
 // by the total number of marks.  Falls back to bt_any_bulges when the tables do not fit.
 struct ABShared { unsigned *skey, *sval; unsigned bits, distinct; int mode; unsigned batch[64]; };   // mode 0: serial fallback, 1: wave path
 
+// The lane-0 part of the map-building pass (logged insertions of ABuild::lazy, bulge_txn.h: bt_ab_insert / bt_ab_append), with the
+// fields of the build hoisted out of the loop and, where every array is in LDS (<true>), DS instead of FLAT accesses: as calls of
+// bt_ab_insert each of the ~18 insertions of a typical id re-loaded a dozen pointers and counters of the structure through generic
+// pointers, 2 - 3 k cycles apiece -- most of the "rb_begin" phase of a transaction.
+// what: 1 = `run` new ids of instance i (sh.batch), 2 = instance i joins entry kt.  Returns the new sh.mode (> 0: fine).
+template <bool L>
+__device__ __forceinline__ int ab_lazy_lane0(Txn &t, BulgeWork &w, ABShared &sh, unsigned what, unsigned i, char ec, unsigned run, unsigned kt_join,
+                                             unsigned slots, unsigned shift, bool estimate)
+{
+	ABuild &a = w.abb;
+	unsigned *key = a.m.key, *mhead = a.mhead, *mtail = a.mtail, *mcnt = a.mcnt, *log_inst = a.log_inst, *log_next = a.log_next, *skey = sh.skey, *sval = sh.sval;
+	char *echar = a.echar;
+	BT_ASSUME_LDS(L, key); BT_ASSUME_LDS(L, mhead); BT_ASSUME_LDS(L, mtail); BT_ASSUME_LDS(L, mcnt); BT_ASSUME_LDS(L, log_inst); BT_ASSUME_LDS(L, log_next);
+	BT_ASSUME_LDS(L, skey); BT_ASSUME_LDS(L, sval); BT_ASSUME_LDS(L, echar);
+	unsigned size = a.m.size, nlog = a.nlog;
+	const unsigned cap = a.m.cap, logcap = a.logcap, distinct = sh.distinct;
+	int mode = sh.mode;
+	if (what == 2u) {
+		if (nlog >= logcap) { t.err |= BT_ERR_SCRATCH; return -1; }
+		log_inst[nlog] = i; log_next[nlog] = BT_NONE;
+		log_next[mtail[kt_join]] = nlog; mtail[kt_join] = nlog++; mcnt[kt_join]++;
+		a.any = true; a.nlog = nlog;
+		return mode;
+	}
+	for (unsigned x = 0; x < run; x++) {
+		const unsigned bb = sh.batch[x];
+		unsigned hh = (bb * 2654435761u) >> shift;
+		unsigned kk = skey[hh];
+		while (kk != BT_NONE && kk != bb) { hh = (hh + 1) & (slots - 1); kk = skey[hh]; }
+		if (kk == bb) continue;                                          // the id occurs twice in this window: second look-up finds the entry just made
+		if (estimate && size >= distinct) { mode = -2; break; }            // more distinct ids than estimated: again, with the counting pass
+		if (size >= cap || nlog >= logcap) { t.err |= BT_ERR_SCRATCH; mode = -1; break; }
+		const unsigned kt = size++;
+		key[kt] = bb; echar[kt] = ec;
+		log_inst[nlog] = i; log_next[nlog] = BT_NONE;
+		mhead[kt] = nlog; mtail[kt] = nlog; mcnt[kt] = 1; nlog++;
+		skey[hh] = bb; sval[hh] = (kt << 8) | (unsigned char)ec;
+	}
+	a.m.size = size; a.nlog = nlog;
+	return mode;
+}
+
+
 #define AB_COUNT_SLOTS 512u
 // count_slots: size of the distinct-id counting set (a power of two >= AB_COUNT_SLOTS; the dense kernel has room for more)
 __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane, bool endc_ready = false,
-                                               const unsigned count_slots = AB_COUNT_SLOTS, unsigned *count_tab = nullptr /* caller's own table of count_slots words */)
+                                               const unsigned count_slots = AB_COUNT_SLOTS, unsigned *count_tab = nullptr /* caller's own table of count_slots words */,
+                                               int prof = 0)
 {
+	PC_T0();
 	const unsigned D = g.D, n = w.n;
+	// (the window summaries through explicit address spaces -- ldx: DS or global instead of FLAT, see the top of this file)
+	char *const endc = w.endc; const char *const wck = w.wck;
+	const unsigned *const wst = w.wst, *const wlen = w.wlen, *const wmn = w.wmn;
+	const unsigned long long *const wmk = reinterpret_cast<const unsigned long long *>(w.wmk);
+	const unsigned mks = w.mks;
 	const unsigned cshift = 32u - (unsigned)__builtin_ctz(count_slots);
 	unsigned mark = 0, amark = 0;
-	if (lane == 0) {
-		if (!endc_ready) bt_end_chars(t, w);
-		mark = t.fscr_used; amark = t.scr_used;
+	if (!endc_ready) {                                                     // bt_end_chars, one instance per lane
+		for (unsigned i = lane; i < n; i += 64) stx(&endc[i], ldx(&wlen[i]) >= g.k + 1 ? ldx(&wck[i]) : ' ');
+		WSYNC();
 	}
+	if (lane == 0) { mark = t.fscr_used; amark = t.scr_used; }
 	for (int attempt = 0;; attempt++) {                                    // (a second attempt only after an estimate that was too low, see below)
 	if (lane == 0) {
 		t.fscr_used = mark; t.scr_used = amark;
@@ -2256,7 +2307,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	const bool estimate = attempt == 0 && n > 32u && g.ab_estimate;
 	if (sh.mode && estimate) {
 		unsigned mx = 0;
-		for (unsigned i = lane; i < n; i += 64) { const unsigned v = w.endc[i] == ' ' ? 0u : w.wmn[i]; mx = v > mx ? v : mx; }
+		for (unsigned i = lane; i < n; i += 64) { const unsigned v = ldx(&endc[i]) == ' ' ? 0u : ldx(&wmn[i]); mx = v > mx ? v : mx; }
 #pragma unroll
 		for (int dd = 32; dd > 0; dd >>= 1) { const unsigned v = __shfl_xor(mx, dd); mx = v > mx ? v : mx; }
 		WSYNC();
@@ -2268,8 +2319,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			sh.bits = bits; sh.distinct = distinct;
 			sh.skey = (unsigned *)t.alloc2((2u << bits) * 4);
 			sh.sval = sh.skey ? sh.skey + (1u << bits) : nullptr;
-			if (!sh.skey || !bt_ab_prepare(t, w, distinct)) sh.mode = -1;
-			else w.abb.lazy = g.lazy_map != 0;
+			if (!sh.skey || !bt_ab_prepare(t, w, distinct, g.lazy_map != 0)) sh.mode = -1;
 		}
 		WSYNC();
 	} else if (sh.mode) {
@@ -2279,12 +2329,13 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 		unsigned distinct = 0;
 		bool full = false;
 		for (unsigned i = 0; i < n && !full; i++) {
-			if (w.endc[i] == ' ') continue;
-			const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
-			const unsigned start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+			if (ldx(&endc[i]) == ' ') continue;
+			const unsigned long long *mk = wmk + (size_t)i * mks;
+			const unsigned wl = ldx(&wlen[i]);
+			const unsigned start = ldx(&wst[i]), lim = wl < D ? wl : D, nm = ldx(&wmn[i]);
 			for (unsigned j0 = 0; j0 < nm; j0 += 64) {
 				unsigned j = j0 + lane;
-				unsigned long long v = j < nm ? mk[j] : ~0ull;
+				unsigned long long v = j < nm ? ldx(&mk[j]) : ~0ull;
 				unsigned b = (unsigned)v;
 				bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
 				unsigned long long ms = __ballot(stop);
@@ -2313,12 +2364,13 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 				sh.bits = bits; sh.distinct = distinct;
 				sh.skey = (unsigned *)t.alloc2((2u << bits) * 4);
 				sh.sval = sh.skey ? sh.skey + (1u << bits) : nullptr;
-				if (!sh.skey || !bt_ab_prepare(t, w, distinct)) sh.mode = -1;
-				else w.abb.lazy = g.lazy_map != 0;                    // log the insertions, build the Boost map only if the call has >= 2 groups (bulge_txn.h: ABuild::lazy)
+				if (!sh.skey || !bt_ab_prepare(t, w, distinct, g.lazy_map != 0)) sh.mode = -1;      // log the insertions, build the Boost map only if the call has >= 2 groups (bulge_txn.h: ABuild::lazy)
 			}
 		}
 		WSYNC();
 	}
+	PC_ADD(16);
+	if (prof && lane == 0 && sh.mode > 0) { atomicAdd(&g_phase_cycles[BT_IS_LDS(w.abb.m.key) ? 20 : 21], 1000000ull); atomicAdd(&g_phase_cycles[22], (unsigned long long)t.fscr_used * 1000ull); atomicAdd(&g_phase_cycles[23], (unsigned long long)sh.distinct * 1000ull); }
 	if (sh.mode < 0) return 0;                                             // t.err is set
 	if (sh.mode == 0) {                                                    // tables do not fit: one thread, map sized by the total number of marks
 		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
@@ -2327,18 +2379,26 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	}
 	// ---- pass 2: build the map; lanes skip what changes nothing
 	const unsigned slots = 1u << sh.bits, shift = 32 - sh.bits;
-	for (unsigned i = lane; i < slots; i += 64) { sh.skey[i] = BT_NONE; sh.sval[i] = BT_NONE; }
+	for (unsigned i = lane; i < slots; i += 64) { stx(&sh.skey[i], BT_NONE); stx(&sh.sval[i], BT_NONE); }
 	WSYNC();
 	bool bad = false;
+	// (the first 64 marks of the NEXT instance are requested while this one is worked on: with dozens of instances the lists live in the
+	// arena, and every instance used to begin with a memory round trip of its own)
+	unsigned long long vpre = ~0ull;
+	unsigned pre_i = n;
+	auto first_chunk = [&](unsigned ii) { const unsigned long long *m0 = wmk + (size_t)ii * mks; return lane < ldx(&wmn[ii]) ? ldx(&m0[lane]) : ~0ull; };
 	for (unsigned i = 0; i < n && !bad; i++) {
-		const char ec = w.endc[i];
+		const char ec = ldx(&endc[i]);
 		if (ec == ' ') continue;
-		const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
-		const unsigned start = w.wst[i], lim = w.wlen[i] < D ? w.wlen[i] : D, nm = w.wmn[i];
+		const unsigned long long *mk = wmk + (size_t)i * mks;
+		const unsigned wl = ldx(&wlen[i]);
+		const unsigned start = ldx(&wst[i]), lim = wl < D ? wl : D, nm = ldx(&wmn[i]);
+		const unsigned long long v0 = pre_i == i ? vpre : first_chunk(i);
+		if (i + 1 < n) { vpre = first_chunk(i + 1); pre_i = i + 1; }
 		unsigned pos = 0;
 		while (pos < nm) {
 			unsigned j = pos + lane;
-			unsigned long long v = j < nm ? mk[j] : ~0ull;
+			unsigned long long v = pos == 0 ? v0 : j < nm ? ldx(&mk[j]) : ~0ull;
 			unsigned b = (unsigned)v;
 			bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
 			unsigned long long ms = __ballot(stop);
@@ -2346,9 +2406,10 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			unsigned ev = 0, val = BT_NONE, h = 0;
 			if (lane < upto) {
 				h = (b * 2654435761u) >> shift;
+				const unsigned *const skey = sh.skey, *const sval = sh.sval;
 				for (;;) {
-					unsigned kk = sh.skey[h];
-					if (kk == b) { val = sh.sval[h]; ev = (char)(val & 0xFFu) != ec ? 2u : 0u; break; }
+					unsigned kk = ldx(&skey[h]);
+					if (kk == b) { val = ldx(&sval[h]); ev = (char)(val & 0xFFu) != ec ? 2u : 0u; break; }
 					if (kk == BT_NONE) { ev = 1u; break; }                 // no entry yet (h = where the shadow entry goes)
 					h = (h + 1) & (slots - 1);
 				}
@@ -2362,7 +2423,12 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			unsigned run = eev == 1u ? (ins == ~0ull ? 64u - f : (unsigned)__builtin_ctzll(~ins)) : 0u;
 			if (lane >= f && lane < f + run) sh.batch[lane - f] = b;
 			WSYNC();
-			if (lane == 0) {
+			if (lane == 0 && w.abb.lazy) {
+				const bool lds = BT_IS_LDS(w.abb.m.key) && BT_IS_LDS(sh.skey);      // (one allocation decision for all arrays of the build, bt_ab_prepare)
+				const unsigned what = eev == 1u ? 1u : 2u;
+				sh.mode = lds ? ab_lazy_lane0<true>(t, w, sh, what, i, ec, run, evl >> 8, slots, shift, estimate)
+				              : ab_lazy_lane0<false>(t, w, sh, what, i, ec, run, evl >> 8, slots, shift, estimate);
+			} else if (lane == 0) {
 				if (eev == 1u) {
 					for (unsigned x = 0; x < run && sh.mode > 0; x++) {
 						unsigned bb = sh.batch[x], hh = (bb * 2654435761u) >> shift;
@@ -2383,8 +2449,10 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	}
 	if (bad && sh.mode == -2) { WSYNC(); continue; }
 	if (bad) return 0;
+	PC_ADD(17);
 	if (lane == 0) sh.mode = bt_ab_finish(t, w) ? 3 : 2;
 	WSYNC();
+	PC_ADD(18);
 	return sh.mode == 3;
 	}
 }
@@ -2442,7 +2510,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			WSYNC();
 		}
 		PH_ADD(1);
-		int any = wave_any_bulges(g, t, w, absh, lane);
+		int any = wave_any_bulges(g, t, w, absh, lane, false, AB_COUNT_SLOTS, nullptr, prof);
 		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
@@ -3586,7 +3654,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {
 		unsigned long long z[64] = {0};
-		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 16 * 8));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 24 * 8));
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_hist), z, 64 * 8));
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_max), z, 16));
 		{ std::vector<unsigned long long> zz(4096, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_max), zz.data(), 4096 * 8)); }
@@ -3719,11 +3787,12 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	c->stats.verdict_ms = be.ro_ms; c->stats.ro_ranks = be.split_ro() ? c->comm->n : 1;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
 	if (be.prof) {
-		unsigned long long z[16];
+		unsigned long long z[24];
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
-		const char *nm[16] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan",
-		                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints"};
-		for (int i = 0; i < 16; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
+		const char *nm[24] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan",
+		                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints",
+		                      " b:endchars+sizing", " b:map-build", " b:finish", " b:loop-setup", " #maps in LDS", " #maps in the arena", " fast bytes used (k)", " distinct ids (k)"};
+		for (int i = 0; i < 24; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 		unsigned long long hh[4][16], mx[2];
 		HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
 		HIP_TRY(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_txn_max), sizeof mx));
