@@ -46,6 +46,12 @@ enum { CTR_STRIDE = 32,
        CTR_TXN = 10 * CTR_STRIDE, CTR_DETAIL = 11 * CTR_STRIDE, CTR_COUNT = 12 * CTR_STRIDE };
 enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
 
+// optional cycle counters of the decision loops (simplify.hip defines them for SBL_PHASES=1; nothing elsewhere)
+#ifndef BT_PROF_ADD
+#define BT_PROF_T0(t) ((void)0)
+#define BT_PROF_ADD(t, i) ((void)0)
+#endif
+
 struct GraphView {
 	uint8_t *ch; uint32_t *op, *nx, *pv;
 	uint32_t *bif[2], *nodeof[2];
@@ -119,11 +125,12 @@ struct Txn {
 	bool ext_stamps;                    // element stamps are done by the caller's wave-wide scans (reads) and post-collapse pass (writes)
 	bool chain;                         // serial chain (simplify.hip: k_chain): nothing else is in flight and no reservation exists to be checked
 	uint32_t push_e, push_d, push_len;  // ... for this target instance / new branch length
+	bool prof; unsigned long long prof_t;      // SBL_PHASES=1 (BT_PROF_ADD)
 
 	__host__ __device__ void init(const GraphView &gv, uint32_t id_, uint32_t widx, uint32_t mode_, uint8_t *arena, uint32_t arena_bytes)
 	{
 		g = gv; id = id_; tid = id_ + 1; stamp = gv.round_bits | widx; mode = mode_;
-		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; tc_list = nullptr; tc_cap = 0; tc_n = 0; defer_cleanup = false; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0;
+		last_r = last_w = BT_NONE; scr = arena; scr_cap = arena_bytes; scr_used = 0; fscr = nullptr; fscr_cap = 0; fscr_used = 0; err = 0; tc_head = BT_NONE; tc_list = nullptr; tc_cap = 0; tc_n = 0; defer_cleanup = false; wrote = false; defer_push = false; ext_stamps = false; chain = false; push_e = BT_NONE; push_d = 0; push_len = 0; prof = false; prof_t = 0;
 	}
 	// ---- scratch
 	__host__ __device__ __forceinline__ void *alloc(uint32_t bytes)
@@ -434,6 +441,7 @@ struct BulgeWork {
 	// mq_* with all lanes -- one look-up per lane, the same stamps -- into mres[], set mready, call again).
 	uint32_t nold;               // SBL_PHASES=1: collapses of this transaction that took the round-3 form
 	bool mscan, mready;
+	uint32_t mscan_min;          // ... with more than this many marks inside the two branches together
 	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
 	uint32_t *occ; uint32_t occ_cap;
@@ -483,7 +491,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
 	w.use_stale = false; w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mready = false; w.nold = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
@@ -678,6 +686,47 @@ __host__ __device__ inline uint32_t bt_max_mult(Txn &t, BulgeWork &w, uint32_t i
 		if (c > r) r = c;
 	}
 	return r;
+}
+
+// MaxBifurcationMultiplicity of BOTH branches of a bulge, four bifurcations per memory round trip.  count_bif is a stamp check (owner,
+// write stamp of the id) followed by the two list sizes -- two dependent round trips per bifurcation inside a branch when one thread
+// walks them one after the other, ~14 for the usual three or four bifurcations per branch: the largest single item of the decision
+// loops (SBL_PHASES: "r:multiplicities", 40 % of rb_run).  Here the loads of four bifurcations are issued together (the stamp words and
+// the sizes do not depend on each other: a violation is reported either way) and only then looked at.  Same values, same stamps.
+template <bool L = false>
+__host__ __device__ __forceinline__ void bt_max_mult_pair(Txn &t, BulgeWork &w, uint32_t i, uint32_t di, uint32_t j, uint32_t dj, uint32_t &ri, uint32_t &rj)
+{
+	if (!t.mode || !t.ext_stamps) { ri = bt_max_mult<L>(t, w, i, di); rj = bt_max_mult<L>(t, w, j, dj); return; }
+	const uint32_t *wmn = w.wmn;
+	const uint64_t *mki = w.wmk + (size_t)i * w.mks, *mkj = w.wmk + (size_t)j * w.mks;
+	BT_ASSUME_LDS(L, wmn); BT_ASSUME_LDS(L, mki); BT_ASSUME_LDS(L, mkj);
+	uint32_t ni = 0, nj = 0;
+	{ const uint32_t nm = wmn[i]; while (ni < nm && (uint32_t)(mki[ni] >> 32) < di) ni++; }
+	{ const uint32_t nm = wmn[j]; while (nj < nm && (uint32_t)(mkj[nj] >> 32) < dj) nj++; }
+	const GraphView &g = t.g;
+	uint32_t a = 0, b = 0;
+	const uint32_t total = ni + nj;
+	for (uint32_t p0 = 0; p0 < total; p0 += 4) {
+		uint32_t id[4], ow[4], wm[4], l0[4], l1[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t p = p0 + u < total ? p0 + u : p0;            // (a short last batch loads its first bifurcation again)
+			id[u] = p < ni ? (uint32_t)mki[p] : (uint32_t)mkj[p - ni];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) { ow[u] = g.own[id[u]]; wm[u] = g.wmax[g.nblk + id[u]]; l0[u] = g.lsize[0][id[u]]; l1[u] = g.lsize[1][id[u]]; }
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t p = p0 + u;
+			if (p >= total) break;
+			if (t.mode != 3 && !t.chain && ow[u] != t.stamp) t.violation(BT_NONE);      // stamp_id_light(id, false)
+			if (wm[u] > t.tid) t.violation(BT_NONE);
+			if (t.mode == 2) bt_atomic_max(&g.rmax[g.nblk + id[u]], t.tid);
+			const uint32_t c = l0[u] + l1[u];
+			if (p < ni) { if (c > a) a = c; } else if (c > b) b = c;
+		}
+	}
+	ri = a; rj = b;
 }
 
 // number of marked steps strictly inside a branch of `distance` steps (what bt_max_mult would look up)
@@ -1009,6 +1058,7 @@ template <bool L = false>
 __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // (always inline: as a call it takes t / w as generic pointers and spills around itself -- +5 ms per stage when the inliner gave up on it)
 {
 	const uint32_t D = t.g.D;
+	BT_PROF_T0(t);
 	const uint32_t *grp_off = w.ab.grp_off, *grp_mem = w.ab.grp_mem, *start = w.start, *wlen = w.wlen, *wmn = w.wmn;
 	char *endc = w.endc;
 	const uint64_t *wmk = w.wmk, *visit = w.visit;
@@ -1040,7 +1090,9 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 				w.idJ++; w.jready = false;
 				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
 				// after a collapse that rewrote I's own window
+				BT_PROF_ADD(t, 23);
 				if (w.need_fill) { bt_fill_visit<L>(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }
+				BT_PROF_ADD(t, 20);
 				const uint64_t *mkJ = wmk + (size_t)kmerJ * w.mks;
 				const uint32_t limJ = wlen[kmerJ] < D ? wlen[kmerJ] : D, nmJ = wmn[kmerJ], nvisit = w.nvisit;
 				for (uint32_t j = 0; j < nmJ; j++) {
@@ -1052,17 +1104,22 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 					while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (visit[mid] < probe) lo = mid + 1; else hi = mid; }
 					if (lo < nvisit && (uint32_t)(visit[lo] >> 32) == nowBif) {
 						uint32_t dJ = step, dI = (uint32_t)visit[lo];
-						if (bt_overlap<L>(t, w, kmerI, dI, kmerJ, dJ)) break;
+						BT_PROF_ADD(t, 23);
+						const bool ov_ = bt_overlap<L>(t, w, kmerI, dI, kmerJ, dJ);
+						BT_PROF_ADD(t, 21);
+						if (ov_) break;
 						if (t.err) return 0;
-						if (w.mscan && !w.mready && bt_marks_inside<L>(w, kmerI, dI) + bt_marks_inside<L>(w, kmerJ, dJ) > BT_MSCAN_MIN) {
+						if (w.mscan && !w.mready && bt_marks_inside<L>(w, kmerI, dI) + bt_marks_inside<L>(w, kmerJ, dJ) > w.mscan_min) {
 							w.mq_i = kmerI; w.mq_di = dI; w.mq_j = kmerJ; w.mq_dj = dJ;
 							w.idJ--; w.jready = true;                    // this J again once the caller has the multiplicities (nothing has been decided or counted yet)
 							return 4;
 						}
 						++w.ret;
-						uint32_t imlp = w.mready ? w.mres[0] : bt_max_mult<L>(t, w, kmerI, dI);
-						uint32_t jmlp = w.mready ? w.mres[1] : bt_max_mult<L>(t, w, kmerJ, dJ);
+						uint32_t imlp, jmlp;
+						if (w.mready) { imlp = w.mres[0]; jmlp = w.mres[1]; }
+						else bt_max_mult_pair<L>(t, w, kmerI, dI, kmerJ, dJ, imlp, jmlp);
 						w.mready = false;
+						BT_PROF_ADD(t, 22);
 						if (imlp > jmlp || (imlp == jmlp && kmerI < kmerJ)) {
 							endc[kmerJ] = endc[kmerI];
 							w.c_src = kmerI; w.c_dS = dI; w.c_tgt = kmerJ; w.c_dT = dJ;

@@ -11,6 +11,12 @@
 #include "sbl_ctx.h"
 #include "sbl_comm.h"
 #include "kmer_kernels.h"
+// cycle counters of the decision loops (bulge_txn.h: BT_PROF_ADD), device only
+__device__ unsigned long long g_phase_cycles[24];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT_PROF_T0(t) do { if ((t).prof) (t).prof_t = __builtin_readcyclecounter(); } while (0)
+#define BT_PROF_ADD(t, i) do { if ((t).prof) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - (t).prof_t); (t).prof_t = n_; } } while (0)
+#endif
 #include "simplify_driver.h"
 
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
@@ -1598,7 +1604,6 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 	if (b < g.nid) { g.touch[b] = 1; if (b > t.id) g.need[b] = 1; }
 }
 
-__device__ unsigned long long g_phase_cycles[24];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
 __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
 __device__ unsigned long long g_round_max[4096];   // SBL_PHASES=1: per launch of k_commit (slot = round stamp slot / 4), the slowest transaction: (cycles << 24) | min(instances, 255) << 16 | old-form collapses << 8 | collapses
@@ -2370,7 +2375,6 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 		WSYNC();
 	}
 	PC_ADD(16);
-	if (prof && lane == 0 && sh.mode > 0) { atomicAdd(&g_phase_cycles[BT_IS_LDS(w.abb.m.key) ? 20 : 21], 1000000ull); atomicAdd(&g_phase_cycles[22], (unsigned long long)t.fscr_used * 1000ull); atomicAdd(&g_phase_cycles[23], (unsigned long long)sh.distinct * 1000ull); }
 	if (sh.mode < 0) return 0;                                             // t.err is set
 	if (sh.mode == 0) {                                                    // tables do not fit: one thread, map sized by the total number of marks
 		if (lane == 0) sh.mode = bt_any_bulges(t, w, false) ? 3 : 2;
@@ -2495,7 +2499,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	if (!flag) return;
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0;
-	                 t.tc_cap = 1024; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true; }
+	                 t.tc_cap = 1024; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true; t.prof = prof != 0; }
 	WSYNC();
 	wave_setup(g, t, w, false, lane, flag);
 	PH_ADD(0);
@@ -2514,7 +2518,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// lazy windows (bulge_txn.h: BulgeWork::lazy) when the id is large and has the graph to itself: the set of windows a collapse
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
-		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = w.n > 24u && g.jscan_rounds;
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = (w.n > 24u || (g.test_flags & 16u)) && g.jscan_rounds; if (g.test_flags & 16u) w.mscan_min = (g.test_flags >> 8) & 15u;
 			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
@@ -3791,7 +3795,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
 		const char *nm[24] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan",
 		                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints",
-		                      " b:endchars+sizing", " b:map-build", " b:finish", " b:loop-setup", " #maps in LDS", " #maps in the arena", " fast bytes used (k)", " distinct ids (k)"};
+		                      " b:endchars+sizing", " b:map-build", " b:finish", " b:loop-setup", " r:FillVisit", " r:Overlap", " r:multiplicities", " r:J walk + search"};
 		for (int i = 0; i < 24; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 		unsigned long long hh[4][16], mx[2];
 		HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
