@@ -370,9 +370,13 @@ def main():
                         # timed on the GPU box's host cores in the same run"): it becomes the baseline, the bounded sample stays beside it
                         fa2 = os.path.join(d, "full.fa")
                         W.write_fasta(fa2, seqs)
-                        r2 = subprocess.run([ref_dump, fa2, os.path.join(d, "f"), "stage:%d:%d:%d" % (a.k, a.D, a.iters)], capture_output=True, text=True)
-                        m2 = re.search(r"bulges=(\d+) seconds=([0-9.]+)", r2.stderr)
-                        if r2.returncode == 0 and m2:
+                        try:                                      # (bounded: a loaded host must not turn the bench line into a time-out of the whole run)
+                            r2 = subprocess.run([ref_dump, fa2, os.path.join(d, "f"), "stage:%d:%d:%d" % (a.k, a.D, a.iters)], capture_output=True, text=True, timeout=1200)
+                            m2 = re.search(r"bulges=(\d+) seconds=([0-9.]+)", r2.stderr)
+                        except subprocess.TimeoutExpired:
+                            r2, m2 = None, None
+                            out["cpu_baseline"]["full"] = "not finished within 1200 s on this host: the bounded sample stands"
+                        if r2 is not None and r2.returncode == 0 and m2:
                             fb, fdt = int(m2.group(1)), float(m2.group(2))
                             import hashlib
                             fsha = hashlib.sha256(open(os.path.join(d, "f.0.out"), "rb").read()).hexdigest()
