@@ -593,6 +593,31 @@ def test_long_k_active_set_doubling_equals_the_full_doubling(k, monkeypatch):
     assert a[0] > 0
 
 
+@pytest.mark.parametrize("k", [40, 64])
+def test_long_k_terminal_windows_listed_twice_change_nothing(k, monkeypatch):
+    """k_lk_cand_keys (longk.hip) appends the first and the last window of both strands of every record to the candidate list without
+    looking whether they are already there: a terminal window whose suffix is still ACTIVE (the k-mer occurs elsewhere) is listed twice,
+    and in a record of exactly k characters first and last window are the same one -- three entries.  Harmless because a terminal
+    window is always a bifurcation ('#' before or after it) and marks are written by value; this test pins that: records of exactly k
+    characters whose k-mer (or its reverse complement) also lies inside longer records, active-set path forced, against the oracle."""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    x = W.random_dna(k, 1, seed=5)[0]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = x.translate(comp)[::-1]
+    a, b = W.random_dna(3000, 2, seed=6)
+    seqs = [x, a[:1500] + x + a[1500:], x, b[:700] + rc + b[700:], rc, x + b[:900], a[:800] + x]
+    want = Oracle(seqs).enumerate(k)
+    assert want[0] > 0
+    for env in (None, "SBL_LONGK_FORCE_ACTIVE", "SBL_LONGK_NO_DISCARD"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        got = _bf(seqs).enumerate(k)
+        if env:
+            monkeypatch.delenv(env)
+        assert got[0] == want[0] and (got[1] == want[1]).all() and (got[2] == want[2]).all(), env
+
+
 def test_long_k_stage_on_random_records_takes_the_active_set_path():
     """unrelated random records with one planted repeat: nearly every suffix is unique after 16 characters, the doubling continues over the
     few that are not -- result equal to the oracle's, state included"""
