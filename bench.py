@@ -290,7 +290,8 @@ def main():
                          "avg_launch_ms": dur_ms, "avg_launch_ms_all_launches": dur_ms_clock, "timing": timing,
                          "launches_per_step": launches[dom], "algorithmic_bytes_per_launch": alg8d[dom],
                          "algorithmic_model": "SURVEY.md 8d: N x 24.125 + 12 x instances + iterations x N x 4 = %.2f GB per stage; the simplification share "
-                                              "(iterations x N x 4 B) spread over the launches of the dominant kernel" % (stage_8d / 1e9),
+                                              "(iterations x N x 4 B) spread over the launches of the dominant kernel (since round 3; rounds 1 and 2 priced `frac` "
+                                              "with this design's own per-kernel model, now `frac_design_model`: not comparable)" % (stage_8d / 1e9),
                          "stage": {"bytes_8d": stage_8d, "achieved": stage_8d / (ms_step * 1e-3) / 1e9, "frac": stage_8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "frac_design_model": achieved_design / HBM_PEAK_GBS, "design_model_bytes_per_launch": alg[dom],
                          "design_model": "this design's per-kernel model (DESIGN.md 4: e.g. k_commit = 8 B x (D + k) per instance of the launch's transactions)",
