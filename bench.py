@@ -45,6 +45,167 @@ def W_source_digest():
     return h.hexdigest()[:16]
 
 
+# ---- BASELINE.json's other configurations in the driver's format: python bench.py --config 3|4|5 -------------------------------------
+# (the default run is the headline configuration, configs[1]'s shape at 8 strains; these are single-GPU lines a reader can check
+# without DESIGN.md: per-stage times, the SURVEY.md 8d roofline per stage -- with the k > 32 figure where k > 32 --, the reference
+# beside them, the state the timed region left compared with the reference's own output)
+FINE_STAGES = [(30, 150), (100, 500), (500, 1500)]          # reference src/util.cpp:76-87 (FineStageFile)
+
+
+def alg_bytes_8d(N, instances, iterations, k):
+    """SURVEY.md 8d: algorithmic HBM bytes of one stage.  k <= 32: N x 24.125 + 12 x instances + iterations x N x 4;
+    k > 32: 48.125 B per strand-k-mer (fingerprint-sized slots) + k / 4 B per verified occurrence of a bifurcation group."""
+    if k <= 32:
+        return N * 24.125 + 12.0 * instances + iterations * N * 4.0
+    return N * 48.125 + 12.0 * instances + iterations * N * 4.0 + (k / 4.0) * instances
+
+
+def run_config(a):
+    import hashlib
+    import struct
+    import subprocess
+    import tempfile
+    import re
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no host compute path")
+    torch.cuda.set_device(0)
+    import __graft_entry__ as G
+    G.build()
+    from sibelia_amd import BlockFinder, workloads as W
+    big = {v["name"]: v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "big_vectors.json")))["vectors"]}
+    small = {v["name"]: v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "vectors.json")))["vectors"]}
+    if a.config == 3:
+        strains, L0 = (a.strains, a.L0)
+        seqs = W.gen_strains(L0=L0, n=strains, seed=1)
+        stages, iters = FINE_STAGES, 4
+        what = "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1), the reference's `-s fine` cascade (30,150) (100,500) (500,1500), maxIterations=4" % (strains, L0 / 1e6)
+        fixture = small.get("synth/strains8_4600k_fine") if (strains, L0) == (8, 4_600_000) else None
+        fx_cmd = "stage:500:1500:4"
+    elif a.config == 4:
+        strains, L0 = (62 if a.strains == 8 else a.strains, a.L0)
+        seqs = W.gen_strains(L0=L0, n=strains, seed=1)
+        stages, iters = [(a.k, a.D)], a.iters
+        what = "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1), k=%d D=%d maxIterations=%d, one full stage" % (strains, L0 / 1e6, a.k, a.D, a.iters)
+        fixture, fx_cmd = None, None                            # (the reference needs > 30 h for 62 x 4.6 Mbp: pinned at 1/10 length, tests/test_gpu_parity.py)
+    else:
+        total, nrec = 900_000_000, 4
+        seqs = W.longk_case(total, nrec)
+        stages, iters = [(5000, 15000)], 4
+        what = "%d Mbp of uniform random DNA in %d records with planted repeats (workloads.longk_case), k=5000 D=15000 maxIterations=4, one full stage" % (total // 1_000_000, nrec)
+        fixture, fx_cmd = big.get("synth/random4x225M_k5000"), "stage:5000:15000:4"
+    bf = BlockFinder(seqs, device=0)
+    bf.save_state()
+
+    def step(collect=None):
+        bf.restore_state()
+        last = 0
+        for (k, D) in stages:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            last = bf.PerformGraphSimplifications(k, D, iters)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            if collect is not None:
+                st = bf.stats()
+                rec = collect.setdefault((k, D), {"ms": 0.0, "stats": st, "phase_ms": {}})
+                rec["ms"] += 1e3 * dt1
+                rec["stats"] = st
+                for key, v in st.items():
+                    if key.endswith("_ms"):
+                        rec["phase_ms"][key] = rec["phase_ms"].get(key, 0.0) + v
+        return last
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    per = {}
+    for _ in range(a.steps):
+        bulges = step(per)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_step = 1e3 * dt / a.steps
+    # what was timed is what is checked
+    vs, vp = bf.state_views()
+    h = hashlib.sha256(struct.pack("<QI", bulges, len(vs)))
+    for x, y in zip(vs, vp):
+        h.update(struct.pack("<Q", len(x))); h.update(x); h.update(y)
+    sha = h.hexdigest()
+    match, fx_name = None, None
+    if fixture is not None:
+        want = [o for o in fixture["outputs"] if o["cmd"] == fx_cmd][0]
+        match = bool(want["sha256"] == sha and want["bulges"] == bulges)
+        fx_name = "%s %s (output of the unmodified reference, oracle/_ref)" % (fixture["name"], fx_cmd)
+    stage_lines, Ntot, bytes_tot = [], 0.0, 0.0
+    for (k, D) in stages:
+        rec = per[(k, D)]
+        st = rec["stats"]
+        N = float(st["strand_kmers"])
+        ms = rec["ms"] / a.steps
+        alg = alg_bytes_8d(N, float(st["instances"]), float(st["iterations"]), k)
+        ph = {kk: v / a.steps for kk, v in sorted(rec["phase_ms"].items())}
+        if k > 32:
+            dom, dom_ms, dom_launches = "long-k enumeration (k_lk_* + rocPRIM radix-sort passes: exact rank doubling)", ph.get("enumerate_ms", 0.0), 1
+        else:
+            cand = {"k_commit": ph.get("commit_ms", 0.0), "k_reserve": ph.get("reserve_ms", 0.0), "k_probe": ph.get("probe_ms", 0.0), "k_snapshot": ph.get("snapshot_ms", 0.0),
+                    "enumeration (k_kmer_records .. k_scatter_members)": ph.get("enumerate_ms", 0.0)}
+            dom = max(cand, key=lambda q: cand[q])
+            dom_ms, dom_launches = cand[dom], (max(1, int(st["rounds"])) if dom in ("k_commit", "k_reserve", "k_probe") else 1)
+        stage_lines.append({"k": k, "D": D, "ms": ms, "strand_kmers": N, "value": N / (ms * 1e-3), "bif_ids": st["bif_count"], "instances": st["instances"], "bulges": st["bulges"],
+                            "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"], "phase_ms": ph,
+                            "roofline": {"bound": "hbm", "kernel": dom, "algorithmic_bytes_stage": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "dominant_ms": dom_ms, "dominant_launches": dom_launches,
+                                         "dominant_avg_launch_ms": dom_ms / dom_launches,
+                                         "model": "SURVEY.md 8d, k %s 32" % ("<=" if k <= 32 else ">")}})
+        Ntot += N; bytes_tot += alg
+    slow = max(stage_lines, key=lambda r: r["ms"])
+    out = {"metric": "k-mers/sec in BlockFinder graph-build+simplify, BASELINE.json config %d" % a.config,
+           "value": Ntot / (ms_step * 1e-3), "unit": "strand-k-mers/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": what, "baseline_config": a.config, "strand_kmers_per_step": Ntot, "stages": [[k, D] for k, D in stages], "parallelism": "1 GPU"},
+           "stages": stage_lines,
+           "roofline": {"bound": "hbm", "kernel": slow["roofline"]["kernel"] + " of the slowest stage (k=%d)" % slow["k"], "achieved": bytes_tot / (ms_step * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_tot / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_step": bytes_tot, "avg_launch_ms": slow["roofline"]["dominant_avg_launch_ms"],
+                        "model": "SURVEY.md 8d summed over the stages of the step (per stage under `stages`); `achieved` = those bytes / the step's wall time; "
+                                 "per-kernel times and HBM traffic of this command: profiles/r05_config%d_kernel_stats.csv / _pmc_summary.json" % a.config},
+           "state_sha256": sha, "matches_reference_fixture": match, "reference_fixture": fx_name}
+    # ---- the reference beside it
+    cpu_model = "?"
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    host = "%s, %d logical cores on the host" % (cpu_model, os.cpu_count() or 0)
+    ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if a.config == 3 and not a.no_cpu_baseline and os.path.exists(ref_dump):
+        sample = W.gen_strains(L0=a.cpu_sample_L0, n=strains, seed=1)
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "in.fa")
+            W.write_fasta(fa, sample)
+            r = subprocess.run([ref_dump, fa, os.path.join(d, "o")] + ["stage:%d:%d:%d" % (k, D, iters) for k, D in stages], capture_output=True, text=True)
+            secs = [float(x) for x in re.findall(r"seconds=([0-9.]+)", r.stderr)]
+            if r.returncode == 0 and len(secs) == len(stages):
+                Ns = sum(W.strand_kmers(sample, k) for k, _ in stages)
+                out["cpu_baseline"] = {"value": Ns / sum(secs), "unit": "strand-k-mers/s", "cores": 1, "kind": "reference", "host": host,
+                                       "sample": "the unmodified reference (oracle/_ref, 1 thread: it has no parallelism) through the same three stages on %d strains x %.2f Mbp from "
+                                                 "the same generator (%d strand-k-mers over the stages; %s s per stage)" % (strains, a.cpu_sample_L0 / 1e6, Ns, " / ".join("%.1f" % x for x in secs))}
+    elif a.config in (4, 5):
+        v = big["synth/strains62_460k" if a.config == 4 else "synth/random4x225M_k5000"]
+        o = [x for x in v["outputs"] if x["cmd"].startswith("stage:")][0]
+        Nref = float(W.strand_kmers([b"x" * l for l in v["lengths"]], int(o["cmd"].split(":")[1])))
+        out["cpu_baseline"] = {"value": Nref / o["reference_seconds"], "unit": "strand-k-mers/s", "cores": 1, "kind": "reference",
+                               "host": "RECORDED in the build container (8 vCPU Intel Xeon @ 2.10 GHz, tests/golden/make_big_golden.py), not on this host",
+                               "sample": "the unmodified reference's PerformGraphSimplifications on %s: %.0f s for %d strand-k-mers (tests/golden/big_vectors.json: reference_seconds)%s"
+                                         % (v["name"], o["reference_seconds"], int(Nref),
+                                            "; the reference is superlinear in the number of strains -- 62 x 460 kbp is 1/10 of this workload's genome length and took 3.2 h, the full size > 30 h" if a.config == 4 else
+                                            " = this very workload at full size")}
+    print(json.dumps(out), flush=True)
+    bf.close()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +224,14 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare the GPU result of the CPU sample with the oracle")
     ap.add_argument("--cpu-full", action="store_true", help="(default since round 4) time the unmodified reference on the FULL workload as well")
     ap.add_argument("--no-cpu-full", action="store_true", help="bounded CPU sample only (~20 s) instead of the reference on the full workload (~4 - 8 min, 1 thread)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 3, 4, 5],
+                    help="one of BASELINE.json's other configurations instead of the headline one: 3 = 8 strains through the `-s fine` cascade, 4 = 62 strains at k = 25, 5 = 900 Mbp of random DNA at k = 5000 (single GPU)")
+    ap.add_argument("--require-sharded", action="store_true", help="--gpus > 1: exit non-zero instead of falling back to replicas when the sharded (strong-scaling) configuration cannot run")
     a = ap.parse_args()
+    if a.config:
+        if a.gpus > 1:
+            raise SystemExit("--config 3 / 4 / 5 are single-GPU lines (the multi-GPU configuration of the driver's contract is the default workload)")
+        return run_config(a)
 
     # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL), so that the
     # multi-GPU line needs no wrapper (the driver's own launch sets WORLD_SIZE and lands below directly)
@@ -136,6 +304,8 @@ def main():
                 except Exception:      # noqa: BLE001
                     pass
                 bf.close()
+                if a.require_sharded:
+                    raise SystemExit("sharded (strong-scaling) configuration failed and --require-sharded was given: " + shard_error)
                 a.shard_enum = False
                 seqs = W.gen_strains(**D.rank_workload(rank, a.strains, a.L0))
                 N = W.strand_kmers(seqs, a.k)
@@ -273,7 +443,7 @@ def main():
             "metric": "k-mers/sec in BlockFinder graph-build+simplify, 8xE.coli k=25",
             "value": Ntot / (dt / a.steps), "unit": "strand-k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong" if a.shard_enum else "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "strong" if a.shard_enum else ("weak-fallback" if shard_error else "weak"), "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "%d synthetic E. coli-like strains x %.1f Mbp (gen_strains seed 1, 1%% SNP, indels, inversions), "
                                    "k=%d D=%d maxIterations=%d, one full stage" % (a.strains, a.L0 / 1e6, a.k, a.D, a.iters),

@@ -7,9 +7,11 @@
 // builds that program into oracle/_ref/ (it contains reference objects, so it is never committed);
 // tests/test_gpu_dropin.py runs it on the GPU box and compares every output file with what the unmodified reference wrote.
 //
-// The header is not touched: the device context of a BlockFinder lives in a side table keyed by `this` (a maintainer would add a
-// member `sbl_ctx * amd_` instead and release it in a destructor; the class has none, so the table entry lives as long as the
-// process, like the reference's own object inside main's auto_ptr).
+// The header is not touched: the device context of a BlockFinder lives in a side table keyed by `this`.  The reference's class has no
+// destructor (src/blockfinder.h:28-45), so nothing tells this file when an object dies: an entry is released when another BlockFinder
+// is constructed at the same address, by SyntenyFinderAMD_ReleaseDevice(this) -- the one line a maintainer's `~BlockFinder()` holds
+// ("Releasing the device context") -- or at process exit; the reference's own program keeps its single object in
+// main's auto_ptr until it returns.
 #include <map>
 #include <memory>
 #include <mutex>
@@ -36,6 +38,13 @@ namespace
 		if (f.empty()) return Device::ProgressCallBack();
 		return [f](size_t progress, Device::State state) { f(progress, static_cast<SyntenyFinder::BlockFinder::State>(state)); };
 	}
+}
+
+// releases the device context (sbl_destroy) of a BlockFinder that is about to die; harmless for an object that has none
+extern "C" void SyntenyFinderAMD_ReleaseDevice(const void * blockFinder)
+{
+	std::lock_guard<std::mutex> hold(tableLock);
+	table.erase(static_cast<const SyntenyFinder::BlockFinder *>(blockFinder));
 }
 
 namespace SyntenyFinder

@@ -13,14 +13,17 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libsibelia_amd.so")
-SOURCES = ["sbl_api.hip", "simplify.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip", "enumerate.hip"]
+SOURCES = ["sbl_api.hip", "simplify.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
 HEADERS = ["sbl_common.h", "sbl_ctx.h", "sbl_comm.h", "kmer_kernels.h", "kmer_bucket_kernels.h", "bulge_txn.h", "simplify_steps.h", "simplify_driver.h",
            os.path.join("..", "..", "include", "sibelia_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _sources():
-    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    missing = [s for s in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:      # a renamed or deleted translation unit must be a build error, not a library with undefined symbols
+        raise FileNotFoundError("sibelia_amd/build.py lists sources that do not exist: " + ", ".join(missing))
+    return list(SOURCES)
 
 
 def _obj(src: str) -> str:

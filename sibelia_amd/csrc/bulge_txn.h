@@ -83,6 +83,17 @@ struct GraphView {
 	// the separators' slots (ascending; they never move during a stage) and the number of original slots: a walk that starts at an
 	// original slot recognises the separators of its chromosome by their slot instead of loading characters (simplify.hip: SepBounds)
 	const uint32_t *sep; uint32_t nsep, norig;
+	// Block index over the ORIGINAL slots (round 5): four 64-bit words per block of 64 consecutive slots --
+	//   [0] / [1]  bit i: slot 64 b + i carries a mark on strand 0 / 1 (bif[s][e] != BT_NONE)
+	//   [2]        bit i: the slot is a separator (never changes during a stage)
+	//   [3]        low half: highest write stamp (wmax) of any element of the block; high half: != 0 once the block is no longer
+	//              PRISTINE (an element died, or a link of / into the block stopped pointing at the neighbouring slot)
+	// A window that lies in pristine blocks is the slots a, a +- 1, ... themselves: the probe and the reservation of a round read three
+	// or four 32-byte records per window and gather only the marked ids instead of walking 175 x (character + mark + link + stamp).
+	// Maintained at the mark write sites (AddPoint / ErasePoint: bt_idx_mark), where a collapse changes links (bt_idx_dirty) and
+	// where write stamps are published (bt_idx_wstamp); nullptr = no index (every reader then takes the walking path).
+	unsigned long long *bidx;
+	uint32_t idx_probe, idx_reserve;    // the probe / the reservation of a round read the index (simplify.hip: k_probe_idx, reserve_idx)
 };
 
 // ------------------------------------------------------------------------------------------- atomics (host + device)
@@ -90,6 +101,26 @@ __host__ __device__ __forceinline__ uint32_t bt_atomic_add(uint32_t *p, uint32_t
 __host__ __device__ __forceinline__ uint32_t bt_atomic_min(uint32_t *p, uint32_t v) { return __atomic_fetch_min(p, v, __ATOMIC_RELAXED); }
 __host__ __device__ __forceinline__ uint32_t bt_atomic_max(uint32_t *p, uint32_t v) { return __atomic_fetch_max(p, v, __ATOMIC_RELAXED); }
 __host__ __device__ __forceinline__ uint32_t bt_atomic_or(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+// ------------------------------------------------------------------------------------------- block index maintenance
+#define BT_IDX_WORDS 4u
+__host__ __device__ __forceinline__ void bt_idx_mark(const GraphView &g, uint32_t s, uint32_t e, bool set)
+{
+	if (!g.bidx || e >= g.norig) return;
+	unsigned long long *w = &g.bidx[(size_t)(e >> 6) * BT_IDX_WORDS + s];
+	const unsigned long long bit = 1ull << (e & 63u);
+	if (set) (void)__atomic_fetch_or(w, bit, __ATOMIC_RELAXED); else (void)__atomic_fetch_and(w, ~bit, __ATOMIC_RELAXED);
+}
+__host__ __device__ __forceinline__ void bt_idx_dirty(const GraphView &g, uint32_t e)
+{
+	if (!g.bidx || e >= g.norig) return;
+	reinterpret_cast<uint32_t *>(&g.bidx[(size_t)(e >> 6) * BT_IDX_WORDS + 3])[1] = 1u;
+}
+__host__ __device__ __forceinline__ void bt_idx_wstamp(const GraphView &g, uint32_t e, uint32_t tid)
+{
+	if (!g.bidx || e >= g.norig) return;
+	(void)__atomic_fetch_max(reinterpret_cast<uint32_t *>(&g.bidx[(size_t)(e >> 6) * BT_IDX_WORDS + 3]), tid, __ATOMIC_RELAXED);
+}
 
 // ------------------------------------------------------------------------------------------- strand iterators
 struct SIt { uint32_t e; uint32_t d; };   // element + direction (0 positive, 1 negative); reference src/stranditerator.cpp
@@ -164,6 +195,7 @@ struct Txn {
 		if (mode == 1) { if (g.wmax[r] > tid) { BT_TRACE_VIOL("read-after-higher-write", r, g.wmax[r], 0); violation(BT_NONE); } return; }
 		if (write) {
 			uint32_t a = bt_atomic_max(&g.wmax[r], tid);
+			if (r < g.nblk) bt_idx_wstamp(g, r << BT_BLOCK_SHIFT, tid);
 			if (a > tid || g.rmax[r] > tid) { BT_TRACE_VIOL("write-after-higher-access", r, a, g.rmax[r]); violation(BT_NONE); }
 		} else {
 			bt_atomic_max(&g.rmax[r], tid);
@@ -224,6 +256,7 @@ struct Txn {
 		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
 		g.lsize[a.d][b]++;
 		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
+		bt_idx_mark(g, a.d, a.e, true);
 		push_dirty(b);
 	}
 	// AddPoint with the node already allocated and the id already stamped by the caller (wave-wide collapse)
@@ -234,6 +267,7 @@ struct Txn {
 		g.nnext[nd] = g.head[a.d][b]; g.head[a.d][b] = nd;
 		g.lsize[a.d][b]++;
 		g.bif[a.d][a.e] = b; g.nodeof[a.d][a.e] = nd;
+		bt_idx_mark(g, a.d, a.e, true);
 		push_dirty(b);
 		return true;
 	}
@@ -246,6 +280,7 @@ struct Txn {
 		tw(a.e); iw(b);
 		uint32_t nd = g.nodeof[a.d][a.e];
 		g.bif[a.d][a.e] = BT_NONE;
+		bt_idx_mark(g, a.d, a.e, false);
 		g.ndead[nd] = 1;                     // the node keeps its element: a proxy that is already in use stays dereferenceable
 		g.nclr[nd] = tc_head; tc_head = nd;
 		push_dirty(b);
@@ -763,8 +798,9 @@ __host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t d
 	if (dS < dT) {                                   // erase the surplus
 		t.tr(target);
 		uint32_t before = g.pv[target], cur = target;
-		for (uint32_t i = 0; i < dT - dS; i++) { t.tw(cur); g.ch[cur] = BT_DEAD_CHAR; cur = g.nx[cur]; }
+		for (uint32_t i = 0; i < dT - dS; i++) { t.tw(cur); g.ch[cur] = BT_DEAD_CHAR; bt_idx_dirty(g, cur); cur = g.nx[cur]; }
 		t.tw(before); t.tw(cur);
+		bt_idx_dirty(g, before); bt_idx_dirty(g, cur);
 		g.nx[before] = cur; g.pv[cur] = before;
 	} else if (dS > dT) {                            // insert the deficit before `target`
 		uint32_t m = dS - dT;
@@ -774,6 +810,7 @@ __host__ __device__ inline void bt_replace_direct(Txn &t, SIt source, uint32_t d
 		t.tr(target);
 		uint32_t before = g.pv[target];
 		t.tw(before); t.tw(target);
+		bt_idx_dirty(g, before); bt_idx_dirty(g, target);
 		for (uint32_t i = 0; i < span; i++) {        // the characters are read from the source one by one (no element is both source and target)
 			uint32_t ne = base + i;
 			if (i < m) {

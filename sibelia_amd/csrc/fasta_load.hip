@@ -305,6 +305,7 @@ extern "C" sbl_status sbl_load_fasta(sbl_ctx *c, const char *path)
 		if (first != ~0ull) fail(hlineno.back(), what);
 		// ---- record table
 		c->nchr = nrec; c->nelem = E;
+		c->hint_elem_slack = 0; c->hint_cap_n = 0; c->hint_checkpoints = false;      // (as sbl_load)
 		c->sepidx.assign(nrec + 1, 0);
 		for (unsigned r = 0; r <= nrec; r++) {
 			c->sepidx[r] = hstart[r] + r;

@@ -390,6 +390,7 @@ extern "C" sbl_status sbl_load(sbl_ctx *c, uint32_t nchr, const uint8_t *const *
 		}
 		c->sepidx[nchr] = (uint32_t)(e - 1);
 		c->nchr = nchr; c->nelem = E;
+		c->hint_elem_slack = 0; c->hint_cap_n = 0; c->hint_checkpoints = false;      // capacities an earlier, unrelated input asked for do not carry over
 		c->fa_names.clear();
 		c->d_ch.ensure(Epad); c->d_sepidx.ensure((size_t)(nchr + 1) * 4);
 		HIP_TRY(hipMemcpyAsync(c->d_ch.p, ch.data(), Epad, hipMemcpyHostToDevice, c->stream));

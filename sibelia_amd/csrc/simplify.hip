@@ -945,6 +945,252 @@ __device__ __forceinline__ int probe_endchars(const GraphView &g, const BulgeWor
 	return 1;
 }
 
+// ---- probe of a pending id from the BLOCK INDEX (round 5) --------------------------------------------------------------------------
+// A window that lies in pristine 64-slot blocks (GraphView::bidx) is the slots a, a +- 1, ... themselves, so everything the verdict needs
+// -- first separator, the character at step k, the marked steps before the window's end -- is in the three or four 32-byte records the
+// window touches: one lane per (instance, block) loads its record, and only the MARKED slots' ids are gathered (a dozen per window
+// instead of 175 x {character, mark, link, stamp}).  The recurrence of the instance's own id is known without a look at the marks:
+// it is another instance of the same list, and the instances are in LDS.  No transaction state, no arena: the kernel runs at twice
+// the occupancy of the walking probe (k_probe), which only sees the entries this one cannot serve -- an instance on an inserted
+// element, a window that touches a block which is no longer pristine or carries a write stamp above the prober (the exact order check
+// needs the elements), more instances than the LDS list holds -- flagged PROBE_UNSERVED in live[].
+// Pass 1 takes the endChars alone (see probe_endchars); pass 2 the marks.
+#define PROBE_UNSERVED 3u
+#define PIDX_MAX_INST 256u
+__device__ unsigned long long g_rsv_ticks[8];      // SBL_TEST_FLAGS=32: summed wall-clock ticks of the reservation's phases (set-up, exclusive claims, ordering claims), entries, claims, instances
+__device__ unsigned g_idx_stats[8];          // SBL_TRACE: probes by outcome of k_probe_idx (known live, < 2 instances, clean, live, table full, not served); reservations: instances served / walked
+__device__ __forceinline__ unsigned long long idx_bits(int lo, int hi)      // bits lo .. hi-1 of a 64-bit word (clamped)
+{
+	lo = lo < 0 ? 0 : lo; hi = hi > 64 ? 64 : hi;
+	if (hi <= lo) return 0ull;
+	const unsigned long long up = hi >= 64 ? ~0ull : (1ull << hi) - 1ull;
+	return up & ~((1ull << lo) - 1ull);
+}
+// verdict-table insert of one mark per lane (b == BT_NONE: none); true when some id is now reached by two different endChars
+__device__ __forceinline__ bool vt_insert(VerdictTable &vt, unsigned b, unsigned bit, unsigned &distinct)
+{
+	bool fresh = false, found = false;
+	if (b != BT_NONE) {
+		unsigned h = (b * 2654435761u) >> 23;
+		for (;;) {
+			const unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
+			if (old == BT_NONE || old == b) {
+				fresh = old == BT_NONE;
+				const unsigned m = atomicOr(&vt.mask[h], bit) | bit;
+				if (m & (m - 1u)) found = true;
+				break;
+			}
+			h = (h + 1u) & (VT_SLOTS - 1u);
+		}
+	}
+	distinct += (unsigned)__popcll(__ballot(fresh));
+	return __any(found);
+}
+// One window WALKED by the wave, for the windows the index cannot serve (an inserted or erased element inside, an instance on an inserted
+// element): up to `maxsteps` steps from element `a` on strand `dir`, 64 consecutive slots per memory round trip while the links allow it.
+// Gives the window's length (steps before the separator), the raw character at step k, the order check of every element read, and -- when
+// mks != nullptr -- the marked steps >= 1 before the own id recurs as (step, id) pairs in LDS (at most PIDX_WALK_MARKS; more: overflow).
+#define PIDX_WALK_MARKS 192u
+struct WalkedWindow { unsigned len, craw, nm; bool viol, overflow; };
+__device__ __forceinline__ WalkedWindow idx_walk_window(const GraphView &g, unsigned a, unsigned dir, unsigned maxsteps, unsigned lane, unsigned id, unsigned tid,
+                                                        unsigned *mk_step, unsigned *mk_id)
+{
+	WalkedWindow r; r.len = maxsteps; r.craw = 0; r.nm = 0; r.viol = false; r.overflow = false;
+	const unsigned k = g.k;
+	const unsigned *__restrict__ link = dir ? g.pv : g.nx, *__restrict__ mark = g.bif[dir];
+	unsigned cur = a, done = 0;
+	bool open = true;                                                    // the own id has not recurred yet
+	while (done < maxsteps && cur != BT_NONE) {
+		const bool inr = done + lane < maxsteps && (dir ? lane <= cur : (unsigned long long)cur + lane < g.cap_e);
+		const unsigned c = inr ? (dir ? cur - lane : cur + lane) : cur;
+		const unsigned chv = g.ch[c], lnk = link[c], bv = mark[c], wm = g.wmax[c];
+		const unsigned prev = __shfl_up(lnk, 1);
+		const unsigned long long ml = __ballot(inr && (lane == 0 || prev == c));
+		const unsigned pre = ml == ~0ull ? 64u : (unsigned)__builtin_ctzll(~ml);          // intact prefix, >= 1
+		const unsigned long long ms = __ballot(lane < pre && chv == BT_SEP);
+		const unsigned stop = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+		const bool proc = lane < pre && lane < stop;
+		if (__any(proc && wm > tid)) r.viol = true;
+		const unsigned upto = pre < stop ? pre : stop;
+		if (k >= done && k < done + upto) r.craw = __shfl(chv, k - done);
+		if (mk_step && open) {
+			const unsigned long long own = __ballot(proc && done + lane >= 1u && bv == id);
+			const unsigned ownat = own ? (unsigned)__builtin_ctzll(own) : 64u;
+			const bool take = proc && lane < ownat && done + lane >= 1u && bv != BT_NONE;
+			const unsigned long long tm = __ballot(take);
+			const unsigned o = r.nm + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
+			if (take && o < PIDX_WALK_MARKS) { mk_step[o] = done + lane; mk_id[o] = bv; }
+			r.nm += (unsigned)__popcll(tm);
+			if (own) open = false;
+		}
+		if (stop < pre) { r.len = done + stop; return r; }
+		cur = __shfl(lnk, pre - 1u);
+		done += pre;
+	}
+	if (r.nm > PIDX_WALK_MARKS) r.overflow = true;
+	return r;
+}
+// returns 1 live, 0 clean, -1 the verdict table could fill up / a walked window has too many marks (k_probe decides)
+__device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, const unsigned *s_sel, const uint8_t *s_dir, unsigned *s_own, unsigned *mk_step, unsigned *mk_id,
+                                         unsigned n, unsigned lane, unsigned id, unsigned tid)
+{
+	const unsigned k = g.k, D = g.D, ws = D + k + 2u, norig = g.norig;
+	const unsigned nbw = (ws + 126u) >> 6;                                 // blocks a window can touch
+	const unsigned lsh = nbw <= 4u ? 2u : nbw <= 8u ? 3u : nbw <= 16u ? 4u : 99u;
+	if (lsh == 99u) return -1;
+	const unsigned lpi = 1u << lsh, ipc = 64u >> lsh;                      // lanes per instance, instances per chunk
+	const unsigned il = lane >> lsh, j = lane & (lpi - 1u);
+	const unsigned nblk = (norig + 63u) >> 6;
+	unsigned distinct = 0;
+	bool viol = false;
+	for (int pass = 1; pass <= 2; pass++) {
+		unsigned ecmask = 0;
+		if (pass == 2) {
+			// first recurrence of the own id in every window = the nearest instance of the same list ahead (consecutive slots)
+			for (unsigned i = lane; i < n; i += 64) {
+				const unsigned a = s_sel[i], d = s_dir[i];
+				unsigned own = ~0u;
+				for (unsigned x = 0; x < n; x++) {
+					const unsigned ax = s_sel[x], dx = s_dir[x];
+					const unsigned delta = d ? a - ax : ax - a;
+					if (dx == d && x != i && (d ? ax < a : ax > a) && delta < own) own = delta;
+				}
+				s_own[i] = own;
+			}
+			for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+			WSYNC();
+		}
+		for (unsigned i0 = 0; i0 < n; i0 += ipc) {
+			const unsigned i = i0 + il;
+			const bool act = i < n;
+			const unsigned a = act ? s_sel[i] : 0u, dir = act ? s_dir[i] : 0u;
+			const bool fresh = act && a >= norig;                          // an instance on an inserted element: not indexed, walked below
+			const unsigned ablk = a >> 6;
+			const bool inr = act && !fresh && j < nbw && (dir ? j <= ablk : ablk + j < nblk);
+			const unsigned bi = inr ? (dir ? ablk - j : ablk + j) : 0u;
+			const ulonglong2 *rp = reinterpret_cast<const ulonglong2 *>(g.bidx + (size_t)bi * BT_IDX_WORDS);
+			const ulonglong2 r0 = rp[0], r1 = rp[1];                       // marks of both strands; separators, (not pristine, write stamp)
+			const unsigned cslot = fresh ? 0u : dir ? (a >= k ? a - k : a) : (a + k < norig ? a + k : a);
+			const unsigned craw = g.ch[cslot];
+			const unsigned long long mk = dir ? __brevll(r0.y) : r0.x, sp = dir ? __brevll(r1.x) : r1.x;      // step order: bit r = step t0 + r
+			const int t0 = dir ? (int)a - (int)(bi * 64u + 63u) : (int)(bi * 64u) - (int)a;
+			const unsigned long long vm = inr ? idx_bits(-t0, (int)ws - t0) : 0ull;
+			const unsigned long long sepm = sp & vm;
+			unsigned fs = sepm ? (unsigned)(t0 + (int)__builtin_ctzll(sepm)) : ~0u;
+			for (unsigned d = 1; d < lpi; d <<= 1) { const unsigned v = __shfl_xor(fs, d); fs = v < fs ? v : fs; }
+			unsigned len = fs < ws ? fs : ws;
+			const unsigned reach = pass == 1 ? (fs < k ? fs : k) : (fs < ws - 1u ? fs : ws - 1u);      // last step whose block matters
+			const bool touched = inr && t0 <= (int)reach && t0 + 63 >= 0;
+			bool slow = fresh || (touched && (unsigned)(r1.y >> 32) != 0u);                            // a block that is no longer pristine
+			for (unsigned d = 1; d < lpi; d <<= 1) slow |= __shfl_xor((int)slow, d) != 0;
+			// a block written by a higher id: the exact order check of the elements READ in it (steps before the separator, up to k in pass 1)
+			unsigned long long hot = __ballot(touched && !slow && (unsigned)r1.y > tid);
+			for (; hot; hot &= hot - 1ull) {
+				const unsigned src = (unsigned)__builtin_ctzll(hot);
+				const unsigned hb = __shfl(bi, src), ha = __shfl(a, src), hd = __shfl(dir, src), hf = __shfl(fs, src);
+				const unsigned slot = hb * 64u + lane;
+				const int step = hd ? (int)ha - (int)slot : (int)slot - (int)ha;
+				const unsigned lastread = pass == 1 ? (hf < k + 1u ? hf : k + 1u) : (hf < ws ? hf : ws);
+				const unsigned wm = g.wmax[slot < norig ? slot : ha];
+				if (__any(step >= 0 && (unsigned)step < lastread && slot < norig && wm > tid)) viol = true;
+			}
+			char ec = dir ? bt_comp((char)craw) : (char)craw;
+			unsigned bit = len >= k + 1u ? (ec == 'A' ? 1u : ec == 'C' ? 2u : ec == 'G' ? 4u : 8u) : 0u;
+			const unsigned long long todo = __ballot(act && slow && j == 0u);      // windows to walk
+			if (pass == 1) {
+				if (act && !slow) ecmask |= bit;
+				for (unsigned long long td = todo; td; td &= td - 1ull) {
+					const unsigned src = (unsigned)__builtin_ctzll(td);
+					const unsigned wa = __shfl(a, src), wd = __shfl(dir, src);
+					const WalkedWindow ww = idx_walk_window(g, wa, wd, k + 1u, lane, id, tid, nullptr, nullptr);
+					if (ww.viol) viol = true;
+					if (ww.len >= k + 1u) { const char e2 = wd ? bt_comp((char)ww.craw) : (char)ww.craw; ecmask |= e2 == 'A' ? 1u : e2 == 'C' ? 2u : e2 == 'G' ? 4u : 8u; }
+				}
+				continue;
+			}
+			// ---- pass 2: the marked steps 1 .. min(D, len, own recurrence) - 1 of the windows the index serves
+			const unsigned own = act ? s_own[i] : 0u;
+			const unsigned lim = len < D ? len : D, upper = own < lim ? own : lim;
+			unsigned long long cm = act && !slow && bit ? mk & vm & idx_bits(1 - t0, (int)upper - t0) : 0ull;
+			unsigned total = (unsigned)__popcll(cm);
+			for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d);
+			if (distinct + total > (VT_SLOTS * 3) / 4) return -1;            // the table could fill up
+			const unsigned *__restrict__ marks = g.bif[dir];
+			while (__any(cm != 0ull)) {
+				unsigned sl[4]; bool has[4]; unsigned bb[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					has[q] = cm != 0ull;
+					const unsigned r = has[q] ? (unsigned)__builtin_ctzll(cm) : 0u;
+					if (has[q]) cm &= cm - 1ull;
+					const unsigned step = (unsigned)(t0 + (int)r);
+					sl[q] = has[q] ? (dir ? a - step : a + step) : a;
+				}
+#pragma unroll
+				for (int q = 0; q < 4; q++) bb[q] = marks[fresh ? 0u : sl[q]];
+				bool found = false;
+#pragma unroll
+				for (int q = 0; q < 4; q++) found |= vt_insert(vt, has[q] ? bb[q] : BT_NONE, bit, distinct);
+				if (found) { if (viol) wave_stamp(g, 0, tid, 3, id, 0, tid + 1); return 1; }
+			}
+			// ---- ... and the walked ones
+			for (unsigned long long td = todo; td; td &= td - 1ull) {
+				const unsigned src = (unsigned)__builtin_ctzll(td);
+				const unsigned wa = __shfl(a, src), wd = __shfl(dir, src);
+				WSYNC();
+				const WalkedWindow ww = idx_walk_window(g, wa, wd, ws, lane, id, tid, mk_step, mk_id);
+				if (ww.viol) viol = true;
+				if (ww.overflow) return -1;
+				WSYNC();
+				if (ww.len < k + 1u) continue;                              // endChar ' ': the instance takes no part
+				const char e2 = wd ? bt_comp((char)ww.craw) : (char)ww.craw;
+				const unsigned b2 = e2 == 'A' ? 1u : e2 == 'C' ? 2u : e2 == 'G' ? 4u : 8u;
+				const unsigned lim2 = ww.len < D ? ww.len : D;
+				if (distinct + ww.nm > (VT_SLOTS * 3) / 4) return -1;
+				bool found = false;
+				for (unsigned m0 = 0; m0 < ww.nm; m0 += 64) {
+					const unsigned m = m0 + lane;
+					const bool ok = m < ww.nm && mk_step[m] < lim2;
+					found |= vt_insert(vt, ok ? mk_id[m] : BT_NONE, b2, distinct);
+				}
+				if (found) { if (viol) wave_stamp(g, 0, tid, 3, id, 0, tid + 1); return 1; }
+			}
+		}
+		if (pass == 1) {
+			for (int d = 32; d > 0; d >>= 1) ecmask |= __shfl_xor(ecmask, d);
+			if (__popc(ecmask) <= 1) { if (viol) wave_stamp(g, 0, tid, 3, id, 0, tid + 1); return 0; }      // every instance continues with the same character: clean
+		}
+	}
+	if (viol) wave_stamp(g, 0, tid, 3, id, 0, tid + 1);
+	return 0;
+}
+__global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, uint8_t *live, unsigned w0)
+{
+	__shared__ VerdictTable vt;
+	__shared__ unsigned s_sel[PIDX_MAX_INST], s_own[PIDX_MAX_INST];
+	__shared__ uint8_t s_dir[PIDX_MAX_INST];
+	__shared__ unsigned s_mkstep[PIDX_WALK_MARKS], s_mkid[PIDX_WALK_MARKS];      // marks of a walked window (idx_walk_window)
+	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x;
+	round_stamp(g, 0);
+	if (wi >= nwin) return;
+	const unsigned id = g.win[wi], tid = id + 1;
+	if (g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
+	const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
+		if (off < PIDX_MAX_INST) { s_sel[off] = el; s_dir[off] = (uint8_t)s; }
+	});
+	int r = 0;
+	if (n >= 2) {
+		if (n > PIDX_MAX_INST || n != g.lsize[0][id] + g.lsize[1][id]) r = -1;      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
+		else { WSYNC(); r = probe_idx(g, vt, s_sel, s_dir, s_own, s_mkstep, s_mkid, n, lane, id, tid); }
+	}
+	if (lane == 0) {
+		if (r < 0) live[wi] = PROBE_UNSERVED;
+		else if (r == 0) { g.need[id] = 0; g.touch[id] = 0; live[wi] = 0; }      // verdict taken now: clean until somebody touches it again
+		else { g.need[id] = 2; live[wi] = 1; }
+		if (g.test_flags & 32u) atomicAdd(&g_idx_stats[n < 2 ? 1 : r == 0 ? 2 : r == 1 ? 3 : r == -1 ? 4 : 5], 1u);
+	}
+}
+
 static_assert(PROBE_WAVES == 1u, "k_probe synchronises its lanes with WSYNC(): one wave per workgroup");
 __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0)
 {
@@ -954,8 +1200,9 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
 	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x & 63u;
-	round_stamp(g, 0);
+	if (!g.idx_probe) round_stamp(g, 0);                               // (behind k_probe_idx the probe phase started with that kernel)
 	if (wi >= nwin) return;
+	if (g.idx_probe && live[wi] != PROBE_UNSERVED) return;             // decided by k_probe_idx
 	const unsigned id = g.win[wi], tid = id + 1;
 	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
 	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }
@@ -1145,8 +1392,9 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
 #define CLAIM_CAP 4096u                      // ids a window entry can list; beyond that commit re-walks serially
 
 #define RESUME_SLOTS 128u                   // instances whose core walk end is remembered for the ordering pass
-#define SEEN_SLOTS 2048u                     // LDS set of the ids a wave has already claimed (homologous instances repeat them)
-struct ClaimList { unsigned *buf; unsigned *n; unsigned *seen; };      // n: LDS counter shared by the waves of the workgroup
+// (the LDS set of the ids a workgroup has already claimed -- homologous instances repeat them -- has 1 << seen_bits slots: 1024 where ids
+// have a handful of instances, 2048 where they have dozens; dynamic LDS, DeviceBackend::reserve)
+struct ClaimList { unsigned *buf; unsigned *n; unsigned *seen; unsigned sbits; };      // n: LDS counter shared by the waves of the workgroup; seen: 1 << sbits slots
 
 // Visits the elements first, next(first), ... (at most maxcount, stopping before a separator) with 64 lanes and
 // calls f(b0, b1) on EVERY lane for each step of 64 (marks of both strands, BT_NONE for idle lanes) so that f may ballot.
@@ -1221,13 +1469,13 @@ __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, un
 {
 	bool has = b != BT_NONE;
 	if (has) {                                                   // claim every id once per wave
-		unsigned h = (b * 2654435761u) >> 21;
+		unsigned h = (b * 2654435761u) >> (32u - cl.sbits);
 		has = false;
 		for (int probe = 0; probe < 8; probe++) {
 			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
 			if (old == BT_NONE) { has = true; break; }
 			if (old == b) break;
-			h = (h + 1) & (SEEN_SLOTS - 1);
+			h = (h + 1) & ((1u << cl.sbits) - 1u);
 			if (probe == 7) has = true;                          // crowded table: claim again, harmless
 		}
 	}
@@ -1246,13 +1494,13 @@ __device__ __forceinline__ void wave_claim_order(const GraphView &g, ClaimList &
 {
 	bool has = b != BT_NONE && b != id;
 	if (has) {
-		unsigned h = (b * 2654435761u) >> 21;
+		unsigned h = (b * 2654435761u) >> (32u - cl.sbits);
 		has = false;
 		for (int probe = 0; probe < 8; probe++) {
 			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
 			if (old == BT_NONE) { has = true; break; }
 			if (old == b) break;
-			h = (h + 1) & (SEEN_SLOTS - 1);
+			h = (h + 1) & ((1u << cl.sbits) - 1u);
 			if (probe == 7) has = true;
 		}
 	}
@@ -1412,6 +1660,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 						push1(r0[u]); push1(r1[u]);
 						if (off < nstamp) {
 							unsigned a = atomicMax(&g.wmax[c], tid);
+							if (off == 0 || (c & 63u) == (d ? 63u : 0u)) bt_idx_wstamp(g, c, tid);      // (consecutive slots: one lane per 64-slot block)
 							unsigned rm = g.rmax[c];
 							if (a > tid || rm > tid) {
 								atomicMin(&g.ctr[CTR_VIOL], id);
@@ -1448,6 +1697,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 			push1(b0); push1(b1);
 			if (done + lane < nstamp) {
 				unsigned a = atomicMax(&g.wmax[c], tid);
+				bt_idx_wstamp(g, c, tid);
 				unsigned rm = g.rmax[c];
 				if (a > tid || rm > tid) {
 					atomicMin(&g.ctr[CTR_VIOL], id);
@@ -1493,23 +1743,137 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 	}
 }
 
+// ---- the reservation walks of an instance from the BLOCK INDEX (round 5) ------------------------------------------------------------
+// The neighbourhood of an instance -- core D + 2k + 3 ahead (both strands, exclusive), then up to 2(D + k + 2) + k ahead on the opposite
+// strand and D + k + 2 behind on the own strand (ordering) -- is ten or eleven 64-slot blocks: sixteen lanes per instance load their
+// block's record (marks of both strands, separators, "not pristine"), cut the ranges at the first separator, and only the MARKED slots'
+// ids are gathered and claimed.  Same (id, kind) pairs as the walks (bt_footprint_idx is the one-thread form, checked against
+// bt_footprint by tests/hostsim on every reservation).  Four instances per wave and pass; an instance whose neighbourhood touches a
+// block that is no longer pristine, or that sits on an inserted element, takes the walks (returned as a bit per instance of the group).
+struct RsvIdxLane { unsigned long long ex0, ex1, ord; int t0; unsigned a, s; bool ahead; };
+// masks of the lane's block for the group of four instances i0 .. i0 + 3; returns a bit per instance of the group that must take the walks
+__device__ __forceinline__ unsigned reserve_idx_masks(const GraphView &g, const unsigned *inst, unsigned ninst, unsigned i0, unsigned lane, unsigned NA, unsigned NB,
+                                                      unsigned core, unsigned fwd, unsigned back, RsvIdxLane &L)
+{
+	const unsigned il = lane >> 4, j = lane & 15u, i = i0 + il, norig = g.norig, nblk = (norig + 63u) >> 6;
+	const bool act = i < ninst;
+	const unsigned packed = act ? inst[i] : 0u, a = packed >> 1, s = packed & 1u, ablk = a >> 6;
+	const bool fresh = act && a >= norig;                                  // an instance on an inserted element: not indexed
+	const bool ahead = j < NA, behind = !ahead && j < NA + NB;
+	const unsigned jj = ahead ? j : j - NA;
+	const bool rev = ahead ? s != 0u : s == 0u;                            // the walk of this lane goes towards lower slots
+	const bool inr = act && !fresh && (ahead || behind) && (rev ? jj <= ablk : ablk + jj < nblk);
+	const unsigned bi = inr ? (rev ? ablk - jj : ablk + jj) : 0u;
+	const ulonglong2 *rp = reinterpret_cast<const ulonglong2 *>(g.bidx + (size_t)bi * BT_IDX_WORDS);
+	const ulonglong2 r0 = rp[0], r1 = rp[1];
+	const unsigned long long m0 = rev ? __brevll(r0.x) : r0.x, m1 = rev ? __brevll(r0.y) : r0.y, sp = rev ? __brevll(r1.x) : r1.x;
+	const int t0 = rev ? (int)a - (int)(bi * 64u + 63u) : (int)(bi * 64u) - (int)a;      // step (from the instance, in this lane's direction) of bit 0
+	const unsigned lo = ahead ? 0u : 1u, hi = ahead ? fwd + 1u : back + 1u;               // the steps lo .. hi - 1 belong to this walk
+	const unsigned long long vm = inr ? idx_bits((int)lo - t0, (int)hi - t0) : 0ull;
+	const unsigned long long sepm = sp & vm & idx_bits(1 - t0, 64);       // (step 0 is the instance itself, never a separator)
+	const unsigned fsl = sepm ? (unsigned)(t0 + (int)__builtin_ctzll(sepm)) : ~0u;
+	unsigned fa = ahead ? fsl : ~0u, fb = behind ? fsl : ~0u;
+#pragma unroll
+	for (int d = 1; d < 16; d <<= 1) { const unsigned va = __shfl_xor(fa, d), vb = __shfl_xor(fb, d); fa = va < fa ? va : fa; fb = vb < fb ? vb : fb; }
+	const unsigned stop = ahead ? fa : fb;                                  // the walk ends BEFORE this step (first separator)
+	const unsigned last = stop < hi ? stop : hi - 1u;                      // last step whose block matters (the separator's own block included)
+	bool slow = fresh || (inr && (unsigned)(r1.y >> 32) != 0u && t0 <= (int)last && t0 + 63 >= (int)lo);
+#pragma unroll
+	for (int d = 1; d < 16; d <<= 1) slow |= __shfl_xor((int)slow, d) != 0;
+	const unsigned end = stop < hi ? stop : hi;
+	L.t0 = t0; L.a = a; L.s = s; L.ahead = ahead;
+	L.ex0 = L.ex1 = L.ord = 0ull;
+	if (inr && !slow) {
+		if (ahead) {
+			const unsigned cend = end < core ? end : core;
+			const unsigned long long cm = idx_bits(-t0, (int)cend - t0), om = idx_bits((int)core - t0, (int)end - t0);
+			L.ex0 = m0 & cm; L.ex1 = m1 & cm; L.ord = (s ? m0 : m1) & om;      // the core: both strands; beyond it: the opposite strand
+		} else L.ord = (s ? m1 : m0) & idx_bits(1 - t0, (int)end - t0);      // behind: the own strand
+	}
+	const unsigned long long sb = __ballot(act && slow && j == 0u);
+	return (unsigned)((sb & 1ull) | ((sb >> 15) & 2ull) | ((sb >> 30) & 4ull) | ((sb >> 45) & 8ull));
+}
+// The marked slots under the set bits of the lanes' masks, COMPACTED through a per-wave LDS list and gathered 64 at a time: the sixteen
+// lanes of an instance hold their marks very unevenly (the core is four of eleven blocks), and a claim step (LDS set, atomicMin, list
+// append: ~40 instructions) is the same price for one id as for 64 -- the reservation is issue-bound.  bits0 / bits1: marks of strand
+// st0 / st1 in this lane's block; f(id) is called on EVERY lane, once per 64 ids.  false: more marks than the list holds (nothing done).
+template <class F>
+__device__ __forceinline__ bool reserve_idx_emit(const GraphView &g, const RsvIdxLane &L, unsigned long long bits0, unsigned st0, unsigned long long bits1, unsigned st1,
+                                                 bool backward, unsigned *list, unsigned RSV_LIST /* entries of the list */, unsigned lane, F f)
+{
+	const unsigned cnt = (unsigned)__popcll(bits0) + (unsigned)__popcll(bits1);
+	unsigned incl = cnt;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
+	const unsigned total = __shfl(incl, 63);
+	if (total > RSV_LIST) return false;
+	if (!total) return true;
+	const bool down = backward ? L.s == 0u : L.s != 0u;                    // slots decrease with the step
+	unsigned o = incl - cnt;
+	for (; bits0; bits0 &= bits0 - 1ull) { const unsigned step = (unsigned)(L.t0 + (int)__builtin_ctzll(bits0)); list[o++] = (down ? L.a - step : L.a + step) | (st0 << 31); }
+	for (; bits1; bits1 &= bits1 - 1ull) { const unsigned step = (unsigned)(L.t0 + (int)__builtin_ctzll(bits1)); list[o++] = (down ? L.a - step : L.a + step) | (st1 << 31); }
+	__builtin_amdgcn_wave_barrier();
+	for (unsigned p0 = 0; p0 < total; p0 += 256u) {
+		unsigned bb[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const unsigned p = p0 + 64u * q + lane;
+			const unsigned e = list[p < total ? p : 0u];
+			bb[q] = g.bif[e >> 31][e & 0x7FFFFFFFu];
+			if (p >= total) bb[q] = BT_NONE;
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) if (p0 + 64u * q < total) f(bb[q]);
+	}
+	__builtin_amdgcn_wave_barrier();
+	return true;
+}
+// (the uncompacted form, for a group with more marks than the list holds: four gathers in flight per lane)
+template <class F>
+__device__ __forceinline__ void reserve_idx_gather(const GraphView &g, const RsvIdxLane &L, unsigned long long bits, unsigned strand, bool backward, F f)
+{
+	const unsigned *__restrict__ marks = g.bif[strand];
+	const bool down = backward ? L.s == 0u : L.s != 0u;                    // slots decrease with the step
+	while (__any(bits != 0ull)) {
+		unsigned sl[4]; bool has[4]; unsigned bb[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			has[q] = bits != 0ull;
+			const unsigned r = has[q] ? (unsigned)__builtin_ctzll(bits) : 0u;
+			if (has[q]) bits &= bits - 1ull;
+			const unsigned step = (unsigned)(L.t0 + (int)r);
+			sl[q] = has[q] ? (down ? L.a - step : L.a + step) : L.a;
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) bb[q] = marks[sl[q]];
+#pragma unroll
+		for (int q = 0; q < 4; q++) f(has[q] ? bb[q] : BT_NONE);
+	}
+}
+
 // one wave per window entry: claim every id of the neighbourhood and remember the list for the commit check
 // The instances of the id are dealt out to the waves of the workgroup (blockDim.x / 64 of them: two where ids have a handful of
 // instances -- 8 strains: 85.0 ms per stage against 86.1 with four and 88.8 with eight -- four where they have dozens, DeviceBackend::rsv_waves).
 #define RSV_WAVES_MAX 4u
-__global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live)
+__global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap)
 {
 	const unsigned RSV_WAVES = blockDim.x >> 6;
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	round_stamp(g, 1);
 	if (w >= nwin || !live[w]) return;
-	__shared__ unsigned seen[SEEN_SLOTS];
+	const bool rprof = (g.test_flags & 32u) != 0u;
+	unsigned long long rt = rprof ? wall_clock64() : 0ull;
+#define RSV_T(i) do { if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[i], n_ - rt); rt = n_; } } while (0)
+	extern __shared__ unsigned rsv_dyn[];                             // the seen-set (1 << seen_bits words), then one list of list_cap words per wave
+	unsigned *const seen = rsv_dyn;
 	__shared__ unsigned resume[RESUME_SLOTS], inst[RESUME_SLOTS];     // per instance: end of the core walk; (element << 1) | strand
+	__shared__ uint8_t served[RESUME_SLOTS];                          // ... its neighbourhood came from the block index (debugging aid)
 	__shared__ unsigned nclaims, ninst_s;
 	__shared__ unsigned s_sep[64];                                     // the separators' slots (see SepBounds), when there are at most 64
 	const unsigned *sepl = g.sep && g.nsep <= 64 ? s_sep : nullptr;
 	if (sepl && threadIdx.x < 64) s_sep[threadIdx.x] = threadIdx.x < g.nsep ? g.sep[threadIdx.x] : BT_NONE;
-	for (unsigned i = threadIdx.x; i < SEEN_SLOTS; i += 64 * RSV_WAVES) seen[i] = BT_NONE;
+	for (unsigned i = threadIdx.x; i < (1u << seen_bits); i += 64 * RSV_WAVES) seen[i] = BT_NONE;
+	unsigned *const my_list = rsv_dyn + (1u << seen_bits) + (size_t)(threadIdx.x >> 6) * list_cap;      // the marked slots of a group of instances, compacted (reserve_idx_emit)
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
 	if (wv == 0) {
@@ -1520,7 +1884,8 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 		if (lane == 0) ninst_s = m;
 	}
 	__syncthreads();
-	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = &nclaims; cl.seen = seen;
+	RSV_T(0);
+	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = &nclaims; cl.seen = seen; cl.sbits = seen_bits;
 	if (wv == 0) wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
 	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
 	// Who can interact with an instance: anything marked where the transaction itself reads or writes (core, both
@@ -1530,7 +1895,55 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	auto order = [&](unsigned b0, unsigned b1) { wave_claim_order(g, cl, st, id, b0, lane); wave_claim_order(g, cl, st, id, b1, lane); };
 	const unsigned ninst = ninst_s;
 	const bool burst = !(g.test_flags & 4u);                          // (SBL_TEST_FLAGS=4: the step-wise walks everywhere, for A/B runs)
-	if (ninst <= RESUME_SLOTS) {
+	// block index (round 5): groups of four instances, sixteen lanes each (reserve_idx_masks); an instance it cannot serve takes the walks
+	const unsigned NA = (fwd + 1u + 126u) >> 6, NB = (back + 1u + 126u) >> 6;
+	const bool indexed = g.idx_reserve && NA + NB <= 16u && ninst <= RESUME_SLOTS;
+	if (indexed) {
+		for (unsigned i0 = 4u * wv; i0 < ninst; i0 += 4u * RSV_WAVES) {      // all exclusive claims first: the seen-set keeps the first kind
+			RsvIdxLane L;
+			const unsigned slowm = reserve_idx_masks(g, inst, ninst, i0, lane, NA, NB, core, fwd, back, L);
+			if (rprof && threadIdx.x == 0 && (L.ex0 | L.ex1 | L.ord) != ~0ull) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[6], n_ - rt); rt = n_; }      // (the records have arrived)
+			if (!reserve_idx_emit(g, L, L.ex0, 0u, L.ex1, 1u, false, my_list, list_cap, lane, [&](unsigned b) { wave_claim(g, cl, st, b, lane); })) {
+				reserve_idx_gather(g, L, L.ex0, 0u, false, [&](unsigned b) { wave_claim(g, cl, st, b, lane); });
+				reserve_idx_gather(g, L, L.ex1, 1u, false, [&](unsigned b) { wave_claim(g, cl, st, b, lane); });
+			}
+			if (lane < 4u && i0 + lane < ninst) { served[i0 + lane] = (uint8_t)(((slowm >> lane) & 1u) ^ 1u); if (g.test_flags & 32u) atomicAdd(&g_idx_stats[6 + ((slowm >> lane) & 1u)], 1u); }
+			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
+				if (!((slowm >> q) & 1u)) continue;
+				const unsigned i = i0 + q;
+				const SepBounds sp = sep_bounds(g, sepl, inst[i] >> 1, lane);
+				unsigned nxt = BT_NONE;
+				if (!burst || !wave_core_claim_burst(g, inst[i] >> 1, inst[i] & 1u, core, lane, cl, st, sp, nxt))
+					nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st, sp);
+				if (lane == 0) resume[i] = nxt;
+			}
+		}
+		__syncthreads();
+		RSV_T(1);
+		for (unsigned i0 = 4u * wv; i0 < ninst; i0 += 4u * RSV_WAVES) {
+			RsvIdxLane L;
+			const unsigned slowm = reserve_idx_masks(g, inst, ninst, i0, lane, NA, NB, core, fwd, back, L);
+			{
+				// (ahead lanes: opposite strand, slots in the instance's direction; behind lanes: own strand, the other way -- two emit calls
+				// share nothing but the list, so the lanes of the other kind pass empty masks)
+				const unsigned long long oa = L.ahead ? L.ord : 0ull, ob = L.ahead ? 0ull : L.ord;
+				if (!reserve_idx_emit(g, L, oa, L.s ^ 1u, 0ull, 0u, false, my_list, list_cap, lane, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); }))
+					reserve_idx_gather(g, L, oa, L.s ^ 1u, false, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
+				if (!reserve_idx_emit(g, L, ob, L.s, 0ull, 0u, true, my_list, list_cap, lane, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); }))
+					reserve_idx_gather(g, L, ob, L.s, true, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
+			}
+			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
+				if (!((slowm >> q) & 1u)) continue;
+				const unsigned i = i0 + q;
+				const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
+				const SepBounds sp = sep_bounds(g, sepl, e0, lane);
+				if (burst && wave_flank_order_burst(g, e0, s, fwd + 1 > core ? nxt : BT_NONE, fwd + 1 > core ? fwd + 1 - core : 0u, back, lane, sp,
+				                                    [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) continue;
+				wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
+				                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sp);
+			}
+		}
+	} else if (ninst <= RESUME_SLOTS) {
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
 			const SepBounds sp = sep_bounds(g, sepl, inst[i] >> 1, lane);
 			unsigned nxt = BT_NONE;
@@ -1571,7 +1984,9 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 			}
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) cl.buf[0] = nclaims;
+	RSV_T(2);
+	if (threadIdx.x == 0) { cl.buf[0] = nclaims; if (rprof) { atomicAdd(&g_rsv_ticks[3], 1ull); atomicAdd(&g_rsv_ticks[4], (unsigned long long)nclaims); atomicAdd(&g_rsv_ticks[5], (unsigned long long)ninst); } }
+#undef RSV_T
 }
 // ---- wave-wide CollapseBulgeGreedily ------------------------------------------------------------------------
 // Same effect as bt_collapse (bulge_txn.h) = EraseBifurcations + DNASequence::Replace + UpdateBifurcations
@@ -1597,6 +2012,7 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 {
 	if (b == BT_NONE) return;
 	g.bif[strand][e] = BT_NONE;
+	bt_idx_mark(g, strand, e, false);
 	g.ndead[nd] = 1;
 	g.nclr[nd] = atomicExch(&t.tc_head, nd);
 	{ unsigned ix = atomicAdd(&t.tc_n, 1u); if (ix < t.tc_cap) t.tc_list[ix] = nd; }
@@ -1711,6 +2127,7 @@ __device__ __forceinline__ void wave_add_points(const GraphView &g, Txn &t, Bulg
 		g.nnext[nd] = pred[c] != BT_NONE ? s_nodebase + pred[c] : hd[c];
 		if (last[c]) { g.head[ad][ab] = nd; g.lsize[ad][ab] = ls[c] + cnt[c]; }
 		g.bif[ad][ae] = ab; g.nodeof[ad][ae] = nd;
+		bt_idx_mark(g, ad, ae, true);
 		if (ab < g.nid) { g.touch[ab] = 1; if (ab > t.id) g.need[ab] = 1; }
 	}
 }
@@ -1774,6 +2191,8 @@ __device__ __forceinline__ void wave_collapse(const GraphView &g, Txn &t, BulgeW
 	WSYNC();
 	PC_ADD(11);
 	if (t.err) return;
+	if (dS != dT)                                                      // links change between T[k - 1] and T[k + dT]: those blocks are no longer pristine (GraphView::bidx)
+		for (unsigned i = k - 1u + lane; i <= k + dT; i += 64) bt_idx_dirty(g, T[i]);
 	{
 		const unsigned nb = s_newbase;
 		for (unsigned j0 = 0; j0 < (dS < dT ? dT : common); j0 += 64) {
@@ -2029,6 +2448,7 @@ __device__ __forceinline__ void wave_collapse_g(const GraphView &g, Txn &t, Bulg
 			if (!has) continue;
 			const unsigned strand = q ? opp : d, b = q ? bo[u] : bd[u], node = q ? no[u] : nd[u];
 			g.bif[strand][e] = BT_NONE;
+			bt_idx_mark(g, strand, e, false);
 			g.ndead[node] = 1;
 			g.nclr[node] = atomicExch(&t.tc_head, node);
 			{ const unsigned ix = atomicAdd(&t.tc_n, 1u); if (ix < t.tc_cap) t.tc_list[ix] = node; }
@@ -2036,6 +2456,10 @@ __device__ __forceinline__ void wave_collapse_g(const GraphView &g, Txn &t, Bulg
 		}
 	}
 	// ---- 4b: DNASequence::Replace in + coordinates (wave_collapse explains P / C and the replayed double accumulation)
+	if (dS != dT) {                                                    // links change between T[k - 1] and T[k + dT]: those blocks are no longer pristine (GraphView::bidx)
+#pragma unroll
+		for (int u = 0; u < NC; u++) { const unsigned x = lane + 64u * u; if (x + 1u >= k && x < nT) bt_idx_dirty(g, Tv[u]); }
+	}
 	{
 		const unsigned nb = newbase;
 		for (unsigned j0 = 0; j0 < (dS < dT ? dT : common); j0 += 64) {
@@ -2990,11 +3414,60 @@ __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t *p, uint8_t v, size_
 }
 
 // ------------------------------------------------------------------------------------------- device backend
+// ---- block index over the original slots (GraphView::bidx) -----------------------------------------------------------------------
+// Built once per stage from the arrays (and again after a roll-back); from then on the transactions keep it up to date
+// (bt_idx_mark / bt_idx_dirty / bt_idx_wstamp).  One wave per block of 64 slots.
+__global__ void __launch_bounds__(256) k_build_blkidx(const uint8_t *__restrict__ ch, const unsigned *__restrict__ nx, const unsigned *__restrict__ pv,
+                                                      const unsigned *__restrict__ bif0, const unsigned *__restrict__ bif1, unsigned norig, unsigned nblk,
+                                                      unsigned long long *__restrict__ bidx)
+{
+	const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (blk >= nblk) return;
+	const unsigned e = blk * 64u + lane;
+	const bool in = e < norig;
+	const uint8_t c = in ? ch[e] : (uint8_t)BT_DEAD_CHAR;
+	const unsigned long long m0 = __ballot(in && bif0[e] != BT_NONE), m1 = __ballot(in && bif1[e] != BT_NONE), sp = __ballot(in && c == BT_SEP);
+	const bool bad = in && (c == BT_DEAD_CHAR || (e + 1u < norig && nx[e] != e + 1u) || (e > 0u && pv[e] != e - 1u));
+	const unsigned long long dirty = __ballot(bad) ? 1ull << 32 : 0ull;
+	if (lane == 0) {
+		unsigned long long *w = bidx + (size_t)blk * BT_IDX_WORDS;
+		w[0] = m0; w[1] = m1; w[2] = sp; w[3] = dirty;
+	}
+}
+// SBL_CHECK_INDEX=1 (tests): the maintained index against a rebuild -- marks and separators exactly, "not pristine" and the write
+// stamps at least what the arrays show.  out[0] = blocks that differ, out[1] = first of them.
+__global__ void __launch_bounds__(256) k_check_blkidx(const uint8_t *__restrict__ ch, const unsigned *__restrict__ nx, const unsigned *__restrict__ pv,
+                                                      const unsigned *__restrict__ bif0, const unsigned *__restrict__ bif1, const unsigned *__restrict__ wmax, unsigned norig, unsigned nblk,
+                                                      const unsigned long long *__restrict__ bidx, unsigned *__restrict__ out)
+{
+	const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (blk >= nblk) return;
+	const unsigned e = blk * 64u + lane;
+	const bool in = e < norig;
+	const uint8_t c = in ? ch[e] : (uint8_t)BT_DEAD_CHAR;
+	const unsigned long long m0 = __ballot(in && bif0[e] != BT_NONE), m1 = __ballot(in && bif1[e] != BT_NONE), sp = __ballot(in && c == BT_SEP);
+	const bool bad = in && (c == BT_DEAD_CHAR || (e + 1u < norig && nx[e] != e + 1u) || (e > 0u && pv[e] != e - 1u));
+	const bool dirty = __ballot(bad) != 0ull;
+	unsigned wm = in ? wmax[e] : 0u;
+	for (int d = 32; d > 0; d >>= 1) { const unsigned v = __shfl_xor(wm, d); wm = v > wm ? v : wm; }
+	if (lane == 0) {
+		const unsigned long long *w = bidx + (size_t)blk * BT_IDX_WORDS;
+		const bool ok = w[0] == m0 && w[1] == m1 && w[2] == sp && (!dirty || (w[3] >> 32)) && (unsigned)w[3] >= wm;
+		if (!ok) { atomicAdd(&out[0], 1u); atomicMin(&out[1], blk); }
+	}
+}
+// the write stamps are reset with rmax / wmax at the start of every iteration attempt (DeviceBackend::reset_round_state)
+__global__ void __launch_bounds__(256) k_idx_clear_stamps(unsigned long long *__restrict__ bidx, unsigned nblk)
+{
+	const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blk < nblk) reinterpret_cast<unsigned *>(bidx + (size_t)blk * BT_IDX_WORDS + 3)[0] = 0u;
+}
+
 struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, robuf;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
@@ -3027,6 +3500,16 @@ struct DeviceBackend {
 	// the stage is run again from its input -- intact until the copy-back -- with checkpoints and iteration replays (sbl_simplify_run).
 	bool optimistic = false;
 	unsigned rsv_waves = 4;                                           // waves of a reservation workgroup (k_reserve)
+	// block index of the original slots (GraphView::bidx): read by the probe and the reservation, maintained by the transactions
+	bool use_index = getenv("SBL_NO_BLOCK_INDEX") == nullptr;        // measurement / test switch: every window is walked (round 4)
+	uint32_t idx_nblk = 0;
+	void index_build()
+	{
+		if (!use_index || !idx_nblk) return;
+		k_build_blkidx<<<(idx_nblk + 3) / 4, 256, 0, c->stream>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), st->pv.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(),
+		                                                         g.norig, idx_nblk, st->bidx.as<unsigned long long>());
+		HIP_TRY(hipGetLastError());
+	}
 	double snapshot_ms = 0, reserve_ms = 0, commit_ms = 0, probe_ms = 0;
 	double commit_event_ms = 0; uint64_t commit_event_launches = 0;      // the event pairs around every 4th launch of the commit kernel
 	unsigned ev_phase = 0;
@@ -3052,6 +3535,9 @@ struct DeviceBackend {
 		// (lock[] belongs to the element-wise stamping of the host-side test driver; the kernels check exclusivity against own[])
 		st->rmax.ensure(nres * 4); st->wmax.ensure(nres * 4);
 		g.lock = nullptr; g.rmax = st->rmax.as<uint32_t>(); g.wmax = st->wmax.as<uint32_t>();
+		g.bidx = use_index && idx_nblk ? st->bidx.as<unsigned long long>() : nullptr;
+		g.idx_probe = g.bidx && getenv("SBL_NO_IDX_PROBE") == nullptr ? 1u : 0u;        // measurement switches: the walking probe / reservation for every entry
+		g.idx_reserve = g.bidx && getenv("SBL_NO_IDX_RESERVE") == nullptr ? 1u : 0u;
 	}
 	bool posted = false;                                              // the selection in flight posts the counters itself (k_select_write)
 	void read_ctr()
@@ -3104,6 +3590,7 @@ struct DeviceBackend {
 		unsigned v[2] = { ck_ne, ck_nn };
 		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_NE, &v[0], 4, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_NN, &v[1], 4, hipMemcpyHostToDevice, c->stream));
+		index_build();                                              // (the block index is derived state: rebuilt from the restored arrays)
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	// segment ranking of the current list (shared with the copy-back): returns the list length, leaves flag / segidx / seg_head / dist[cur] filled
@@ -3254,6 +3741,7 @@ struct DeviceBackend {
 		if (stamps_too) {
 			HIP_TRY(hipMemsetAsync(st->rmax.p, 0, nres * 4, c->stream));
 			HIP_TRY(hipMemsetAsync(st->wmax.p, 0, nres * 4, c->stream));
+			if (g.bidx) k_idx_clear_stamps<<<(idx_nblk + 255) / 256, 256, 0, c->stream>>>(st->bidx.as<unsigned long long>(), idx_nblk);
 		}
 	}
 	void clear_counters()
@@ -3341,14 +3829,17 @@ struct DeviceBackend {
 			share(nwin, &w0, &w1);
 			const uint32_t R = c->comm->n;
 			st->robuf.ensure((size_t)R * 4 + 64);
+			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0);
 			if (w1 > w0) k_probe<<<w1 - w0, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), w0);
 			k_probe_trail<<<1, 1, 0, c->stream>>>(st->ctr.as<unsigned>(), st->robuf.as<unsigned>(), c->comm->rank);
 			HIP_TRY(hipGetLastError());
 			allgather_shares(st->live.as<char>(), nwin, 1);
 			allgather_shares(st->robuf.as<char>(), R, 4);
 			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<unsigned>(), R);
-		} else
+		} else {
+			if (g.idx_probe) k_probe_idx<<<nwin, 64, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u);      // the block index first; k_probe walks what it could not serve
 			k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), 0u);
+		}
 		probed_nwin = nwin;                                          // (the next selection counts what this probe retired)
 		HIP_TRY(hipGetLastError());
 	}
@@ -3357,7 +3848,10 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 2;
-		k_reserve<<<nwin, 64 * rsv_waves, 0, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>());
+		// dynamic LDS: the seen-set + one compaction list per wave, sized by the instances an id has (a handful: 1024 + 2 x 256 words = 6 KB;
+		// dozens: 2048 + 4 x 1024 words) -- what a reservation workgroup holds in LDS decides how many are resident
+		const unsigned seen_bits = rsv_waves <= 2 ? 10u : 11u, list_cap = rsv_waves <= 2 ? 256u : 1024u;
+		k_reserve<<<nwin, 64 * rsv_waves, ((1u << seen_bits) + rsv_waves * list_cap) * 4, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>(), seen_bits, list_cap);
 		HIP_TRY(hipGetLastError());
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
@@ -3443,7 +3937,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -3487,7 +3981,17 @@ struct ProgressFilter {
 };
 enum { RUN_DONE = 0, RUN_DENSE_FAILED = 1, RUN_RESTART = 2 };
 static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic);
+static void simplify_run_guarded(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
+{
+	// With several GPUs on one job every snapshot and every probe of the stage is a collective (allgather_shares): a rank that leaves
+	// the stage with an error anywhere -- an allocation that fails, a HIP error, a check that throws -- must release the peers that
+	// would wait for it there (the deterministic RestartStage is thrown on all ranks alike and never gets here).
+	if (!c->comm) { simplify_run_guarded(c, k, D, max_iter, progress, user, bulges); return; }
+	try { simplify_run_guarded(c, k, D, max_iter, progress, user, bulges); }
+	catch (...) { c->comm->abort_peers(); throw; }
+}
+static void simplify_run_guarded(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
 {
 	// the stage's input (d_ch / d_op) is only replaced by the copy-back at the very end, so an attempt that cannot finish -- a one-launch
 	// run out of pool or arena space, an optimistic run that would need a roll-back -- is simply followed by the next one from the same input
@@ -3526,10 +4030,12 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	size_t E = c->nelem, ne0 = (E + 31) / 32 * 32;
 	size_t cap_e = ne0 + E / 8 + (1u << 20);
 	if (const char *e = getenv("SBL_TEST_ELEM_SLACK")) cap_e = ne0 + (size_t)atoll(e);      // test hook: provoke the grow / restart paths
-	cap_e = std::max(cap_e, ne0 + c->hint_elem_slack);                // what an abandoned attempt of this context asked for (DeviceBackend::grow)
+	cap_e = std::max(cap_e, ne0 + std::min<size_t>(c->hint_elem_slack, 4 * E + (1u << 20)));      // what an abandoned attempt of this context asked for (DeviceBackend::grow), bounded by the current input
 	be.ne0_ = ne0;
 	SBL_CHECK(cap_e < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "element capacity overflow");
 	sbl_run_enumeration(c, k, cap_e);
+	if (c->comm) if (const char *e = getenv("SBL_TEST_FAIL_SIMPLIFY_RANK")) if ((uint32_t)atoi(e) == c->comm->rank)      // test hook: this rank leaves the stage between two collectives
+		throw SblError{SBL_ERR_OOM, "out of memory (SBL_TEST_FAIL_SIMPLIFY_RANK: this rank leaves the simplification stage)"};
 	be.nid_ = c->bif_count;
 	be.cap_e = (uint32_t)cap_e;
 
@@ -3665,6 +4171,9 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		{ std::vector<unsigned long long> zz(4096 * 2, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_few), zz.data(), 4096 * 2 * 8)); }
 		{ std::vector<unsigned long long> zz(4096 * 3, 0); for (unsigned r = 0; r < 4096; r++) zz[3 * r] = ~0ull; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_span), zz.data(), 4096 * 3 * 8)); }
 	}
+	if (dense) be.use_index = false;                                   // (the one-launch path reads no index: nothing to maintain)
+	be.idx_nblk = be.use_index ? (uint32_t)((E + 63) / 64) : 0u;
+	if (be.idx_nblk) st->bidx.ensure((size_t)be.idx_nblk * BT_IDX_WORDS * 8);
 	be.bind();
 	be.g.k = k; be.g.D = D;
 	be.g.test_flags = getenv("SBL_TEST_FLAGS") ? (unsigned)atoi(getenv("SBL_TEST_FLAGS")) : 0u;
@@ -3677,6 +4186,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	be.g.tstamp = nullptr; be.g.tslot = 0;
 	be.g.sep = c->d_sepidx.as<unsigned>(); be.g.nsep = c->nchr + 1; be.g.norig = (uint32_t)E;
 	if (getenv("SBL_SEP_BY_CHAR")) be.g.sep = nullptr;                   // measurement switch: separators recognised by their character everywhere
+	be.index_build();
 	if (!dense && be.phase_events) be.stamps_init();
 	HIP_TRY(hipEventRecord(c->ev[3], s));
 
@@ -3715,6 +4225,30 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 	if (!dense && be.phase_events) be.stamps_collect();
+	if (be.g.bidx && (be.g.test_flags & 32u)) {                          // SBL_TEST_FLAGS=32: what the block index served
+		unsigned z[8];
+		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_idx_stats), sizeof z));
+		fprintf(stderr, "[sbl] block index: probes known-live %u, < 2 instances %u, clean %u, live %u, table full %u, not served %u; reservation instances served %u, walked %u\n", z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+		memset(z, 0, sizeof z);
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_idx_stats), z, sizeof z));
+		unsigned long long rz[8];
+		HIP_TRY(hipMemcpyFromSymbol(rz, HIP_SYMBOL(g_rsv_ticks), sizeof rz));
+		if (rz[3]) fprintf(stderr, "[sbl] reservations: %llu entries, %.1f claims and %.1f instances each; per entry (10 ns ticks of the device wall clock): set-up %.0f, records %.0f, exclusive claims %.0f, ordering claims %.0f\n",
+		                   rz[3], (double)rz[4] / rz[3], (double)rz[5] / rz[3], (double)rz[0] / rz[3], (double)rz[6] / rz[3], (double)rz[1] / rz[3], (double)rz[2] / rz[3]);
+		memset(rz, 0, sizeof rz);
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rsv_ticks), rz, sizeof rz));
+	}
+	if (be.g.bidx && getenv("SBL_CHECK_INDEX")) {                        // test switch: the maintained block index against a rebuild
+		unsigned init[2] = {0u, BT_NONE}, res[2];
+		unsigned *d_out = st->ctr.as<unsigned>() + CTR_DETAIL + 16;
+		HIP_TRY(hipMemcpyAsync(d_out, init, sizeof init, hipMemcpyHostToDevice, s));
+		k_check_blkidx<<<(be.idx_nblk + 3) / 4, 256, 0, s>>>(st->ch.as<uint8_t>(), st->nx.as<unsigned>(), st->pv.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>(),
+		                                                    st->wmax.as<unsigned>(), be.g.norig, be.idx_nblk, st->bidx.as<unsigned long long>(), d_out);
+		HIP_TRY(hipMemcpyAsync(res, d_out, sizeof res, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] block index check: %u of %u blocks differ from a rebuild\n", res[0], be.idx_nblk);
+		if (res[0]) { char b[160]; snprintf(b, sizeof b, "block index out of date: %u of %u blocks differ from a rebuild (first: block %u)", res[0], be.idx_nblk, res[1]); throw SblError{SBL_ERR_INTERNAL, b}; }
+	}
 
 	// ---- T3: copy-back (reference src/blockfinder.cpp:85-95): linearise the list into the dense state arrays
 	be.read_ctr();

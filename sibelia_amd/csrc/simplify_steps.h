@@ -53,7 +53,7 @@ __host__ __device__ inline void ss_mark_big(const GraphView &g, uint32_t id)
 // Probe of a pending id between rounds (no writer is running): ids whose AnyBulges verdict is false NOW are retired
 // without any reservation -- exactly like ids the snapshot found clean, they become pending again if a lower id later
 // rewrites something they can see.  Returns true when the id really has bulges (it then goes through reserve / commit).
-__host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes)
+__host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint8_t *arena, uint32_t arena_bytes, uint32_t *err_out = nullptr)
 {
 	uint32_t id = g.win[widx];
 	Txn t;
@@ -61,6 +61,7 @@ __host__ __device__ inline bool ss_probe(const GraphView &g, uint32_t widx, uint
 	t.init(g, id, widx, 3, arena, arena_bytes);
 	bool has = false;
 	if (bt_setup(t, w, true)) { bt_scan_all(t, w); bt_end_chars(t, w); has = bt_any_bulges(t, w, true); }
+	if (err_out) *err_out = t.err;
 	if (t.err) return true;                    // undecidable here: let the commit path sort it out
 	if (!has) { g.need[id] = 0; g.touch[id] = 0; bt_atomic_add(&g.ctr[CTR_COMMITTED], 1u); }   // verdict taken now: clean until touched again
 	return has;
@@ -148,6 +149,103 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 		bt_atomic_or(&g.ctr[CTR_ERR], t.err);
 	}
 	bt_atomic_add(&g.ctr[CTR_BULGES], w.ret);
+}
+
+// ---- the block index (GraphView::bidx) read by ONE thread: reference forms of what k_probe / k_reserve evaluate with 64 lanes
+// (simplify.hip: probe_idx, reserve_idx).  tests/hostsim runs them beside ss_probe / bt_footprint on every probed / reserved entry and
+// compares, and rebuilds the index from the arrays at the end of a stage: the maintenance sites (bt_idx_mark / bt_idx_dirty /
+// bt_idx_wstamp) are complete iff the two agree on every vector.
+struct IdxRec { unsigned long long m[2], sep; uint32_t wmaxb, dirty; };
+__host__ __device__ inline IdxRec bt_idx_load(const GraphView &g, uint32_t blk)
+{
+	IdxRec r;
+	const unsigned long long *p = g.bidx + (size_t)blk * BT_IDX_WORDS;
+	r.m[0] = p[0]; r.m[1] = p[1]; r.sep = p[2]; r.wmaxb = (uint32_t)p[3]; r.dirty = (uint32_t)(p[3] >> 32);
+	return r;
+}
+// AnyBulges verdict of id from the index: 1 live, 0 clean, -2 the index cannot serve one of its windows (a fresh slot, a block that is
+// no longer pristine, or -- with tid != 0 -- a block that carries a write stamp above tid: the walking path makes the exact order check)
+__host__ __device__ inline int ss_verdict_idx(const GraphView &g, uint32_t id, uint32_t tid)
+{
+	if (!g.bidx) return -2;
+	const uint32_t k = g.k, D = g.D, ws = D + k + 2;
+	enum { CAP = 2048 };
+	uint32_t keys[CAP]; uint8_t masks[CAP];
+	for (uint32_t i = 0; i < CAP; i++) { keys[i] = BT_NONE; masks[i] = 0; }
+	uint32_t used = 0;
+	bool found = false;
+	for (uint32_t s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+			if (g.ndead[nd]) continue;
+			const uint32_t a = g.nslot[nd];
+			if (a >= g.norig) return -2;
+			uint32_t len = ws;
+			for (uint32_t t = 0; t < ws; t++) {
+				if (s && t > a) { len = t; break; }
+				const uint32_t slot = s ? a - t : a + t;
+				if (slot >= g.norig) { len = t; break; }
+				const IdxRec r = bt_idx_load(g, slot >> 6);
+				if (r.dirty) return -2;
+				if ((r.sep >> (slot & 63u)) & 1ull) { len = t; break; }
+				if (tid && r.wmaxb > tid) return -2;
+			}
+			if (len < k + 1) continue;                                // endChar ' ': the instance takes no part
+			const uint8_t raw = g.ch[s ? a - k : a + k];
+			const char ec = s ? bt_comp((char)raw) : (char)raw;
+			const uint8_t bit = ec == 'A' ? 1 : ec == 'C' ? 2 : ec == 'G' ? 4 : 8;
+			const uint32_t lim = len < D ? len : D;
+			for (uint32_t t = 1; t < lim; t++) {
+				const uint32_t slot = s ? a - t : a + t;
+				const IdxRec r = bt_idx_load(g, slot >> 6);
+				if (!((r.m[s] >> (slot & 63u)) & 1ull)) continue;
+				const uint32_t b = g.bif[s][slot];
+				if (b == id) break;
+				uint32_t h = (b * 2654435761u) >> 21;
+				for (;;) {
+					if (keys[h] == BT_NONE) { if (++used > CAP / 2) return -2; keys[h] = b; }
+					if (keys[h] == b) { masks[h] |= bit; if (masks[h] & (masks[h] - 1)) found = true; break; }
+					h = (h + 1) & (CAP - 1);
+				}
+			}
+		}
+	return found ? 1 : 0;
+}
+// bt_footprint from the index: calls f exactly for the (id, kind) pairs bt_footprint reports (possibly in another order / multiplicity);
+// false: the index cannot serve the neighbourhood of one of the instances (nothing may have been reported then -- callers collect first)
+template <class F>
+__host__ __device__ inline bool bt_footprint_idx(const GraphView &g, uint32_t id, F f)
+{
+	if (!g.bidx) return false;
+	const uint32_t back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
+	f(id, 0u);
+	for (uint32_t s = 0; s < 2; s++)
+		for (uint32_t nd = g.head[s][id]; nd != BT_NONE; nd = g.nnext[nd]) {
+			if (g.ndead[nd]) continue;
+			const uint32_t a = g.nslot[nd];
+			if (a >= g.norig) return false;
+			for (uint32_t t = 0; t <= fwd; t++) {                     // ahead: the core (both strands, exclusive), then the opposite strand (ordering)
+				if (s && t > a) break;
+				const uint32_t slot = s ? a - t : a + t;
+				if (slot >= g.norig) break;
+				const IdxRec r = bt_idx_load(g, slot >> 6);
+				if (r.dirty) return false;
+				const unsigned long long bit = 1ull << (slot & 63u);
+				if (t && (r.sep & bit)) break;
+				if (t < core) { if (r.m[0] & bit) f(g.bif[0][slot], 0u); if (r.m[1] & bit) f(g.bif[1][slot], 0u); }
+				else if (r.m[s ^ 1u] & bit) f(g.bif[s ^ 1u][slot], 1u);
+			}
+			for (uint32_t t = 1; t <= back; t++) {                    // behind: the own strand (ordering)
+				if (!s && t > a) break;
+				const uint32_t slot = s ? a + t : a - t;
+				if (slot >= g.norig) break;
+				const IdxRec r = bt_idx_load(g, slot >> 6);
+				if (r.dirty) return false;
+				const unsigned long long bit = 1ull << (slot & 63u);
+				if (r.sep & bit) break;
+				if (r.m[s] & bit) f(g.bif[s][slot], 1u);
+			}
+		}
+	return true;
 }
 
 __host__ __device__ inline bool ss_owns_footprint(const GraphView &g, uint32_t widx)

@@ -24,6 +24,40 @@ struct HostBackend {
 	int order_mode = 0;
 	uint32_t arena_bytes = 1u << 16, big_arena_bytes = 1u << 26;
 	std::vector<uint8_t> arena, big_arena;
+	// block index (GraphView::bidx): maintained by the transaction code, rebuilt here from the arrays for comparison
+	std::vector<unsigned long long> bidx;
+	uint64_t idx_probe_checked = 0, idx_probe_served = 0, idx_fp_checked = 0, idx_fp_served = 0;
+	void idx_build(std::vector<unsigned long long> &out, bool stamps) const
+	{
+		const uint32_t norig = g.norig, nb = (norig + 63) / 64;
+		out.assign((size_t)nb * BT_IDX_WORDS, 0ull);
+		for (uint32_t e = 0; e < norig; e++) {
+			unsigned long long *w = &out[(size_t)(e >> 6) * BT_IDX_WORDS];
+			const unsigned long long bit = 1ull << (e & 63u);
+			if (bif[0][e] != BT_NONE) w[0] |= bit;
+			if (bif[1][e] != BT_NONE) w[1] |= bit;
+			if (ch[e] == BT_SEP) w[2] |= bit;
+			const bool bad = ch[e] == BT_DEAD_CHAR || (e + 1 < norig && nx[e] != e + 1) || (e > 0 && pv[e] != e - 1);
+			if (bad) w[3] |= 1ull << 32;
+			if (stamps && wmax[e] > (uint32_t)w[3]) w[3] = (w[3] & ~0xFFFFFFFFull) | wmax[e];
+		}
+	}
+	// the maintained index against a rebuild: marks and separators exactly, "not pristine" and the stamps at least what a rebuild finds
+	void idx_check(const char *where) const
+	{
+		if (!g.bidx) return;
+		std::vector<unsigned long long> want;
+		idx_build(want, true);
+		for (size_t b = 0; b * BT_IDX_WORDS < want.size(); b++) {
+			const unsigned long long *h = &bidx[b * BT_IDX_WORDS], *w = &want[b * BT_IDX_WORDS];
+			const bool ok = h[0] == w[0] && h[1] == w[1] && h[2] == w[2] && (!(w[3] >> 32) || (h[3] >> 32)) && (uint32_t)h[3] >= (uint32_t)w[3];
+			if (!ok) {
+				char msg[256];
+				snprintf(msg, sizeof msg, "block index out of date (%s): block %zu has %llx %llx %llx %llx, a rebuild gives %llx %llx %llx %llx", where, b, h[0], h[1], h[2], h[3], w[0], w[1], w[2], w[3]);
+				throw SblError{SBL_ERR_INTERNAL, msg};
+			}
+		}
+	}
 	uint64_t rng = 88172645463325252ull;
 	// checkpoint
 	struct Ck { std::vector<uint8_t> ch, ndead, touch; std::vector<uint32_t> op, nx, pv, bif[2], nodeof[2], nslot, nnext, head[2], lsize[2]; uint32_t ne, nn; } ck;
@@ -38,6 +72,7 @@ struct HostBackend {
 		g.cap_e = (uint32_t)ch.size(); g.cap_n = (uint32_t)nslot.size();
 		g.nblk = (g.cap_e >> BT_BLOCK_SHIFT) + 1;
 		g.win = win.data();
+		g.bidx = bidx.empty() ? nullptr : bidx.data();
 	}
 	uint32_t nid() { return nid_; }
 	void checkpoint()
@@ -52,6 +87,7 @@ struct HostBackend {
 		cp(ch, ck.ch); cp(ndead, ck.ndead); cp(touch, ck.touch); cp(op, ck.op); cp(nx, ck.nx); cp(pv, ck.pv); cp(nslot, ck.nslot); cp(nnext, ck.nnext);
 		for (int s = 0; s < 2; s++) { cp(bif[s], ck.bif[s]); cp(nodeof[s], ck.nodeof[s]); cp(head[s], ck.head[s]); cp(lsize[s], ck.lsize[s]); }
 		ctr[CTR_NE] = ck.ne; ctr[CTR_NN] = ck.nn;
+		if (g.bidx) idx_build(bidx, false);
 	}
 	void snapshot_all(bool incremental)
 	{
@@ -61,7 +97,10 @@ struct HostBackend {
 	{
 		std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
 		std::fill(lock.begin(), lock.end(), 0xFFFFFFFFu);
-		if (stamps_too) { std::fill(rmax.begin(), rmax.end(), 0u); std::fill(wmax.begin(), wmax.end(), 0u); }
+		if (stamps_too) {
+			std::fill(rmax.begin(), rmax.end(), 0u); std::fill(wmax.begin(), wmax.end(), 0u);
+			for (size_t b = 3; b < bidx.size(); b += BT_IDX_WORDS) bidx[b] &= ~0xFFFFFFFFull;
+		}
 	}
 	void clear_counters()
 	{
@@ -102,7 +141,26 @@ struct HostBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		live.assign(nwin, 0);
-		for (uint32_t w : order(nwin)) live[w] = ss_probe(g, w, arena.data(), arena_bytes) ? 1 : 0;
+		for (uint32_t w : order(nwin)) {
+			// the verdict the index gives (ss_verdict_idx: what k_probe's probe_idx evaluates) must be the walking probe's wherever it gives one
+			const uint32_t id = win[w];
+			const uint32_t viol_before = ctr[CTR_VIOL];
+			const int vi = ss_verdict_idx(g, id, id + 1);
+			uint8_t need_before = need[id];
+			uint32_t perr = 0;
+			const bool has = ss_probe(g, w, arena.data(), arena_bytes, &perr);
+			live[w] = has ? 1 : 0;
+			idx_probe_checked++;
+			if (vi >= 0 && ctr[CTR_VIOL] == viol_before && !perr) {
+				idx_probe_served++;
+				const bool few = g.lsize[0][id] + g.lsize[1][id] < 2;      // (bt_setup: fewer than two instances, nothing to do)
+				if (!few && (vi == 1) != has) {
+					char msg[160];
+					snprintf(msg, sizeof msg, "index verdict %d of id %u differs from the walking probe's %d (need was %u)", vi, id, (int)has, need_before);
+					throw SblError{SBL_ERR_INTERNAL, msg};
+				}
+			}
+		}
 	}
 	void mark_live(uint32_t nwin) { live.assign(nwin, 1); }
 	void reserve(uint32_t nwin, uint32_t round)
@@ -114,11 +172,23 @@ struct HostBackend {
 			if (!live[w]) continue;
 			uint32_t st = g.round_bits | w;
 			uint32_t me = win[w];
+			std::set<std::pair<uint32_t, uint32_t>> walked, indexed;
 			bt_footprint(g, me, [&](uint32_t b, uint32_t kind) {
+				walked.insert({b, kind});
 				if (kind == 0) { bt_atomic_min(&g.own[b], st); claims[w].push_back(b); }
 				else if (b > me) bt_atomic_min(&g.own[b], st);
 				else if (b < me) claims[w].push_back(b | 0x80000000u);
 			});
+			// the footprint the index gives (bt_footprint_idx: what k_reserve's reserve_idx walks) must be the same set of (id, kind) pairs
+			idx_fp_checked++;
+			if (bt_footprint_idx(g, me, [&](uint32_t b, uint32_t kind) { indexed.insert({b, kind}); })) {
+				idx_fp_served++;
+				if (indexed != walked) {
+					char msg[200];
+					snprintf(msg, sizeof msg, "index footprint of id %u differs from the walked one (%zu against %zu pairs)", me, indexed.size(), walked.size());
+					throw SblError{SBL_ERR_INTERNAL, msg};
+				}
+			}
 		}
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
@@ -247,7 +317,15 @@ extern "C" int hostsim_stage(uint32_t nchr, const uint8_t *const *seq, const uin
 			}
 		}
 		be.ctr[CTR_NN] = nn;
+		if (!getenv("HOSTSIM_NO_INDEX")) {
+			be.g.norig = (uint32_t)E;
+			be.idx_build(be.bidx, false);
+			be.bind();
+		}
 		SimplifyReport rep = simplify_graph(be, max_iter, window, nullptr, nullptr);
+		be.idx_check("end of the stage");
+		if (getenv("HOSTSIM_INDEX_STATS")) fprintf(stderr, "[hostsim] index served %llu of %llu probes, %llu of %llu footprints\n", (unsigned long long)be.idx_probe_served,
+		                                           (unsigned long long)be.idx_probe_checked, (unsigned long long)be.idx_fp_served, (unsigned long long)be.idx_fp_checked);
 		for (uint32_t c = 0; c < nchr; c++) {
 			std::vector<uint8_t> s; std::vector<uint32_t> p;
 			for (uint32_t x = be.nx[sep[c]]; x != sep[c + 1]; x = be.nx[x]) { s.push_back(be.ch[x]); p.push_back(be.op[x] & BT_POS_MASK); }

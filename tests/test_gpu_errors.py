@@ -111,6 +111,23 @@ def test_long_k_preflight_reports_missing_memory(monkeypatch):
         bf.close()
 
 
+def test_a_rank_failing_inside_the_simplification_releases_its_peers(monkeypatch):
+    """the read-only phases of the simplification are collectives too (verdict bytes all-gathered per snapshot and per probe): a rank
+    that leaves the stage with an error anywhere must not leave its peers waiting there (SBL_TEST_FAIL_SIMPLIFY_RANK: that rank throws
+    SBL_ERR_OOM between the enumeration and the first snapshot)"""
+    from sibelia_amd import SibeliaError, workloads as W
+    from sibelia_amd.dist import LocalShardedFinder
+    seqs = W.gen_strains(L0=120_000, n=4, seed=11, inv_min=2000, inv_max=8000)
+    f = LocalShardedFinder(seqs, [0, 0, 0])
+    try:
+        monkeypatch.setenv("SBL_TEST_FAIL_SIMPLIFY_RANK", "2")
+        with pytest.raises(SibeliaError):
+            f.simplify_stage(25, 150, 4)
+        monkeypatch.delenv("SBL_TEST_FAIL_SIMPLIFY_RANK")
+    finally:
+        f.close()
+
+
 def test_a_failing_virtual_rank_releases_its_peers(monkeypatch):
     """sharded abort path: one of three virtual ranks fails with SBL_ERR_OOM inside the collective enumeration; its peers must
     come back with an error instead of waiting at the barrier for ever (SBL_TEST_FAIL_RANK: that rank throws SBL_ERR_OOM after the exchange)"""

@@ -1,0 +1,68 @@
+"""Performance guard of the headline workload inside `-m gpu`: one stage of 8 x 4.6 Mbp at k = 25, D = 150 must not take more than
+1.3 x what the last committed bench line under profiles/ (rNN_bench_default.json) recorded for it.  The loose wall-clock bounds of
+the parity tests (CI stability) would let a 2 x regression of the stage through; this one would not.  Best of three timed steps
+after a warm-up, on a box nobody else is using (skipped when rocm-smi shows the GPU busy before the test starts)."""
+import glob
+import json
+import os
+import re
+import subprocess
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOLERANCE = 1.3
+
+
+def _recorded():
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")):
+        m = re.match(r"r(\d+)_bench_default\.json", os.path.basename(f))
+        if not m:
+            continue
+        try:
+            line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+        except (OSError, ValueError, IndexError):
+            continue
+        if d.get("n_gpus", 1) == 1 and "ms_per_step" in d and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), float(d["ms_per_step"]), os.path.basename(f))
+    return best
+
+
+def _gpu_busy_percent():
+    try:
+        out = subprocess.run(["rocm-smi", "--showuse", "--json"], capture_output=True, text=True, timeout=30).stdout
+        use = [float(v) for card in json.loads(out).values() for k, v in card.items() if "GPU use" in k]
+        return max(use) if use else None
+    except Exception:      # noqa: BLE001 -- no rocm-smi, unexpected format: do not skip
+        return None
+
+
+def test_headline_stage_is_not_slower_than_the_committed_bench_line():
+    rec = _recorded()
+    if rec is None:
+        pytest.skip("no profiles/rNN_bench_default.json to compare with")
+    busy = _gpu_busy_percent()
+    if busy is not None and busy > 20.0:
+        pytest.skip("the GPU is %.0f %% busy before the test starts: not an idle box" % busy)
+    from sibelia_amd import BlockFinder, workloads as W
+    seqs = W.gen_strains(L0=4_600_000, n=8, seed=1)
+    bf = BlockFinder(seqs, device=0)
+    try:
+        bf.save_state()
+        times = []
+        for i in range(4):
+            bf.restore_state()
+            t0 = time.perf_counter()
+            bulges = bf.PerformGraphSimplifications(25, 150, 4)
+            if i:
+                times.append(1e3 * (time.perf_counter() - t0))
+        assert bulges == 334284                                        # (the reference's count on this workload, tests/golden/vectors.json)
+        assert bf.stats()["replays"] == 0
+        assert min(times) <= TOLERANCE * rec[1], "stage %.1f ms (best of %s) against %.1f ms recorded in profiles/%s: more than %.1f x" % (
+            min(times), ["%.1f" % t for t in times], rec[1], rec[2], TOLERANCE)
+    finally:
+        bf.close()
