@@ -76,6 +76,22 @@ __global__ void __launch_bounds__(256) k_lk_rank8(const unsigned *__restrict__ s
 	for (unsigned j = 0; j < 8; j++) v = v * 5u + ((unsigned long long)i + j < np ? sym[i + j] : 0u);
 	rank[i] = v;
 }
+// Round 5: the FIRST sorted round starts from 27 symbols instead of 2 x 8: their base-5 number fits 63 bits (5^27 < 2^63), is
+// order-preserving and equal iff the 27 symbols are (positions past the end read '#' = 0, like the padding), so ONE 64-bit sort gives
+// rank_27 -- where the 8-symbol start needed the rounds 8 -> 16 -> 32 (two sorts of all suffixes and two sorts back into position
+// order) to get that far.  Unrelated / random sequence is unique after 27 symbols almost everywhere (config 5: the active set of the
+// second round is the planted repeats), related genomes save one of their rounds.  sym[] holds one symbol per 32-bit word.
+#define LK_FIRST_H 27u
+__global__ void __launch_bounds__(256) k_lk_key27(const unsigned *__restrict__ sym, unsigned np, unsigned long long *__restrict__ keys, unsigned *__restrict__ idx)
+{
+	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= np) return;
+	unsigned long long v = 0;
+#pragma unroll
+	for (unsigned j = 0; j < LK_FIRST_H; j++) v = v * 5ull + ((unsigned long long)i + j < np ? sym[i + j] : 0u);
+	keys[i] = v;
+	idx[i] = i;
+}
 __global__ void __launch_bounds__(256) k_lk_heads(const unsigned long long *__restrict__ skeys, unsigned n, unsigned *__restrict__ flag)
 {
 	unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,13 +105,15 @@ __global__ void __launch_bounds__(256) k_lk_scatter_rank(const unsigned *__restr
 	if (j < n) rank[sidx[j]] = scan[j] - 1;
 }
 
-// final keys of the k-windows; windows that contain a separator get the all-ones key and sort to the end
+// final keys of the k-windows on 2 rb bits (rb = bits of the largest rank); windows that contain a separator get the all-ones key of that
+// width and sort to the end.  The number of valid windows is the metric's N = 2 sum(len - k + 1), known on the host: counting them here
+// -- one atomic per wave on one address, 1.15 M of them on the bench workload -- was 13 ms of the 43 ms of kernels of a k = 100 enumeration.
 __global__ void __launch_bounds__(256) k_lk_window_keys(const unsigned *__restrict__ rank, const unsigned *__restrict__ sepidx, unsigned nchr,
-                                                        unsigned E, unsigned n, unsigned k, unsigned h,
-                                                        unsigned long long *__restrict__ keys, unsigned *__restrict__ idx, unsigned *__restrict__ nvalid)
+                                                        unsigned E, unsigned n, unsigned k, unsigned h, unsigned rb,
+                                                        unsigned long long *__restrict__ keys, unsigned *__restrict__ idx)
 {
 	unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;                                          // (lanes that leave here take no part in the ballot below)
+	if (i >= n) return;
 	bool valid = false;
 	if (i < E) {
 		unsigned c = lk_chr_of(sepidx, nchr, i);
@@ -105,11 +123,9 @@ __global__ void __launch_bounds__(256) k_lk_window_keys(const unsigned *__restri
 		unsigned j = r - sepidx[c], len = sepidx[c + 1] - sepidx[c] - 1;
 		valid = (unsigned long long)j + k <= len;
 	}
-	keys[i] = valid ? (((unsigned long long)rank[i] << 32) | rank[i + k - h]) : ~0ull;
+	const unsigned long long none = 2u * rb >= 64u ? ~0ull : (1ull << (2u * rb)) - 1ull;
+	keys[i] = valid ? (((unsigned long long)rank[i] << rb) | rank[i + k - h]) : none;
 	idx[i] = i;
-	// one atomic per wave, not per window: 1.8 G atomics on one address were 319 ms of config 5's 2.87 s (rocprofv3, round 3)
-	const unsigned long long m = __ballot(valid);
-	if (m && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) atomicAdd(nvalid, (unsigned)__popcll(m));
 }
 
 // per sorted window: prev / next character masks (bit 0-3 = A C G T, bit 4 = '#'; next in bits 8-12) and the group-head flag
@@ -329,10 +345,13 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	HIP_TRY(hipMemcpyAsync(L.sym.p, rank, np * 4, hipMemcpyDeviceToDevice, s));
 	size_t h = 1;
 	unsigned maxrank = 4;                                            // symbols 0 .. 4
+	const bool first27 = k >= LK_FIRST_H && getenv("SBL_LONGK_FROM_1") == nullptr && getenv("SBL_LONGK_NO_DISCARD") == nullptr && getenv("SBL_LONGK_FROM_8") == nullptr;      // (SBL_LONGK_FROM_8: A/B switch, the round-4 start)
 	if (k >= 16 && getenv("SBL_LONGK_FROM_1") == nullptr) {          // (k > 32 here: always; the switch is for A/B tests)
-		k_lk_rank8<<<nblocks(np, 256), 256, 0, s>>>(L.sym.as<unsigned>(), (unsigned)np, L.rank[1].as<unsigned>());
 		rank = L.rank[1].as<unsigned>();
-		h = 8; maxrank = 390624;
+		if (!first27) {
+			k_lk_rank8<<<nblocks(np, 256), 256, 0, s>>>(L.sym.as<unsigned>(), (unsigned)np, L.rank[1].as<unsigned>());
+			h = 8; maxrank = 390624;
+		}
 	}
 	const bool by_sort = np >= (1u << 22) && getenv("SBL_LONGK_SCATTER") == nullptr;      // small inputs: the scatter stays in cache
 	const bool discard = k >= 16 && getenv("SBL_LONGK_FROM_1") == nullptr && getenv("SBL_LONGK_NO_DISCARD") == nullptr;
@@ -351,9 +370,11 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			const bool full = first || na > np / 2;
 			const unsigned rb = first ? lk_bits(maxrank) : rbp;
 			const unsigned m = full ? (unsigned)np : na;
-			if (full) k_lk_pair_keys<<<nblocks(np, 256), 256, 0, s>>>(rank, (unsigned)np, (unsigned)h, rb, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
+			const bool from27 = first && first27;                   // the first round: rank_27 straight from the symbols (k_lk_key27), one 63-bit sort
+			if (from27) k_lk_key27<<<nblocks(np, 256), 256, 0, s>>>(L.sym.as<unsigned>(), (unsigned)np, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
+			else if (full) k_lk_pair_keys<<<nblocks(np, 256), 256, 0, s>>>(rank, (unsigned)np, (unsigned)h, rb, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
 			else k_lk_active_keys<<<nblocks(na, 256), 256, 0, s>>>(rank, L.act.as<unsigned>(), na, (unsigned)np, (unsigned)h, rb, L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
-			lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), m, std::min(64u, 2 * rb));
+			lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), m, from27 ? 63u : std::min(64u, 2 * rb));
 			k_lk_heads2<<<nblocks(m, 256), 256, 0, s>>>(L.skeys.as<unsigned long long>(), m, rb, L.flag.as<unsigned>(), L.scan.as<unsigned>());
 			lk_max_scan(c, L.flag.as<unsigned>(), L.mask.as<unsigned>(), m);       // gstart
 			lk_max_scan(c, L.scan.as<unsigned>(), L.aux.as<unsigned>(), m);        // sstart
@@ -366,7 +387,7 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			HIP_TRY(hipStreamSynchronize(s));
 			const bool was_first = first;
 			first = false;
-			h *= 2;
+			h = from27 ? LK_FIRST_H : 2 * h;
 			// decided once, after the first round: an input whose suffixes mostly still share their 16-prefix with somebody is a set of related
 			// genomes -- it stays that way, and the plain doubling below (dense ranks: fewer key bits, no max-scans, no compaction) is 10 - 20 %
 			// faster on it (8 x 4.6 Mbp, k = 100 / 500: 56 ms against 62 - 67 ms); the ranks so far are valid ranks for it, just not dense
@@ -400,11 +421,15 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			HIP_TRY(hipStreamSynchronize(s));
 			h *= 2;
 		}
-		k_lk_window_keys<<<nblocks(n, 256), 256, 0, s>>>(rank, c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, k, (unsigned)h,
-		                                                L.keys.as<unsigned long long>(), L.idx.as<unsigned>(), c->d_counters.as<unsigned>());
-		lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), n);
-		HIP_TRY(hipMemcpyAsync(&nv, c->d_counters.p, 4, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
+		const unsigned rbw = lk_bits((unsigned long long)maxrank + 1);   // (+ 1: the all-ones key of that width stays above every valid key)
+		k_lk_window_keys<<<nblocks(n, 256), 256, 0, s>>>(rank, c->d_sepidx.as<unsigned>(), c->nchr, (unsigned)E, (unsigned)n, k, (unsigned)h, rbw,
+		                                                L.keys.as<unsigned long long>(), L.idx.as<unsigned>());
+		lk_sort(c, L.keys.as<unsigned long long>(), L.skeys.as<unsigned long long>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), n, std::min(64u, 2 * rbw));
+		{	// valid windows = the metric's N, at the front of the sorted order (the invalid ones carry the largest key)
+			unsigned long long N = 0;
+			for (uint32_t ch = 0; ch < c->nchr; ch++) { const size_t len = c->sepidx[ch + 1] - c->sepidx[ch] - 1; if (len >= k) N += 2 * (len - k + 1); }
+			nv = (unsigned)N;
+		}
 	}
 	for (int st = 0; st < 2; st++) {
 		c->d_bif[st].ensure(elem_capacity * 4);
