@@ -226,8 +226,12 @@ def main():
     ap.add_argument("--no-cpu-full", action="store_true", help="bounded CPU sample only (~20 s) instead of the reference on the full workload (~4 - 8 min, 1 thread)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 3, 4, 5],
                     help="one of BASELINE.json's other configurations instead of the headline one: 3 = 8 strains through the `-s fine` cascade, 4 = 62 strains at k = 25, 5 = 900 Mbp of random DNA at k = 5000 (single GPU)")
+    ap.add_argument("--dry-collectives", action="store_true", help="self-test of the RCCL transport with --gpus real ranks (processes) that all open device 0 "
+                    "(tools/rccl_two_ranks_one_gpu.py): runs, or reports LOUDLY that RCCL refuses two ranks on one device; no bench line")
     ap.add_argument("--require-sharded", action="store_true", help="--gpus > 1: exit non-zero instead of falling back to replicas when the sharded (strong-scaling) configuration cannot run")
     a = ap.parse_args()
+    if a.dry_collectives:
+        os.execvp(sys.executable, [sys.executable, os.path.join(ROOT, "tools", "rccl_two_ranks_one_gpu.py"), str(max(2, a.gpus))])
     if a.config:
         if a.gpus > 1:
             raise SystemExit("--config 3 / 4 / 5 are single-GPU lines (the multi-GPU configuration of the driver's contract is the default workload)")

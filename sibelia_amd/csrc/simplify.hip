@@ -956,7 +956,6 @@ __device__ __forceinline__ int probe_endchars(const GraphView &g, const BulgeWor
 // needs the elements), more instances than the LDS list holds -- flagged PROBE_UNSERVED in live[].
 // Pass 1 takes the endChars alone (see probe_endchars); pass 2 the marks.
 #define PROBE_UNSERVED 3u
-#define PIDX_MAX_INST 256u
 __device__ unsigned long long g_rsv_ticks[8];      // SBL_TEST_FLAGS=32: summed wall-clock ticks of the reservation's phases (set-up, exclusive claims, ordering claims), entries, claims, instances
 __device__ unsigned g_idx_stats[8];          // SBL_TRACE: probes by outcome of k_probe_idx (known live, < 2 instances, clean, live, table full, not served); reservations: instances served / walked
 __device__ __forceinline__ unsigned long long idx_bits(int lo, int hi)      // bits lo .. hi-1 of a 64-bit word (clamped)
@@ -967,11 +966,12 @@ __device__ __forceinline__ unsigned long long idx_bits(int lo, int hi)      // b
 	return up & ~((1ull << lo) - 1ull);
 }
 // verdict-table insert of one mark per lane (b == BT_NONE: none); true when some id is now reached by two different endChars
-__device__ __forceinline__ bool vt_insert(VerdictTable &vt, unsigned b, unsigned bit, unsigned &distinct)
+struct VtRef { unsigned *key, *mask; unsigned bits; };      // a verdict table of 1 << bits slots in (dynamic) LDS
+__device__ __forceinline__ bool vt_insert(const VtRef &vt, unsigned b, unsigned bit, unsigned &distinct)
 {
 	bool fresh = false, found = false;
 	if (b != BT_NONE) {
-		unsigned h = (b * 2654435761u) >> 23;
+		unsigned h = (b * 2654435761u) >> (32u - vt.bits);
 		for (;;) {
 			const unsigned old = atomicCAS(&vt.key[h], BT_NONE, b);
 			if (old == BT_NONE || old == b) {
@@ -980,7 +980,7 @@ __device__ __forceinline__ bool vt_insert(VerdictTable &vt, unsigned b, unsigned
 				if (m & (m - 1u)) found = true;
 				break;
 			}
-			h = (h + 1u) & (VT_SLOTS - 1u);
+			h = (h + 1u) & ((1u << vt.bits) - 1u);
 		}
 	}
 	distinct += (unsigned)__popcll(__ballot(fresh));
@@ -990,10 +990,9 @@ __device__ __forceinline__ bool vt_insert(VerdictTable &vt, unsigned b, unsigned
 // element): up to `maxsteps` steps from element `a` on strand `dir`, 64 consecutive slots per memory round trip while the links allow it.
 // Gives the window's length (steps before the separator), the raw character at step k, the order check of every element read, and -- when
 // mks != nullptr -- the marked steps >= 1 before the own id recurs as (step, id) pairs in LDS (at most PIDX_WALK_MARKS; more: overflow).
-#define PIDX_WALK_MARKS 192u
 struct WalkedWindow { unsigned len, craw, nm; bool viol, overflow; };
 __device__ __forceinline__ WalkedWindow idx_walk_window(const GraphView &g, unsigned a, unsigned dir, unsigned maxsteps, unsigned lane, unsigned id, unsigned tid,
-                                                        unsigned *mk_step, unsigned *mk_id)
+                                                        unsigned *mk_step, unsigned *mk_id, unsigned PIDX_WALK_MARKS /* entries of the two lists */)
 {
 	WalkedWindow r; r.len = maxsteps; r.craw = 0; r.nm = 0; r.viol = false; r.overflow = false;
 	const unsigned k = g.k;
@@ -1031,9 +1030,10 @@ __device__ __forceinline__ WalkedWindow idx_walk_window(const GraphView &g, unsi
 	return r;
 }
 // returns 1 live, 0 clean, -1 the verdict table could fill up / a walked window has too many marks (k_probe decides)
-__device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, const unsigned *s_sel, const uint8_t *s_dir, unsigned *s_own, unsigned *mk_step, unsigned *mk_id,
+__device__ __forceinline__ int probe_idx(const GraphView &g, const VtRef &vt, const unsigned *s_sel, const uint8_t *s_dir, unsigned *s_own, unsigned *mk_step, unsigned *mk_id, unsigned walk_marks,
                                          unsigned n, unsigned lane, unsigned id, unsigned tid)
 {
+	const unsigned VT_FILL = 3u << (vt.bits - 2u);                       // three quarters of the slots
 	const unsigned k = g.k, D = g.D, ws = D + k + 2u, norig = g.norig;
 	const unsigned nbw = (ws + 126u) >> 6;                                 // blocks a window can touch
 	const unsigned lsh = nbw <= 4u ? 2u : nbw <= 8u ? 3u : nbw <= 16u ? 4u : 99u;
@@ -1057,7 +1057,7 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 				}
 				s_own[i] = own;
 			}
-			for (unsigned i = lane; i < VT_SLOTS; i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
+			for (unsigned i = lane; i < (1u << vt.bits); i += 64) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 			WSYNC();
 		}
 		for (unsigned i0 = 0; i0 < n; i0 += ipc) {
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 				for (unsigned long long td = todo; td; td &= td - 1ull) {
 					const unsigned src = (unsigned)__builtin_ctzll(td);
 					const unsigned wa = __shfl(a, src), wd = __shfl(dir, src);
-					const WalkedWindow ww = idx_walk_window(g, wa, wd, k + 1u, lane, id, tid, nullptr, nullptr);
+					const WalkedWindow ww = idx_walk_window(g, wa, wd, k + 1u, lane, id, tid, nullptr, nullptr, 0u);
 					if (ww.viol) viol = true;
 					if (ww.len >= k + 1u) { const char e2 = wd ? bt_comp((char)ww.craw) : (char)ww.craw; ecmask |= e2 == 'A' ? 1u : e2 == 'C' ? 2u : e2 == 'G' ? 4u : 8u; }
 				}
@@ -1114,7 +1114,7 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 			unsigned long long cm = act && !slow && bit ? mk & vm & idx_bits(1 - t0, (int)upper - t0) : 0ull;
 			unsigned total = (unsigned)__popcll(cm);
 			for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d);
-			if (distinct + total > (VT_SLOTS * 3) / 4) return -1;            // the table could fill up
+			if (distinct + total > VT_FILL) return -1;                       // the table could fill up
 			const unsigned *__restrict__ marks = g.bif[dir];
 			while (__any(cm != 0ull)) {
 				unsigned sl[4]; bool has[4]; unsigned bb[4];
@@ -1138,7 +1138,7 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 				const unsigned src = (unsigned)__builtin_ctzll(td);
 				const unsigned wa = __shfl(a, src), wd = __shfl(dir, src);
 				WSYNC();
-				const WalkedWindow ww = idx_walk_window(g, wa, wd, ws, lane, id, tid, mk_step, mk_id);
+				const WalkedWindow ww = idx_walk_window(g, wa, wd, ws, lane, id, tid, mk_step, mk_id, walk_marks);
 				if (ww.viol) viol = true;
 				if (ww.overflow) return -1;
 				WSYNC();
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 				const char e2 = wd ? bt_comp((char)ww.craw) : (char)ww.craw;
 				const unsigned b2 = e2 == 'A' ? 1u : e2 == 'C' ? 2u : e2 == 'G' ? 4u : 8u;
 				const unsigned lim2 = ww.len < D ? ww.len : D;
-				if (distinct + ww.nm > (VT_SLOTS * 3) / 4) return -1;
+				if (distinct + ww.nm > VT_FILL) return -1;
 				bool found = false;
 				for (unsigned m0 = 0; m0 < ww.nm; m0 += 64) {
 					const unsigned m = m0 + lane;
@@ -1164,30 +1164,41 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, VerdictTable &vt, c
 	if (viol) wave_stamp(g, 0, tid, 3, id, 0, tid + 1);
 	return 0;
 }
-__global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, uint8_t *live, unsigned w0)
+// Dynamic LDS (what a probing workgroup holds decides how many are resident, and the kernel is sensitive to that: + 4 KB = + 18 %): the
+// verdict table (2 x (1 << vbits) words), the instances (2 x max_inst words + max_inst bytes), the marks of a walked window (2 x walk_marks words).
+// instbuf: per window entry `istride` words -- the number of instances and (element << 1) | strand of each, for the entries found live
+// (BT_NONE in the first word otherwise): the reservation of the round starts from it instead of following the lists again.
+__global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, uint8_t *live, unsigned w0, unsigned vbits, unsigned max_inst, unsigned walk_marks,
+                                                  unsigned *__restrict__ instbuf, unsigned istride)
 {
-	__shared__ VerdictTable vt;
-	__shared__ unsigned s_sel[PIDX_MAX_INST], s_own[PIDX_MAX_INST];
-	__shared__ uint8_t s_dir[PIDX_MAX_INST];
-	__shared__ unsigned s_mkstep[PIDX_WALK_MARKS], s_mkid[PIDX_WALK_MARKS];      // marks of a walked window (idx_walk_window)
+	extern __shared__ unsigned pidx_dyn[];
+	VtRef vt; vt.key = pidx_dyn; vt.mask = pidx_dyn + (1u << vbits); vt.bits = vbits;
+	unsigned *const s_sel = vt.mask + (1u << vbits), *const s_own = s_sel + max_inst, *const s_mkstep = s_own + max_inst, *const s_mkid = s_mkstep + walk_marks;
+	uint8_t *const s_dir = reinterpret_cast<uint8_t *>(s_mkid + walk_marks);
 	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x;
 	round_stamp(g, 0);
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = id + 1;
-	if (g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
+	if (g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (instbuf) instbuf[(size_t)wi * istride] = BT_NONE; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
 	const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
-		if (off < PIDX_MAX_INST) { s_sel[off] = el; s_dir[off] = (uint8_t)s; }
+		if (off < max_inst) { s_sel[off] = el; s_dir[off] = (uint8_t)s; }
 	});
 	int r = 0;
 	if (n >= 2) {
-		if (n > PIDX_MAX_INST || n != g.lsize[0][id] + g.lsize[1][id]) r = -1;      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
-		else { WSYNC(); r = probe_idx(g, vt, s_sel, s_dir, s_own, s_mkstep, s_mkid, n, lane, id, tid); }
+		if (n > max_inst || n != g.lsize[0][id] + g.lsize[1][id]) r = -1;      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
+		else { WSYNC(); r = probe_idx(g, vt, s_sel, s_dir, s_own, s_mkstep, s_mkid, walk_marks, n, lane, id, tid); }
 	}
 	if (lane == 0) {
 		if (r < 0) live[wi] = PROBE_UNSERVED;
 		else if (r == 0) { g.need[id] = 0; g.touch[id] = 0; live[wi] = 0; }      // verdict taken now: clean until somebody touches it again
 		else { g.need[id] = 2; live[wi] = 1; }
 		if (g.test_flags & 32u) atomicAdd(&g_idx_stats[n < 2 ? 1 : r == 0 ? 2 : r == 1 ? 3 : r == -1 ? 4 : 5], 1u);
+	}
+	if (instbuf) {                                                       // the instances of a live entry for the reservation
+		unsigned *ib = instbuf + (size_t)wi * istride;
+		const bool give = r == 1 && n + 1u <= istride;
+		if (give) { WSYNC(); for (unsigned i = lane; i < n; i += 64) ib[1 + i] = (s_sel[i] << 1) | s_dir[i]; }
+		if (lane == 0) ib[0] = give ? n : BT_NONE;
 	}
 }
 
@@ -1465,16 +1476,21 @@ __device__ __forceinline__ void wave_walk_marks2(const GraphView &g, unsigned ca
 	}
 }
 
+// The seen-set remembers the KIND of a claim (bit 31: exclusive): an exclusive claim that finds the id claimed for ordering only upgrades the
+// entry and is made all the same (atomicMin + list entry; the ordering entry stays in the list beside it, harmless: an id the runner owns is
+// never "order-blocked"), so exclusive and ordering claims may come in any order -- the waves of a workgroup need no barrier between them.
+#define SEEN_EXCL 0x80000000u
 __device__ __forceinline__ void wave_claim(const GraphView &g, ClaimList &cl, unsigned st, unsigned b, unsigned lane)
 {
 	bool has = b != BT_NONE;
-	if (has) {                                                   // claim every id once per wave
+	if (has) {                                                   // claim every id once per workgroup
 		unsigned h = (b * 2654435761u) >> (32u - cl.sbits);
 		has = false;
 		for (int probe = 0; probe < 8; probe++) {
-			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
+			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b | SEEN_EXCL);
 			if (old == BT_NONE) { has = true; break; }
-			if (old == b) break;
+			if (old == (b | SEEN_EXCL)) break;
+			if (old == b) { has = atomicCAS(&cl.seen[h], b, b | SEEN_EXCL) == b; break; }      // claimed for ordering so far: upgrade (once)
 			h = (h + 1) & ((1u << cl.sbits) - 1u);
 			if (probe == 7) has = true;                          // crowded table: claim again, harmless
 		}
@@ -1499,7 +1515,7 @@ __device__ __forceinline__ void wave_claim_order(const GraphView &g, ClaimList &
 		for (int probe = 0; probe < 8; probe++) {
 			unsigned old = atomicCAS(&cl.seen[h], BT_NONE, b);
 			if (old == BT_NONE) { has = true; break; }
-			if (old == b) break;
+			if ((old & ~SEEN_EXCL) == b) break;                  // claimed already, either way
 			h = (h + 1) & ((1u << cl.sbits) - 1u);
 			if (probe == 7) has = true;
 		}
@@ -1855,7 +1871,8 @@ __device__ __forceinline__ void reserve_idx_gather(const GraphView &g, const Rsv
 // The instances of the id are dealt out to the waves of the workgroup (blockDim.x / 64 of them: two where ids have a handful of
 // instances -- 8 strains: 85.0 ms per stage against 86.1 with four and 88.8 with eight -- four where they have dozens, DeviceBackend::rsv_waves).
 #define RSV_WAVES_MAX 4u
-__global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap)
+__global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap,
+                                                                 const unsigned *__restrict__ instbuf, unsigned istride)
 {
 	const unsigned RSV_WAVES = blockDim.x >> 6;
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1876,8 +1893,12 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	unsigned *const my_list = rsv_dyn + (1u << seen_bits) + (size_t)(threadIdx.x >> 6) * list_cap;      // the marked slots of a group of instances, compacted (reserve_idx_emit)
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
-	if (wv == 0) {
-		// ListPositions by 64 lanes (see wave_list_nodes): the instances land in LDS, the waves then share them out
+	// the instances: handed over by the probe of this round (k_probe_idx: one coalesced read), or ListPositions by 64 lanes (wave_list_nodes)
+	const unsigned given = instbuf ? instbuf[(size_t)w * istride] : BT_NONE;
+	if (given != BT_NONE && given <= RESUME_SLOTS) {
+		for (unsigned i = threadIdx.x; i < given; i += 64 * RSV_WAVES) inst[i] = instbuf[(size_t)w * istride + 1 + i];
+		if (threadIdx.x == 0) ninst_s = given;
+	} else if (wv == 0) {
 		const unsigned m = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
 			if (off < RESUME_SLOTS) inst[off] = (el << 1) | s;
 		});
@@ -1899,49 +1920,37 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	const unsigned NA = (fwd + 1u + 126u) >> 6, NB = (back + 1u + 126u) >> 6;
 	const bool indexed = g.idx_reserve && NA + NB <= 16u && ninst <= RESUME_SLOTS;
 	if (indexed) {
-		for (unsigned i0 = 4u * wv; i0 < ninst; i0 += 4u * RSV_WAVES) {      // all exclusive claims first: the seen-set keeps the first kind
+		// one pass per group: the records once, exclusive then ordering claims from the same masks (the seen-set keeps the kinds apart, see
+		// wave_claim), the instances the index cannot serve through the walks -- no barrier between the waves of the workgroup
+		for (unsigned i0 = 4u * wv; i0 < ninst; i0 += 4u * RSV_WAVES) {
 			RsvIdxLane L;
 			const unsigned slowm = reserve_idx_masks(g, inst, ninst, i0, lane, NA, NB, core, fwd, back, L);
-			if (rprof && threadIdx.x == 0 && (L.ex0 | L.ex1 | L.ord) != ~0ull) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[6], n_ - rt); rt = n_; }      // (the records have arrived)
+			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[6], n_ - rt); rt = n_; }      // (the records have arrived)
 			if (!reserve_idx_emit(g, L, L.ex0, 0u, L.ex1, 1u, false, my_list, list_cap, lane, [&](unsigned b) { wave_claim(g, cl, st, b, lane); })) {
 				reserve_idx_gather(g, L, L.ex0, 0u, false, [&](unsigned b) { wave_claim(g, cl, st, b, lane); });
 				reserve_idx_gather(g, L, L.ex1, 1u, false, [&](unsigned b) { wave_claim(g, cl, st, b, lane); });
+			}
+			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[1], n_ - rt); rt = n_; }
+			// (ahead lanes: opposite strand, slots in the instance's direction; behind lanes: own strand, the other way)
+			if (!reserve_idx_emit(g, L, L.ord, L.ahead ? L.s ^ 1u : L.s, 0ull, 0u, !L.ahead, my_list, list_cap, lane, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) {
+				reserve_idx_gather(g, L, L.ahead ? L.ord : 0ull, L.s ^ 1u, false, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
+				reserve_idx_gather(g, L, L.ahead ? 0ull : L.ord, L.s, true, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
 			}
 			if (lane < 4u && i0 + lane < ninst) { served[i0 + lane] = (uint8_t)(((slowm >> lane) & 1u) ^ 1u); if (g.test_flags & 32u) atomicAdd(&g_idx_stats[6 + ((slowm >> lane) & 1u)], 1u); }
 			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
 				if (!((slowm >> q) & 1u)) continue;
 				const unsigned i = i0 + q;
-				const SepBounds sp = sep_bounds(g, sepl, inst[i] >> 1, lane);
-				unsigned nxt = BT_NONE;
-				if (!burst || !wave_core_claim_burst(g, inst[i] >> 1, inst[i] & 1u, core, lane, cl, st, sp, nxt))
-					nxt = wave_walk_claim(g, inst[i] >> 1, inst[i] & 1u, core, lane, 3u, cl, st, sp);
-				if (lane == 0) resume[i] = nxt;
-			}
-		}
-		__syncthreads();
-		RSV_T(1);
-		for (unsigned i0 = 4u * wv; i0 < ninst; i0 += 4u * RSV_WAVES) {
-			RsvIdxLane L;
-			const unsigned slowm = reserve_idx_masks(g, inst, ninst, i0, lane, NA, NB, core, fwd, back, L);
-			{
-				// (ahead lanes: opposite strand, slots in the instance's direction; behind lanes: own strand, the other way -- two emit calls
-				// share nothing but the list, so the lanes of the other kind pass empty masks)
-				const unsigned long long oa = L.ahead ? L.ord : 0ull, ob = L.ahead ? 0ull : L.ord;
-				if (!reserve_idx_emit(g, L, oa, L.s ^ 1u, 0ull, 0u, false, my_list, list_cap, lane, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); }))
-					reserve_idx_gather(g, L, oa, L.s ^ 1u, false, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
-				if (!reserve_idx_emit(g, L, ob, L.s, 0ull, 0u, true, my_list, list_cap, lane, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); }))
-					reserve_idx_gather(g, L, ob, L.s, true, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
-			}
-			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
-				if (!((slowm >> q) & 1u)) continue;
-				const unsigned i = i0 + q;
-				const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u, nxt = resume[i];
+				const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u;
 				const SepBounds sp = sep_bounds(g, sepl, e0, lane);
+				unsigned nxt = BT_NONE;
+				if (!burst || !wave_core_claim_burst(g, e0, s, core, lane, cl, st, sp, nxt))
+					nxt = wave_walk_claim(g, e0, s, core, lane, 3u, cl, st, sp);
 				if (burst && wave_flank_order_burst(g, e0, s, fwd + 1 > core ? nxt : BT_NONE, fwd + 1 > core ? fwd + 1 - core : 0u, back, lane, sp,
 				                                    [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) continue;
 				wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
 				                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sp);
 			}
+			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[2], n_ - rt); rt = n_; }
 		}
 	} else if (ninst <= RESUME_SLOTS) {
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
@@ -3456,6 +3465,11 @@ __global__ void __launch_bounds__(256) k_check_blkidx(const uint8_t *__restrict_
 		if (!ok) { atomicAdd(&out[0], 1u); atomicMin(&out[1], blk); }
 	}
 }
+// everything but the pool cursors (CTR_NE, CTR_NN) back to its start value (DeviceBackend::clear_counters)
+__global__ void __launch_bounds__(256) k_clear_counters(unsigned *__restrict__ ctr)
+{
+	for (unsigned i = CTR_ERR + threadIdx.x; i < CTR_COUNT; i += 256) ctr[i] = i == CTR_VIOL ? BT_NONE : 0u;
+}
 // the write stamps are reset with rmax / wmax at the start of every iteration attempt (DeviceBackend::reset_round_state)
 __global__ void __launch_bounds__(256) k_idx_clear_stamps(unsigned long long *__restrict__ bidx, unsigned nblk)
 {
@@ -3467,7 +3481,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
@@ -3476,6 +3490,9 @@ struct SimplifyState {
 	unsigned *h_ctr = nullptr;            // pinned, mapped: CTR_COUNT counters + the sequence number of the last post (k_select_write)
 	unsigned *d_hctr = nullptr;           // its device address
 	unsigned post_seq = 0;
+	hipEvent_t ev[8] = {};                // created once per context (DeviceBackend borrows them): commit sampling pair [2, 3]
+	std::vector<hipEvent_t> snap_ev;      // start / stop pairs around the snapshots of a stage, read at its end (no host synchronisation per snapshot)
+	unsigned char *h_init = nullptr;      // pinned staging for the small host-to-device initialisations of a stage (no synchronisation needed before the host moves on)
 };
 
 struct RestartStage {};      // thrown out of an optimistic attempt that would need a roll-back (DeviceBackend::restore)
@@ -3490,7 +3507,8 @@ struct DeviceBackend {
 	uint32_t window = 0, arena_bytes = 1u << 17, snap_arena_bytes = 1u << 17, snap_threads = 256 * 32;   // snap_threads = resident waves
 	uint32_t big_arena_bytes = 1u << 28;
 	size_t nres = 0;
-	hipEvent_t ev[8] = {};
+	hipEvent_t *ev = nullptr;                                          // SimplifyState::ev
+	unsigned snap_used = 0;                                           // snapshot event pairs recorded in this stage
 	bool timed_commit = false;
 	bool later_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr && getenv("SBL_NO_LATER_STREAM") == nullptr;
 	bool first_stream = getenv("SBL_NO_STREAM_SNAPSHOT") == nullptr;      // measurement switch: the generic window-walking snapshot for iteration 1 too
@@ -3503,6 +3521,12 @@ struct DeviceBackend {
 	// block index of the original slots (GraphView::bidx): read by the probe and the reservation, maintained by the transactions
 	bool use_index = getenv("SBL_NO_BLOCK_INDEX") == nullptr;        // measurement / test switch: every window is walked (round 4)
 	uint32_t idx_nblk = 0;
+	unsigned probe_lds_pad = getenv("SBL_PROBE_LDS_PAD") ? (unsigned)atoi(getenv("SBL_PROBE_LDS_PAD")) : 0u;      // measurement switch: occupancy sensitivity of k_probe_idx
+	// k_probe_idx's LDS by the instances an id has (set with rsv_waves): a handful -- 256-slot verdict table, 64 instances, 64 walked marks = 3.1 KB;
+	// dozens (many strains) -- 512 slots, 256 instances, 192 marks = 7.9 KB.  An entry that does not fit goes to the walking probe.
+	unsigned pidx_vbits = 9, pidx_inst = 256, pidx_marks = 192;
+	unsigned istride() const { return std::min(pidx_inst, 128u) + 1u; }      // words per window entry of the instance hand-over (k_probe_idx -> k_reserve)
+	unsigned pidx_lds() const { return ((2u << pidx_vbits) + 2u * pidx_inst + 2u * pidx_marks) * 4u + pidx_inst + probe_lds_pad; }
 	void index_build()
 	{
 		if (!use_index || !idx_nblk) return;
@@ -3516,7 +3540,6 @@ struct DeviceBackend {
 
 	DeviceBackend() = default;
 	DeviceBackend(const DeviceBackend &) = delete;
-	~DeviceBackend() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }      // also on the error paths out of sbl_simplify_run
 	uint32_t nid() { return nid_; }
 	void bind()
 	{
@@ -3701,7 +3724,8 @@ struct DeviceBackend {
 	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
-		HIP_TRY(hipEventRecord(ev[6], c->stream));
+		while (st->snap_ev.size() < 2 * (size_t)(snap_used + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); st->snap_ev.push_back(e); }
+		HIP_TRY(hipEventRecord(st->snap_ev[2 * snap_used], c->stream));
 		uint32_t plo = 0, phi = nid_;
 		const bool split = split_ro();
 		if (split) share(nid_, &plo, &phi);
@@ -3729,11 +3753,18 @@ struct DeviceBackend {
 			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
 			HIP_TRY(hipGetLastError());
 		}
-		HIP_TRY(hipEventRecord(ev[7], c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		float ms = 0;
-		HIP_TRY(hipEventElapsedTime(&ms, ev[6], ev[7]));
-		snapshot_ms += ms;
+		HIP_TRY(hipEventRecord(st->snap_ev[2 * snap_used + 1], c->stream));
+		snap_used++;                                                // (read by snapshots_collect at the end of the stage: the host does not wait here)
+	}
+	void snapshots_collect()
+	{
+		for (unsigned i = 0; i < snap_used; i++) {
+			float ms = 0;
+			HIP_TRY(hipEventSynchronize(st->snap_ev[2 * i + 1]));
+			HIP_TRY(hipEventElapsedTime(&ms, st->snap_ev[2 * i], st->snap_ev[2 * i + 1]));
+			snapshot_ms += ms;
+		}
+		snap_used = 0;
 	}
 	void reset_round_state(bool stamps_too)
 	{
@@ -3746,11 +3777,9 @@ struct DeviceBackend {
 	}
 	void clear_counters()
 	{
-		// everything but the pool cursors (CTR_NE, CTR_NN)
-		const unsigned none = BT_NONE;
-		HIP_TRY(hipMemsetAsync(st->ctr.as<unsigned>() + CTR_ERR, 0, (size_t)(CTR_COUNT - CTR_ERR) * 4, c->stream));
-		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_VIOL, &none, 4, hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
+		// everything but the pool cursors (CTR_NE, CTR_NN); one small kernel, no host synchronisation
+		k_clear_counters<<<1, 256, 0, c->stream>>>(st->ctr.as<unsigned>());
+		HIP_TRY(hipGetLastError());
 	}
 	// The selection is launched behind a round's last kernel and read with the round's counters: one host round trip per round.
 	bool sel_pending = false, sel_ready = false;
@@ -3822,6 +3851,7 @@ struct DeviceBackend {
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		begin_round();
+		solo_round = false;
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
 		if (split_ro()) {
 			// my share of the window; live[] of the other shares and the lowest order violation anybody saw come back in two small all-gathers
@@ -3829,7 +3859,7 @@ struct DeviceBackend {
 			share(nwin, &w0, &w1);
 			const uint32_t R = c->comm->n;
 			st->robuf.ensure((size_t)R * 4 + 64);
-			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0);
+			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, pidx_vbits, pidx_inst, pidx_marks, nullptr, 0u);      // (shares of a split probe: the other ranks' lists would have to travel too)
 			if (w1 > w0) k_probe<<<w1 - w0, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), w0);
 			k_probe_trail<<<1, 1, 0, c->stream>>>(st->ctr.as<unsigned>(), st->robuf.as<unsigned>(), c->comm->rank);
 			HIP_TRY(hipGetLastError());
@@ -3837,13 +3867,14 @@ struct DeviceBackend {
 			allgather_shares(st->robuf.as<char>(), R, 4);
 			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<unsigned>(), R);
 		} else {
-			if (g.idx_probe) k_probe_idx<<<nwin, 64, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u);      // the block index first; k_probe walks what it could not serve
+			if (g.idx_probe) k_probe_idx<<<nwin, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u, pidx_vbits, pidx_inst, pidx_marks, st->instbuf.as<unsigned>(), istride());      // the block index first; k_probe walks what it could not serve
 			k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), 0u);
 		}
 		probed_nwin = nwin;                                          // (the next selection counts what this probe retired)
 		HIP_TRY(hipGetLastError());
 	}
-	void mark_live(uint32_t nwin) { begin_round(); HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
+	bool solo_round = false;                                          // the current round skipped the probe (mark_live): no instance hand-over
+	void mark_live(uint32_t nwin) { begin_round(); solo_round = true; HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
@@ -3851,7 +3882,9 @@ struct DeviceBackend {
 		// dynamic LDS: the seen-set + one compaction list per wave, sized by the instances an id has (a handful: 1024 + 2 x 256 words = 6 KB;
 		// dozens: 2048 + 4 x 1024 words) -- what a reservation workgroup holds in LDS decides how many are resident
 		const unsigned seen_bits = rsv_waves <= 2 ? 10u : 11u, list_cap = rsv_waves <= 2 ? 256u : 1024u;
-		k_reserve<<<nwin, 64 * rsv_waves, ((1u << seen_bits) + rsv_waves * list_cap) * 4, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>(), seen_bits, list_cap);
+		const bool handed = g.idx_probe && !split_ro() && !solo_round;
+		k_reserve<<<nwin, 64 * rsv_waves, ((1u << seen_bits) + rsv_waves * list_cap) * 4, c->stream>>>(g, nwin, st->claims.as<unsigned>(), st->live.as<uint8_t>(), seen_bits, list_cap,
+		                                                                                               handed ? st->instbuf.as<unsigned>() : nullptr, istride());
 		HIP_TRY(hipGetLastError());
 	}
 	void commit(uint32_t nwin, uint32_t round, bool solo)
@@ -3937,12 +3970,15 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
+	if (st->h_init) (void)hipHostFree(st->h_init);
+	for (auto &e : st->ev) if (e) (void)hipEventDestroy(e);
+	for (auto &e : st->snap_ev) (void)hipEventDestroy(e);
 	delete st;
 	c->simp = nullptr;
 }
@@ -4096,19 +4132,21 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	HIP_TRY(hipGetLastError());
 
+	size_t be_maxn = 0;                                                // largest number of instances of an id (below)
 	// ---- control state
 	st->ctr.ensure(CTR_COUNT * 4);
+	st->sel.ensure((1024 + 16) * 4);
 	{
-		unsigned v[CTR_COUNT] = {0};
+		// counter block and the header of the selection scratch (k_select_*: header + one count per chunk of ids; the kernels leave the header
+		// reset) from a pinned staging buffer the context keeps: the copies are asynchronous and the host does not wait for them
+		if (!st->h_init) HIP_TRY(hipHostMalloc((void **)&st->h_init, (CTR_COUNT + 4) * 4, hipHostMallocDefault));
+		HIP_TRY(hipStreamSynchronize(s));                                  // (a previous stage's copies from the buffer have long completed; cheap when idle)
+		unsigned *v = reinterpret_cast<unsigned *>(st->h_init);
+		memset(v, 0, CTR_COUNT * 4);
 		v[CTR_NE] = (unsigned)ne0; v[CTR_NN] = (unsigned)ninst; v[CTR_VIOL] = BT_NONE;
-		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, sizeof v, hipMemcpyHostToDevice, s));
-		HIP_TRY(hipStreamSynchronize(s));
-	}
-	{	// selection scratch (k_select_*): header + one count per chunk of ids; the kernels leave the header reset
-		st->sel.ensure((1024 + 16) * 4);
-		const unsigned init[4] = { SBL_NONE, SBL_NONE, 0u, 0u };
-		HIP_TRY(hipMemcpyAsync(st->sel.p, init, sizeof init, hipMemcpyHostToDevice, s));
-		HIP_TRY(hipStreamSynchronize(s));
+		v[CTR_COUNT] = SBL_NONE; v[CTR_COUNT + 1] = SBL_NONE; v[CTR_COUNT + 2] = 0u; v[CTR_COUNT + 3] = 0u;
+		HIP_TRY(hipMemcpyAsync(st->ctr.p, v, CTR_COUNT * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(st->sel.p, v + CTR_COUNT, 16, hipMemcpyHostToDevice, s));
 	}
 	st->need.ensure(nidp); st->big.ensure(nidp); st->touch.ensure(nidp); st->own.ensure(nidp * 4);
 	HIP_TRY(hipMemsetAsync(st->need.p, 0, nidp, s));
@@ -4125,6 +4163,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		HIP_TRY(hipMemcpyAsync(&maxn, st->ctr.as<unsigned>() + CTR_BIG, 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		HIP_TRY(hipMemsetAsync(st->ctr.as<unsigned>() + CTR_BIG, 0, 4, s));
+		be_maxn = maxn;
 		size_t slots = std::min<size_t>(std::max<size_t>(16, maxn + maxn / 2), 2048);
 		size_t ws = (size_t)D + k + 2;
 		size_t need = slots * 17 * ws + 12 * (size_t)D + 8 * (size_t)k + (64u << 10) + slots * 64;
@@ -4148,6 +4187,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		st->arena.ensure((size_t)w * be.arena_bytes);
 		st->claims.ensure((size_t)w * (CLAIM_CAP + 1) * 4);
 		st->live.ensure((size_t)w + 64);
+		st->instbuf.ensure((size_t)w * 129 * 4);                          // (DeviceBackend::istride() <= 129)
 	};
 	try { if (!dense) round_buffers(window_max); }
 	catch (const SblError &) {                                        // a smaller or partly occupied GPU: the pinned window always was enough
@@ -4156,10 +4196,17 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		window_max = window;
 		round_buffers(window);
 	}
-	for (auto &e : be.ev) HIP_TRY(hipEventCreate(&e));
+	for (auto &e : st->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+	be.ev = st->ev;
 	be.optimistic = optimistic;
 	be.rsv_waves = ninst > 12 * (size_t)std::max<uint32_t>(1, be.nid_) ? 4u : 2u;      // instances per id: a handful, or dozens (many strains)
 	if (const char *e = getenv("SBL_RSV_WAVES")) be.rsv_waves = (unsigned)std::min(4, std::max(1, atoi(e)));      // measurement switch
+	if (getenv("SBL_PROBE_BIG_LDS") == nullptr) {
+		// (the 512-slot table stays: a probe it cannot hold goes to the walking kernel, whose launch then lasts as long as a full probe -- 15 such
+		// entries per round cost more than the 2 KB save; the instance and mark lists follow the input: largest instance count, mark density)
+		be.pidx_inst = (unsigned)std::min<size_t>(256, std::max<size_t>(64, (be_maxn + 15) / 16 * 16));
+		be.pidx_marks = ninst * 8 > E ? 192u : 64u;
+	}
 	be.ev_phase = c->stage_seq++;
 	be.prof = getenv("SBL_PHASES") ? 1 : 0;
 	if (be.prof) {
@@ -4225,6 +4272,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	}
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 	if (!dense && be.phase_events) be.stamps_collect();
+	be.snapshots_collect();
 	if (be.g.bidx && (be.g.test_flags & 32u)) {                          // SBL_TEST_FLAGS=32: what the block index served
 		unsigned z[8];
 		HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_idx_stats), sizeof z));
