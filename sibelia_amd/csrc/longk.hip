@@ -391,7 +391,15 @@ void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			// decided once, after the first round: an input whose suffixes mostly still share their 16-prefix with somebody is a set of related
 			// genomes -- it stays that way, and the plain doubling below (dense ranks: fewer key bits, no max-scans, no compaction) is 10 - 20 %
 			// faster on it (8 x 4.6 Mbp, k = 100 / 500: 56 ms against 62 - 67 ms); the ranks so far are valid ranks for it, just not dense
-			if (was_first && na > np / 2 && getenv("SBL_LONGK_FORCE_ACTIVE") == nullptr) { plain = true; maxrank = (unsigned)(np - 1); break; }
+			// (round 5: ... but only when ONE more doubling round is left, 4 h > k.  With more to come the active set of related genomes does
+			// collapse on the way -- two strains with 1 % SNPs each share a 216-window 1.3 % of the time -- and the later rounds cost next to
+			// nothing in this loop: k = 500 on 8 x 4.6 Mbp 50 -> 33 ms, k = 1000 56 -> 31 ms, where k = 100 is 47 ms plain against 50 ms.)
+			// From the second round on the input has shown what it is: where more than 85 % of the suffixes are still active at h = 54 (the state a
+			// cascade's earlier stages leave behind: the strains have been made alike over long stretches) the set is not going to collapse, and
+			// the plain rounds are the cheaper ones again (config 3's k = 500 stage: 46 ms plain, 69 ms in this loop).
+			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] long k: h = %zu, %u of %zu suffixes still active\n", h, na, np);
+			const bool sticky = (double)na > (was_first ? 0.98 : 0.85) * (double)np;      // (after ONE round only the unmistakable case: every suffix shares its 27-prefix)
+			if (na > np / 2 && (4 * h > k || sticky) && getenv("SBL_LONGK_FORCE_ACTIVE") == nullptr) { plain = true; maxrank = (unsigned)(np - 1); break; }
 		}
 	}
 	if (discard && !plain) {

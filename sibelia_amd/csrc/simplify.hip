@@ -376,6 +376,9 @@ __device__ __forceinline__ void wave_scan_all(const GraphView &g, const BulgeWor
                                               unsigned first = 0, unsigned stride = 1)
 {
 	const unsigned n = w.n, ws = w.ws;
+	// (Round 5 tried "light" bursts here for windows in pristine blocks without a write stamp above the runner -- no link and no stamp loads,
+	// two of the four per element, decided from the block records of GraphView::bidx: k_commit + 0.6 ms.  The record look-up is a dependent
+	// round trip in front of every batch of bursts; as in round 3, a load only pays when it disappears WITHOUT bookkeeping in its place.)
 	for (unsigned i = first; i < n; i += SCAN_BATCH * stride) {
 		unsigned sel[SCAN_BATCH], dir[SCAN_BATCH];
 		ScanBurst b[SCAN_BATCH];
@@ -1937,6 +1940,7 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 				reserve_idx_gather(g, L, L.ahead ? 0ull : L.ord, L.s, true, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
 			}
 			if (lane < 4u && i0 + lane < ninst) { served[i0 + lane] = (uint8_t)(((slowm >> lane) & 1u) ^ 1u); if (g.test_flags & 32u) atomicAdd(&g_idx_stats[6 + ((slowm >> lane) & 1u)], 1u); }
+			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[2], n_ - rt); rt = n_; }
 			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
 				if (!((slowm >> q) & 1u)) continue;
 				const unsigned i = i0 + q;
@@ -1950,7 +1954,7 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 				wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
 				                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sp);
 			}
-			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[2], n_ - rt); rt = n_; }
+			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[7], n_ - rt); rt = n_; }
 		}
 	} else if (ninst <= RESUME_SLOTS) {
 		for (unsigned i = wv; i < ninst; i += RSV_WAVES) {            // all exclusive claims first: the seen-set keeps the first kind
@@ -4281,8 +4285,8 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_idx_stats), z, sizeof z));
 		unsigned long long rz[8];
 		HIP_TRY(hipMemcpyFromSymbol(rz, HIP_SYMBOL(g_rsv_ticks), sizeof rz));
-		if (rz[3]) fprintf(stderr, "[sbl] reservations: %llu entries, %.1f claims and %.1f instances each; per entry (10 ns ticks of the device wall clock): set-up %.0f, records %.0f, exclusive claims %.0f, ordering claims %.0f\n",
-		                   rz[3], (double)rz[4] / rz[3], (double)rz[5] / rz[3], (double)rz[0] / rz[3], (double)rz[6] / rz[3], (double)rz[1] / rz[3], (double)rz[2] / rz[3]);
+		if (rz[3]) fprintf(stderr, "[sbl] reservations: %llu entries, %.1f claims and %.1f instances each; per entry (10 ns ticks of the device wall clock): set-up %.0f, records %.0f, exclusive claims %.0f, ordering claims + wait for the other waves %.0f, walked instances %.0f\n",
+		                   rz[3], (double)rz[4] / rz[3], (double)rz[5] / rz[3], (double)rz[0] / rz[3], (double)rz[6] / rz[3], (double)rz[1] / rz[3], (double)rz[2] / rz[3], (double)rz[7] / rz[3]);
 		memset(rz, 0, sizeof rz);
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rsv_ticks), rz, sizeof rz));
 	}

@@ -55,12 +55,13 @@ def main():
                       "hbm_bytes_per_launch_est": (2 * v / n + ((wv / wn) if wn else 0.0)) * 1024}
     sys.path.insert(0, ROOT)
     import bench
+    bench_args = os.environ.get("PROFILE_BENCH_ARGS", "")          # e.g. "--config 3": the summaries of another bench configuration (no pmc_latest.json then)
     doc = {"round": tag, "source_digest": bench.W_source_digest(),
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-           "workload": "default bench workload (8 strains x 4.6 Mbp, k=25, D=150, 4 iterations)",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py %s--steps 1 --warmup 0 --no-cpu-baseline" % (bench_args + " " if bench_args else ""),
+           "workload": os.environ.get("PROFILE_WORKLOAD", "default bench workload (8 strains x 4.6 Mbp, k=25, D=150, 4 iterations)"),
            "units": "counter unit KB; hbm_bytes_per_launch_est = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md HBM section)",
            "kernels": kernels}
-    for name in (tag + "_pmc_summary.json", "pmc_latest.json"):
+    for name in ((tag + "_pmc_summary.json",) if bench_args else (tag + "_pmc_summary.json", "pmc_latest.json")):
         json.dump(doc, open(os.path.join(out, name), "w"), indent=1)
     if len(sys.argv) > 5:
         shutil.copy(sys.argv[5], os.path.join(out, tag + "_bench_default.json"))
