@@ -1171,18 +1171,20 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, const VtRef &vt, co
 // verdict table (2 x (1 << vbits) words), the instances (2 x max_inst words + max_inst bytes), the marks of a walked window (2 x walk_marks words).
 // instbuf: per window entry `istride` words -- the number of instances and (element << 1) | strand of each, for the entries found live
 // (BT_NONE in the first word otherwise): the reservation of the round starts from it instead of following the lists again.
+// snapshot != 0: the entries are the touched ids of an incremental snapshot (DeviceBackend::snapshot_idx) -- same verdict, but the write
+// stamps on the device are the PREVIOUS iteration's (they are reset after the snapshot): no order check, nothing counts as "above".
 __global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, uint8_t *live, unsigned w0, unsigned vbits, unsigned max_inst, unsigned walk_marks,
-                                                  unsigned *__restrict__ instbuf, unsigned istride)
+                                                  unsigned *__restrict__ instbuf, unsigned istride, int snapshot)
 {
 	extern __shared__ unsigned pidx_dyn[];
 	VtRef vt; vt.key = pidx_dyn; vt.mask = pidx_dyn + (1u << vbits); vt.bits = vbits;
 	unsigned *const s_sel = vt.mask + (1u << vbits), *const s_own = s_sel + max_inst, *const s_mkstep = s_own + max_inst, *const s_mkid = s_mkstep + walk_marks;
 	uint8_t *const s_dir = reinterpret_cast<uint8_t *>(s_mkid + walk_marks);
 	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x;
-	round_stamp(g, 0);
+	if (!snapshot) round_stamp(g, 0);
 	if (wi >= nwin) return;
-	const unsigned id = g.win[wi], tid = id + 1;
-	if (g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (instbuf) instbuf[(size_t)wi * istride] = BT_NONE; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
+	const unsigned id = g.win[wi], tid = snapshot ? 0xFFFFFFFEu : id + 1;
+	if (!snapshot && g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (instbuf) instbuf[(size_t)wi * istride] = BT_NONE; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
 	const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
 		if (off < max_inst) { s_sel[off] = el; s_dir[off] = (uint8_t)s; }
 	});
@@ -1206,7 +1208,7 @@ __global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, ui
 }
 
 static_assert(PROBE_WAVES == 1u, "k_probe synchronises its lanes with WSYNC(): one wave per workgroup");
-__global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0)
+__global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0, int snapshot = 0)
 {
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
@@ -1214,12 +1216,12 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	__shared__ int ok;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[2048];
 	const unsigned wi = blockIdx.x + w0, lane = threadIdx.x & 63u;
-	if (!g.idx_probe) round_stamp(g, 0);                               // (behind k_probe_idx the probe phase started with that kernel)
+	if (!g.idx_probe && !snapshot) round_stamp(g, 0);                  // (behind k_probe_idx the probe phase started with that kernel)
 	if (wi >= nwin) return;
-	if (g.idx_probe && live[wi] != PROBE_UNSERVED) return;             // decided by k_probe_idx
-	const unsigned id = g.win[wi], tid = id + 1;
-	if (g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
-	if (threadIdx.x == 0) { t.init(g, id, wi, 3, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }
+	if ((g.idx_probe || snapshot) && live[wi] != PROBE_UNSERVED) return;      // decided by k_probe_idx
+	const unsigned id = g.win[wi], tid = snapshot ? 0xFFFFFFFEu : id + 1;
+	if (!snapshot && g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
+	if (threadIdx.x == 0) { t.init(g, id, wi, snapshot ? 0u : 3u, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }      // (snapshot: the stamps are the previous iteration's -- no order check)
 	WSYNC();
 	wave_setup(g, t, w, true, lane, ok);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
@@ -1240,6 +1242,7 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 		if (t.err) has = true;                                        // undecidable here: the commit path sorts it out
 		if (!has) { g.need[id] = 0; g.touch[id] = 0; }             // verdict taken now: clean until somebody touches it again (counted by the next selection, k_select_count)
 		else if (!t.err) g.need[id] = 2;
+		else if (snapshot) g.need[id] = 1;                        // (a snapshot starts from need = 0: an undecidable id must be pending)
 		live[wi] = has ? (t.err ? 2 : 1) : 0;                      // (2: live because undecidable here -- need stays 1; k_apply_probe on the other GPUs)
 	}
 }
@@ -3308,6 +3311,19 @@ __global__ void __launch_bounds__(256) k_count_touched(const uint8_t *__restrict
 	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// ... and their list (any order: the snapshot takes the same verdict of each), appended a wave at a time
+__global__ void __launch_bounds__(256) k_touched_list(const uint8_t *__restrict__ touch, unsigned nid, unsigned *__restrict__ list, unsigned *__restrict__ count)
+{
+	const unsigned id = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+	const bool t = id < nid && touch[id] != 0;
+	const unsigned long long m = __ballot(t);
+	if (!m) return;
+	unsigned base = 0;
+	if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(count, (unsigned)__popcll(m));
+	base = __shfl(base, (unsigned)__builtin_ctzll(m));
+	if (t) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = id;
+}
+
 // ------------------------------------------------------------------------------------------- copy-back (T3) kernels
 // The list is a chain of "segments" = maximal runs of consecutive slots linked consecutively.  Heads are
 // found with a flag pass, segments are ranked by pointer jumping, elements scatter to rank + offset.
@@ -3485,7 +3501,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf, snap_list, snap_live;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
@@ -3725,6 +3741,29 @@ struct DeviceBackend {
 		catch (...) { cm->abort_peers(); throw; }
 		ro_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	}
+	uint32_t snap_slice = 0;                                          // entries per launch of the walking probe's arena (= the round buffers' window_max)
+	void snapshot_idx()
+	{
+		unsigned *cnt = st->ctr.as<unsigned>() + CTR_DETAIL + 8, n = 0;
+		st->snap_list.ensure((size_t)nid_ * 4 + 64); st->snap_live.ensure((size_t)nid_ + 64);
+		HIP_TRY(hipMemsetAsync(cnt, 0, 4, c->stream));
+		k_touched_list<<<(nid_ + 255) / 256, 256, 0, c->stream>>>(st->touch.as<uint8_t>(), nid_, st->snap_list.as<unsigned>(), cnt);
+		HIP_TRY(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemsetAsync(st->need.p, 0, (size_t)nid_ + 1, c->stream));      // untouched ids: still clean
+		HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));     // every verdict is taken now
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		const uint32_t slice = std::max<uint32_t>(1, snap_slice);
+		for (uint32_t off = 0; off < n; off += slice) {
+			const uint32_t m = std::min<uint32_t>(slice, n - off);
+			GraphView gs = g;
+			gs.win = st->snap_list.as<unsigned>() + off;
+			gs.tstamp = nullptr;
+			uint8_t *lv = st->snap_live.as<uint8_t>() + off;
+			k_probe_idx<<<m, 64, pidx_lds(), c->stream>>>(gs, m, lv, 0u, pidx_vbits, pidx_inst, pidx_marks, nullptr, 0u, 1);
+			k_probe<<<m, 64 * PROBE_WAVES, 0, c->stream>>>(gs, m, st->arena.as<uint8_t>(), arena_bytes, lv, 0u, 1);
+		}
+		HIP_TRY(hipGetLastError());
+	}
 	void snapshot_all(bool incremental)
 	{
 		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
@@ -3739,6 +3778,10 @@ struct DeviceBackend {
 			for (int t = 0; t < 2; t++) { ms.elem[t] = c->d_melem[t].as<unsigned>(); ms.id[t] = c->d_mid[t].as<unsigned>(); ms.aux[t] = st->maux[t].as<unsigned>(); ms.n[t] = c->nmarks[t]; }
 			HIP_TRY(hipMemsetAsync(st->touch.p, 0, (size_t)nid_ + 1, c->stream));
 			k_snapshot_first<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), plo, phi);
+		} else if (incremental && g.idx_probe && !split && getenv("SBL_NO_IDX_SNAPSHOT") == nullptr) {
+			// iterations 2 ..: the touched ids through the probe of the rounds (k_probe_idx over the block index, the walking probe for what it
+			// cannot serve) -- the same verdict the stream takes, without linearising the marks first (round 5)
+			snapshot_idx();
 		} else if (incremental && later_stream && !few_touched()) {
 			// iterations 2 ..: the same stream over the marks of the current graph in list order
 			st->nmark.ensure((size_t)cap_n * 4);
@@ -3863,7 +3906,7 @@ struct DeviceBackend {
 			share(nwin, &w0, &w1);
 			const uint32_t R = c->comm->n;
 			st->robuf.ensure((size_t)R * 4 + 64);
-			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, pidx_vbits, pidx_inst, pidx_marks, nullptr, 0u);      // (shares of a split probe: the other ranks' lists would have to travel too)
+			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, pidx_vbits, pidx_inst, pidx_marks, nullptr, 0u, 0);      // (shares of a split probe: the other ranks' lists would have to travel too)
 			if (w1 > w0) k_probe<<<w1 - w0, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), w0);
 			k_probe_trail<<<1, 1, 0, c->stream>>>(st->ctr.as<unsigned>(), st->robuf.as<unsigned>(), c->comm->rank);
 			HIP_TRY(hipGetLastError());
@@ -3871,7 +3914,7 @@ struct DeviceBackend {
 			allgather_shares(st->robuf.as<char>(), R, 4);
 			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<unsigned>(), R);
 		} else {
-			if (g.idx_probe) k_probe_idx<<<nwin, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u, pidx_vbits, pidx_inst, pidx_marks, st->instbuf.as<unsigned>(), istride());      // the block index first; k_probe walks what it could not serve
+			if (g.idx_probe) k_probe_idx<<<nwin, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u, pidx_vbits, pidx_inst, pidx_marks, st->instbuf.as<unsigned>(), istride(), 0);      // the block index first; k_probe walks what it could not serve
 			k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), 0u);
 		}
 		probed_nwin = nwin;                                          // (the next selection counts what this probe retired)
@@ -3974,7 +4017,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->snap_list, &st->snap_live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -4193,11 +4236,13 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		st->live.ensure((size_t)w + 64);
 		st->instbuf.ensure((size_t)w * 129 * 4);                          // (DeviceBackend::istride() <= 129)
 	};
+	be.snap_slice = window_max;
 	try { if (!dense) round_buffers(window_max); }
 	catch (const SblError &) {                                        // a smaller or partly occupied GPU: the pinned window always was enough
 		if (window_max == window) throw;
 		(void)hipGetLastError();
 		window_max = window;
+		be.snap_slice = window;
 		round_buffers(window);
 	}
 	for (auto &e : st->ev) if (!e) HIP_TRY(hipEventCreate(&e));
