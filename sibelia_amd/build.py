@@ -1,7 +1,8 @@
 """Builds libsibelia_amd.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
 
 One object per translation unit (sibelia_amd/lib/obj/*.o, compiled in parallel, recompiled when the source or any header is newer),
-then one link: touching longk.hip does not recompile simplify.hip's 160 KB of round kernels."""
+then one link: touching longk.hip does not recompile the round kernels, and the four kernel units of the simplification
+(graphbuild / snapshot / rounds / commit .hip, split out of simplify.hip in round 5) compile side by side."""
 from __future__ import annotations
 
 import os
@@ -13,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libsibelia_amd.so")
-SOURCES = ["sbl_api.hip", "simplify.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
+SOURCES = ["sbl_api.hip", "simplify.hip", "graphbuild.hip", "snapshot.hip", "rounds.hip", "commit.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
 HEADERS = ["sbl_common.h", "sbl_ctx.h", "sbl_comm.h", "kmer_kernels.h", "kmer_bucket_kernels.h", "bulge_txn.h", "simplify_steps.h", "simplify_driver.h",
+           "simplify_device.h", "simplify_walks.h", "simplify_kernels.h",
            os.path.join("..", "..", "include", "sibelia_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -54,7 +56,7 @@ def build(force: bool = False) -> str:
         def cc(s):
             subprocess.run(["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", _obj(s)], check=True)
 
-        with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as ex:
             list(ex.map(cc, todo))
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in _sources()], check=True)
     return LIB

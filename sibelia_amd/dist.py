@@ -1,6 +1,6 @@
 """Multi-GPU job layout (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm).
 
-Two ways to use N GPUs (DESIGN.md §5):
+Two ways to use N GPUs (DESIGN.md §6):
   * replicas (bench.py default for N > 1): bulge removal is globally ordered and is >90 % of a stage, so
     throughput scales by giving every GPU its own input; the only collectives are the barrier around the
     timed region and two scalar all-reduces (max time, total units).
