@@ -705,9 +705,12 @@ __device__ __forceinline__ unsigned reserve_idx_masks(const GraphView &g, const 
 	for (int d = 1; d < 16; d <<= 1) { const unsigned va = __shfl_xor(fa, d), vb = __shfl_xor(fb, d); fa = va < fa ? va : fa; fb = vb < fb ? vb : fb; }
 	const unsigned stop = ahead ? fa : fb;                                  // the walk ends BEFORE this step (first separator)
 	const unsigned last = stop < hi ? stop : hi - 1u;                      // last step whose block matters (the separator's own block included)
-	bool slow = fresh || (inr && (unsigned)(r1.y >> 32) != 0u && t0 <= (int)last && t0 + 63 >= (int)lo);
+	// the walk ahead and the walk behind are served separately: a block that is no longer pristine on one side sends only that side to the walks
+	const bool dirty = inr && (unsigned)(r1.y >> 32) != 0u && t0 <= (int)last && t0 + 63 >= (int)lo;
+	bool sa = fresh || (dirty && ahead), sb2 = fresh || (dirty && behind);
 #pragma unroll
-	for (int d = 1; d < 16; d <<= 1) slow |= __shfl_xor((int)slow, d) != 0;
+	for (int d = 1; d < 16; d <<= 1) { sa |= __shfl_xor((int)sa, d) != 0; sb2 |= __shfl_xor((int)sb2, d) != 0; }
+	const bool slow = ahead ? sa : sb2;
 	const unsigned end = stop < hi ? stop : hi;
 	L.t0 = t0; L.a = a; L.s = s; L.ahead = ahead;
 	L.ex0 = L.ex1 = L.ord = 0ull;
@@ -718,8 +721,11 @@ __device__ __forceinline__ unsigned reserve_idx_masks(const GraphView &g, const 
 			L.ex0 = m0 & cm; L.ex1 = m1 & cm; L.ord = (s ? m0 : m1) & om;      // the core: both strands; beyond it: the opposite strand
 		} else L.ord = (s ? m1 : m0) & idx_bits(1 - t0, (int)end - t0);      // behind: the own strand
 	}
-	const unsigned long long sb = __ballot(act && slow && j == 0u);
-	return (unsigned)((sb & 1ull) | ((sb >> 15) & 2ull) | ((sb >> 30) & 4ull) | ((sb >> 45) & 8ull));
+	// bits 0 - 3: the walk AHEAD (core + opposite-strand flank) of instance i0 + x must be walked; bits 4 - 7: the walk BEHIND
+	const unsigned long long ba = __ballot(act && sa && j == 0u), bb = __ballot(act && sb2 && j == 0u);
+	const unsigned ma = (unsigned)((ba & 1ull) | ((ba >> 15) & 2ull) | ((ba >> 30) & 4ull) | ((ba >> 45) & 8ull));
+	const unsigned mb = (unsigned)((bb & 1ull) | ((bb >> 15) & 2ull) | ((bb >> 30) & 4ull) | ((bb >> 45) & 8ull));
+	return ma | (mb << 4);
 }
 // The marked slots under the set bits of the lanes' masks, COMPACTED through a per-wave LDS list and gathered 64 at a time: the sixteen
 // lanes of an instance hold their marks very unevenly (the core is four of eleven blocks), and a claim step (LDS set, atomicMin, list
@@ -847,20 +853,23 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 				reserve_idx_gather(g, L, L.ahead ? L.ord : 0ull, L.s ^ 1u, false, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
 				reserve_idx_gather(g, L, L.ahead ? 0ull : L.ord, L.s, true, [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); });
 			}
-			if (lane < 4u && i0 + lane < ninst) { served[i0 + lane] = (uint8_t)(((slowm >> lane) & 1u) ^ 1u); if (g.test_flags & 32u) atomicAdd(&g_idx_stats[6 + ((slowm >> lane) & 1u)], 1u); }
+			if (lane < 4u && i0 + lane < ninst) { served[i0 + lane] = (uint8_t)((((slowm | (slowm >> 4)) >> lane) & 1u) ^ 1u); if (g.test_flags & 32u) atomicAdd(&g_idx_stats[6 + (((slowm | (slowm >> 4)) >> lane) & 1u)], 1u); }
 			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[2], n_ - rt); rt = n_; }
 			for (unsigned q = 0; q < 4u && i0 + q < ninst; q++) {
-				if (!((slowm >> q) & 1u)) continue;
+				const bool wa = (slowm >> q) & 1u, wb = (slowm >> (4u + q)) & 1u;      // which of the instance's two walks the index could not serve
+				if (!wa && !wb) continue;
 				const unsigned i = i0 + q;
 				const unsigned e0 = inst[i] >> 1, s = inst[i] & 1u;
 				const SepBounds sp = sep_bounds(g, sepl, e0, lane);
 				unsigned nxt = BT_NONE;
-				if (!burst || !wave_core_claim_burst(g, e0, s, core, lane, cl, st, sp, nxt))
-					nxt = wave_walk_claim(g, e0, s, core, lane, 3u, cl, st, sp);
-				if (burst && wave_flank_order_burst(g, e0, s, fwd + 1 > core ? nxt : BT_NONE, fwd + 1 > core ? fwd + 1 - core : 0u, back, lane, sp,
-				                                    [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) continue;
-				wave_walk_marks2(g, fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
-				                 s ? g.nx[e0] : g.pv[e0], s ^ 1u, back, 1u << s, lane, order, sp);
+				if (wa) {
+					if (!burst || !wave_core_claim_burst(g, e0, s, core, lane, cl, st, sp, nxt))
+						nxt = wave_walk_claim(g, e0, s, core, lane, 3u, cl, st, sp);
+				}
+				if (wa && wb && burst && wave_flank_order_burst(g, e0, s, fwd + 1 > core ? nxt : BT_NONE, fwd + 1 > core ? fwd + 1 - core : 0u, back, lane, sp,
+				                                                [&](unsigned b) { wave_claim_order(g, cl, st, id, b, lane); })) continue;
+				wave_walk_marks2(g, wa && fwd + 1 > core ? nxt : BT_NONE, s, fwd + 1 - core, 1u << (s ^ 1u),
+				                 wb ? (s ? g.nx[e0] : g.pv[e0]) : BT_NONE, s ^ 1u, back, 1u << s, lane, order, sp);
 			}
 			if (rprof && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_rsv_ticks[7], n_ - rt); rt = n_; }
 		}
