@@ -785,6 +785,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	if (be.idx_nblk) st->bidx.ensure((size_t)be.idx_nblk * BT_IDX_WORDS * 8);
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	if (((D + k + 2u + 126u) >> 6) > 16u) be.g.idx_probe = 0;           // windows of more than 16 blocks: k_probe_idx could serve nobody (every entry walks, as before round 5)
 	be.g.test_flags = getenv("SBL_TEST_FLAGS") ? (unsigned)atoi(getenv("SBL_TEST_FLAGS")) : 0u;
 	be.g.lazy_rescan = getenv("SBL_EAGER_RESCAN") ? 0u : 1u;            // measurement switch: dirty windows rescanned right after every collapse (round 3)
 	be.g.collapse_g = getenv("SBL_OLD_COLLAPSE") ? 0u : 1u;            // measurement switch: the round-3 collapse (a chain of dependent round trips) instead of the gather-first one
