@@ -476,6 +476,9 @@ struct BulgeWork {
 	// mq_* with all lanes -- one look-up per lane, the same stamps -- into mres[], set mready, call again).
 	uint32_t nold;               // SBL_PHASES=1: collapses of this transaction that took the round-3 form
 	bool mscan, mready;
+	// FillVisit by the caller's 64 lanes (commit.hip: wave_fill_visit) instead of one thread's shell sort: with wfill set bt_rb_run returns 5
+	// (fill_i = the instance) where it would call bt_fill_visit; the caller clears need_fill
+	bool wfill; uint32_t fill_i;
 	uint32_t mscan_min;          // ... with more than this many marks inside the two branches together
 	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
@@ -526,7 +529,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
 	w.use_stale = false; w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0; w.wfill = false; w.fill_i = 0;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
@@ -1084,7 +1087,7 @@ __host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
 // 4 (mscan only): see BulgeWork::mscan (bt_rb_mults is the one-thread form).
 // returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
 // the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards,
-// 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search).
+// 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search), 5 (wfill only): see BulgeWork::wfill.
 // every array the decision loops (bt_rb_run) touch is in LDS: the caller may then use bt_rb_run<true>
 __host__ __device__ __forceinline__ bool bt_scratch_in_lds(const BulgeWork &w)
 {
@@ -1124,9 +1127,10 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 					if ((w.stale[kmerJ >> 6] >> (kmerJ & 63u)) & 1ull) w.req[nr++] = kmerJ;
 					if (nr) { w.nreq = nr; return 2; }
 				}
-				w.idJ++; w.jready = false;
 				// FillVisit(I) (bulgeremoval.cpp:352) has no side effects: it is evaluated when the first J needs it, and again
 				// after a collapse that rewrote I's own window
+				if (w.need_fill && w.wfill) { w.fill_i = kmerI; w.jready = true; return 5; }      // (this J again once the caller has filled `visit`)
+				w.idJ++; w.jready = false;
 				BT_PROF_ADD(t, 23);
 				if (w.need_fill) { bt_fill_visit<L>(t, w, kmerI); w.need_fill = false; if (t.err) return 0; }
 				BT_PROF_ADD(t, 20);

@@ -650,6 +650,34 @@ __device__ __attribute__((noinline)) void wave_mults(const GraphView &g, Txn &t,
 	WSYNC();
 }
 
+// ---- the caller side of BulgeWork::wfill: FillVisit (bulgeremoval.cpp:122-146, bt_fill_visit) with 64 lanes.  One thread's shell sort of
+// the ~15 (id, distance) pairs of a window is ~100 dependent LDS round trips (26 k cycles per call, once per I and again after every
+// collapse that rewrote I's window); here every lane holds one pair and counts the smaller ones.
+__device__ __forceinline__ void wave_fill_visit(Txn &t, BulgeWork &w, unsigned D, unsigned lane)
+{
+	const unsigned i = w.fill_i, nm = ldx(&w.wmn[i]);
+	if (nm > 64u) {                                                        // (longer lists: the one-thread form)
+		if (lane == 0) { if (bt_scratch_in_lds(w)) bt_fill_visit<true>(t, w, i); else bt_fill_visit<false>(t, w, i); w.need_fill = false; }
+		WSYNC();
+		return;
+	}
+	const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
+	unsigned long long *visit = reinterpret_cast<unsigned long long *>(w.visit);
+	const unsigned wl = ldx(&w.wlen[i]), start = ldx(&w.wst[i]), lim = wl < D ? wl : D;
+	const unsigned long long v = lane < nm ? ldx(&mk[lane]) : ~0ull;
+	const unsigned step = (unsigned)(v >> 32), b = (unsigned)v;
+	const unsigned long long ms = __ballot(lane >= nm || step >= lim || b == start);
+	unsigned n = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+	bool over = false;
+	if (n > w.visit_cap) { n = w.visit_cap; over = true; }
+	const unsigned long long key = lane < n ? ((unsigned long long)b << 32) | step : ~0ull;
+	unsigned rank = 0;
+	for (unsigned y = 0; y < n; y++) rank += __shfl(key, y) < key ? 1u : 0u;      // (the pairs are distinct: every step occurs once)
+	if (lane < n) stx(&visit[rank], key);
+	if (lane == 0) { w.nvisit = n; w.need_fill = false; if (over) t.err |= BT_ERR_SCRATCH; }
+	WSYNC();
+}
+
 // ---- marks-only window scan, one LANE per instance (64 instances in flight): what AnyBulges needs of a window -- mark at step 0,
 // character at step k, length, the marked steps -- and nothing else (bt_scan_instance with lite set, minus the element cache).
 // For ids with many instances: a lane walks its window with dependent loads, but 64 windows advance together, where the
@@ -968,7 +996,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
 		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = (w.n > 24u || (g.test_flags & 16u)) && g.jscan_rounds; if (g.test_flags & 16u) w.mscan_min = (g.test_flags >> 8) & 15u;
-			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
+			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; w.wfill = !(g.test_flags & 64u); }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
 		while (flag) {
@@ -978,6 +1006,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			if (!flag) break;
 			if (flag == 3) { wave_next_j(g, w, lane); continue; }       // large group: the search for the next J, 256 members per step
 			if (flag == 4) { wave_mults(g, t, w, lane); continue; }     // branches with many bifurcations inside: their multiplicities, one look-up per lane
+			if (flag == 5) { wave_fill_visit(t, w, g.D, lane); if (t.err) break; continue; }      // FillVisit(I), one (id, distance) pair per lane
 			if (flag == 2) {                                             // the loops need these windows as of now
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
@@ -1122,8 +1151,9 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	}
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof_every)
 {
+	const int prof = prof_every && blockIdx.x % (unsigned)prof_every == 0u;      // SBL_PHASES=N: every Nth entry is timed (all of them distort what they measure)
 	__shared__ Txn t;
 	__shared__ BulgeWork w;
 	__shared__ int flag;

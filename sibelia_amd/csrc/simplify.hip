@@ -778,7 +778,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		be.pidx_marks = ninst * 8 > E ? 192u : 64u;
 	}
 	be.ev_phase = c->stage_seq++;
-	be.prof = getenv("SBL_PHASES") ? 1 : 0;
+	be.prof = getenv("SBL_PHASES") ? (atoi(getenv("SBL_PHASES")) > 0 ? atoi(getenv("SBL_PHASES")) : 1) : 0;
 	if (be.prof) sbl_commit_prof_reset();
 	if (dense) be.use_index = false;                                   // (the one-launch path reads no index: nothing to maintain)
 	be.idx_nblk = be.use_index ? (uint32_t)((E + 63) / 64) : 0u;
