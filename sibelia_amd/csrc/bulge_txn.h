@@ -1078,7 +1078,7 @@ __host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
 	const uint32_t ge = w.ab.grp_off[w.gi + 1], kmerI = w.ab.grp_mem[w.idI];
 	while (w.idJ < ge) {
 		const uint32_t kmerJ = w.ab.grp_mem[w.idJ];
-		if (bt_pvalid(t, w.start[kmerJ]) && w.endc[kmerI] != w.endc[kmerJ]) break;
+		if (w.endc[kmerI] != w.endc[kmerJ] && bt_pvalid(t, w.start[kmerJ])) break;
 		w.idJ++;
 	}
 	w.jready = true;
@@ -1115,7 +1115,7 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 			while (w.idJ < ge) {
 				if (w.jscan && !w.jready && ge - w.idJ > 8) return 3;  // the caller finds the next candidate J (see jscan); short tails are walked here
 				const uint32_t kmerJ = grp_mem[w.idJ];
-				if (!bt_pvalid(t, start[kmerJ]) || endc[kmerI] == endc[kmerJ]) { w.idJ++; w.jready = false; continue; }
+				if (endc[kmerI] == endc[kmerJ] || !bt_pvalid(t, start[kmerJ])) { w.idJ++; w.jready = false; continue; }      // (the endChars first: an LDS byte against a look at the node in memory; neither has a side effect)
 				if (w.lazy) {                                        // everything below reads the windows of I and J: as of NOW, like the reference's walks
 					uint32_t nr = 0;
 					if (w.wep[kmerI] != w.epoch) w.req[nr++] = kmerI;

@@ -972,13 +972,25 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		}
 	}
 	WSYNC();
-	if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); }
-	if (!flag) return;
+	// (counted at the END of the transaction: every owner of a launch starts at the same moment, and two atomics on two addresses by ~3 000
+	// waves at once stood in front of the first barrier of each of them -- the wait for the acknowledgement, not the atomic, is what costs)
+	if (!flag) { if (lane == 0) { atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u); } return; }
 	// ---- writer pass: reads and writes are published for order validation
 	if (lane == 0) { t.init(g, id, wi, 2, mine, arena_bytes); t.chain = stampv == BT_NONE; t.defer_push = true; t.ext_stamps = true; t.fscr = fast; t.fscr_cap = fast_bytes; w.ret = 0;
 	                 t.tc_cap = 1024; t.tc_list = (uint32_t *)t.alloc(t.tc_cap * 4); if (!t.tc_list) t.tc_cap = 0; t.err = 0; t.defer_cleanup = true; t.prof = prof != 0; }
 	WSYNC();
-	wave_setup(g, t, w, false, lane, flag);
+	PH_ADD(7);
+	{	// (wave_setup, with a timer between its two halves)
+		const unsigned h0 = g.head[0][t.id], h1 = g.head[1][t.id];          // in flight while lane 0 lays the scratch out
+		if (lane == 0) flag = bt_setup(t, w, false, false) && !t.err ? 1 : 0;
+		WSYNC();
+		PH_ADD(19);
+		if (flag) {
+			const unsigned m = wave_list_positions(g, h0, h1, w, lane);
+			if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; flag = 0; }      // cannot happen on a consistent graph
+			WSYNC();
+		}
+	}
 	PH_ADD(0);
 	if (flag) {
 		wave_scan_all(g, w, lane, stampv, tid, 2, id);
@@ -1099,7 +1111,6 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			}
 			wave_publish_collapse(g, id, t.push_e, t.push_d, t.push_len, lane, sepl);
 			PH_ADD(6);
-			PH_ADD(7);
 			if (w.use_stale) {                                              // marked, not rescanned: whoever reads one of them next asks for it (bt_rb_run returns 2)
 				if (lane == 0) for (unsigned q = 0; q < 4; q++) w.stale[q] |= dirty[q];
 				WSYNC();
@@ -1143,6 +1154,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			}
 			atomicMax(&g_round_max[(g.tslot >> 2) & 4095u], (dur << 24) | ((unsigned long long)(w.n < 255u ? w.n : 255u) << 16) | ((unsigned long long)(w.nold < 255u ? w.nold : 255u) << 8) | (w.ret < 255u ? w.ret : 255u));
 		}
+		atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u);
 		if (t.err) {
 			if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
 			atomicOr(&g.ctr[CTR_ERR], t.err);
@@ -1355,9 +1367,9 @@ void sbl_commit_prof_report(unsigned ts_round)
 {
 	unsigned long long z[24];
 	HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
-	const char *nm[24] = {"setup", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "(unused)", "rescan",
+	const char *nm[24] = {"list-positions", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "init", "rescan",
 	                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints",
-	                      " b:endchars+sizing", " b:map-build", " b:finish", " b:loop-setup", " r:FillVisit", " r:Overlap", " r:multiplicities", " r:J walk + search"};
+	                      " b:endchars+sizing", " b:map-build", " b:finish", "bt_setup", " r:FillVisit", " r:Overlap", " r:multiplicities", " r:J walk + search"};
 	for (int i = 0; i < 24; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 	unsigned long long hh[4][16], mx[2];
 	HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
