@@ -479,6 +479,9 @@ struct BulgeWork {
 	// FillVisit by the caller's 64 lanes (commit.hip: wave_fill_visit) instead of one thread's shell sort: with wfill set bt_rb_run returns 5
 	// (fill_i = the instance) where it would call bt_fill_visit; the caller clears need_fill
 	bool wfill; uint32_t fill_i;
+	// the I loop of a large group (pscan): bt_rb_run returns 6 and the caller moves idI to the next member that is valid AND has a valid later
+	// member with another endChar (pj = the first such J) -- see bt_rb_next_pair; pready = idI / pj are such a pair (or idI is the group's end)
+	bool pscan, pready, pjknown; uint32_t pj;
 	uint32_t mscan_min;          // ... with more than this many marks inside the two branches together
 	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
@@ -529,7 +532,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
 	w.use_stale = false; w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0; w.wfill = false; w.fill_i = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0; w.wfill = false; w.fill_i = 0; w.pscan = false; w.pready = false; w.pjknown = false; w.pj = 0;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;
@@ -1068,7 +1071,7 @@ __host__ __device__ inline bool bt_rb_begin(Txn &t, BulgeWork &w, int any_bulges
 	if (any_bulges < 0) { bt_end_chars(t, w); any_bulges = bt_any_bulges(t, w, false) ? 1 : 0; }
 	if (!any_bulges) return false;
 	t.iw(t.id);
-	w.gi = 0; w.idI = w.ab.grp_off[0]; w.idJ = 0; w.ret = 0; w.inI = false; w.need_fill = false;
+	w.gi = 0; w.idI = w.ab.grp_off[0]; w.idJ = 0; w.ret = 0; w.inI = false; w.need_fill = false; w.pready = false;
 	return true;
 }
 
@@ -1084,10 +1087,30 @@ __host__ __device__ inline void bt_rb_next_j(Txn &t, BulgeWork &w)
 	w.jready = true;
 }
 
+// the search bt_rb_run asks for with return code 6, one thread: the next I at or after idI (current group) that is valid and has a valid
+// later member with a different endChar.  Every I in between would enter its J loop and leave it without having found anything (no
+// side effects: FillVisit is only evaluated when a J needs it) -- in a group of 62 members with one deviating instance that is 60 trips
+// through the caller-side J search.
+__host__ __device__ inline void bt_rb_next_pair(Txn &t, BulgeWork &w)
+{
+	const uint32_t ge = w.ab.grp_off[w.gi + 1];
+	uint32_t i = w.idI;
+	w.pj = 0;
+	for (; i < ge; i++) {
+		const uint32_t mi = w.ab.grp_mem[i];
+		if (!bt_pvalid(t, w.start[mi])) continue;
+		uint32_t j = i + 1;
+		for (; j < ge; j++) { const uint32_t mj = w.ab.grp_mem[j]; if (w.endc[mj] != w.endc[mi] && bt_pvalid(t, w.start[mj])) break; }
+		if (j < ge) { w.pj = j; break; }
+	}
+	w.idI = i; w.pready = true; w.pjknown = i < ge;
+}
+
 // 4 (mscan only): see BulgeWork::mscan (bt_rb_mults is the one-thread form).
 // returns 0: all loops done (Cleanup performed unless deferred), 1: a collapse has been decided (c_src -> c_tgt), 2 (lazy runs only):
 // the windows req[0 .. nreq) must be rescanned (and their wep set to epoch) before the loops can go on -- call again afterwards,
 // 3 (jscan only): see BulgeWork::jscan (bt_rb_next_j is the one-thread form of that search), 5 (wfill only): see BulgeWork::wfill.
+// 6 (pscan only): see BulgeWork::pready (bt_rb_next_pair is the one-thread form).
 // every array the decision loops (bt_rb_run) touch is in LDS: the caller may then use bt_rb_run<true>
 __host__ __device__ __forceinline__ bool bt_scratch_in_lds(const BulgeWork &w)
 {
@@ -1107,10 +1130,14 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 	while (w.gi < w.ab.ngroups) {
 		const uint32_t ge = grp_off[w.gi + 1];
 		while (w.idI < ge) {
+			if (!w.inI && w.pscan && !w.pready && ge - w.idI > 8) return 6;      // the caller finds the next I that has a J at all (see pready); short tails are walked here
 			const uint32_t kmerI = grp_mem[w.idI];
 			if (!w.inI) {
-				if (!bt_pvalid(t, start[kmerI])) { w.idI++; continue; }
-				w.inI = true; w.idJ = w.idI + 1; w.need_fill = true; w.jready = false;
+				if (w.pready) { w.inI = true; w.idJ = w.pjknown ? w.pj : w.idI + 1; w.need_fill = true; w.jready = w.pjknown; w.pready = false; }      // (valid, and pj is its first candidate J -- when known)
+				else {
+					if (!bt_pvalid(t, start[kmerI])) { w.idI++; continue; }
+					w.inI = true; w.idJ = w.idI + 1; w.need_fill = true; w.jready = false;
+				}
 			}
 			while (w.idJ < ge) {
 				if (w.jscan && !w.jready && ge - w.idJ > 8) return 3;  // the caller finds the next candidate J (see jscan); short tails are walked here
@@ -1175,7 +1202,7 @@ __host__ __device__ __forceinline__ int bt_rb_run(Txn &t, BulgeWork &w)      // 
 			}
 			w.inI = false; w.idI++;
 		}
-		w.gi++;
+		w.gi++; w.pready = false;
 		if (w.gi < w.ab.ngroups) w.idI = grp_off[w.gi];
 	}
 	if (!t.defer_cleanup) t.cleanup();           // (simplify.hip: Cleanup by all lanes once the loops are over)

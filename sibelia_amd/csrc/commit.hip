@@ -6,7 +6,7 @@
 #include <vector>
 #include <hip/hip_runtime.h>
 // cycle counters of the decision loops (bulge_txn.h: BT_PROF_ADD), device only
-__device__ unsigned long long g_phase_cycles[24];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
+__device__ unsigned long long g_phase_cycles[32];   // SBL_PHASES=1 debug: summed s_memtime deltas of k_commit's phases
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BT_PROF_T0(t) do { if ((t).prof) (t).prof_t = __builtin_readcyclecounter(); } while (0)
 #define BT_PROF_ADD(t, i) do { if ((t).prof) { unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], n_ - (t).prof_t); (t).prof_t = n_; } } while (0)
@@ -622,6 +622,74 @@ __device__ __forceinline__ void wave_next_j(const GraphView &g, BulgeWork &w, un
 	WSYNC();
 }
 
+// ---- the caller side of BulgeWork::pready (bt_rb_next_pair with 64 lanes): the next member I of the group, at or after idI, that is valid
+// and has a valid later member with another endChar, and the first such J.  Pass A: per endChar, the LAST valid member that carries it;
+// pass B: the first valid member before the last one of some other endChar.  Three dependent look-ups per 64 members and pass
+// (member -> instance -> node's dead flag); the I loop of bt_rb_run spent a trip through wave_next_j on every member.
+__device__ __forceinline__ void wave_next_pair(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane)
+{
+	const unsigned gs = w.idI, ge = w.ab.grp_off[w.gi + 1];
+	WSYNC();                                                       // (everybody has read idI before lane 0 moves it)
+	enum { NC = 8 };
+	unsigned cls_c[NC] = {0, 0, 0, 0, 0, 0, 0, 0}, cls_last[NC] = {0, 0, 0, 0, 0, 0, 0, 0}, ncls = 0;                    // (uniform: endChars seen among the valid members, index of the last one + 1)
+	bool too_many = false;
+	auto load = [&](unsigned j0, unsigned &ec, bool &valid) {
+		const unsigned idx = j0 + lane;
+		const bool in = idx < ge;
+		const unsigned m = in ? ldx(&w.ab.grp_mem[idx]) : 0u;
+		const unsigned st = in ? ldx(&w.start[m]) : 0u;
+		ec = in ? (unsigned)(unsigned char)ldx(&w.endc[m]) : 0u;
+		valid = in && !g.ndead[st >> 1];
+	};
+	const bool one = ge - gs <= 64u;
+	unsigned ec0 = 0; bool v0 = false;
+	for (unsigned j0 = gs; j0 < ge && !too_many; j0 += 64) {
+		unsigned ec; bool valid;
+		load(j0, ec, valid);
+		if (one) { ec0 = ec; v0 = valid; }
+		unsigned long long rem = __ballot(valid);
+		while (rem) {
+			const unsigned c = (unsigned)__shfl((int)ec, (int)__builtin_ctzll(rem));
+			const unsigned long long mask = __ballot(valid && ec == c);
+			const unsigned last = j0 + 64u - (unsigned)__builtin_clzll(mask);      // index of the last one + 1
+			bool known = false;                                        // (fixed-trip loops: the table stays in registers)
+#pragma unroll
+			for (int q = 0; q < NC; q++) if ((unsigned)q < ncls && cls_c[q] == c) { known = true; cls_last[q] = last > cls_last[q] ? last : cls_last[q]; }
+			if (!known) {
+				if (ncls == NC) { too_many = true; break; }
+#pragma unroll
+				for (int q = 0; q < NC; q++) if ((unsigned)q == ncls) { cls_c[q] = c; cls_last[q] = last; }
+				ncls++;
+			}
+			rem &= ~mask;
+		}
+	}
+	unsigned found = ge, pj = 0;
+	if (!too_many) {
+		for (unsigned j0 = gs; j0 < ge && found == ge; j0 += 64) {
+			unsigned ec; bool valid;
+			if (one) { ec = ec0; valid = v0; } else load(j0, ec, valid);
+			unsigned other = 0;                                        // the last valid member with another endChar, + 1
+#pragma unroll
+			for (int q = 0; q < NC; q++) if ((unsigned)q < ncls && cls_c[q] != ec && cls_last[q] > other) other = cls_last[q];
+			const unsigned idx = j0 + lane;
+			const unsigned long long b = __ballot(valid && other > idx + 1u);
+			if (b) {
+				const unsigned li = (unsigned)__builtin_ctzll(b);
+				found = j0 + li;
+				const unsigned eci = (unsigned)__shfl((int)ec, (int)li);
+				const unsigned long long later = __ballot(valid && ec != eci) & (li == 63u ? 0ull : (~0ull << (li + 1u)));
+				pj = later ? j0 + (unsigned)__builtin_ctzll(later) : 0u;    // (0: in a later block of 64 -- wave_next_j finds it)
+			}
+		}
+	}
+	if (lane == 0) {
+		if (too_many) bt_rb_next_pair(t, w);                            // (more endChars than the table holds -- no alphabet of this program has: the one-thread form)
+		else { w.idI = found; w.pready = true; w.pj = pj; w.pjknown = pj != 0u; }
+	}
+	WSYNC();
+}
+
 // ---- the caller side of BulgeWork::mscan: MaxBifurcationMultiplicity of the two branches, one CountBifurcations per lane (bt_rb_mults
 // with 64 lanes; Txn::count_bif stamps the id exactly as the one-thread form does)
 __device__ __attribute__((noinline)) void wave_mults(const GraphView &g, Txn &t, BulgeWork &w, unsigned lane)      // (out of line: it runs once per dense branch and must not cost the common path its registers)
@@ -653,29 +721,54 @@ __device__ __attribute__((noinline)) void wave_mults(const GraphView &g, Txn &t,
 // ---- the caller side of BulgeWork::wfill: FillVisit (bulgeremoval.cpp:122-146, bt_fill_visit) with 64 lanes.  One thread's shell sort of
 // the ~15 (id, distance) pairs of a window is ~100 dependent LDS round trips (26 k cycles per call, once per I and again after every
 // collapse that rewrote I's window); here every lane holds one pair and counts the smaller ones.
-__device__ __forceinline__ void wave_fill_visit(Txn &t, BulgeWork &w, unsigned D, unsigned lane)
+template <int NCH>
+__device__ __forceinline__ void wave_fill_visit_t(Txn &t, BulgeWork &w, unsigned D, unsigned lane)
 {
 	const unsigned i = w.fill_i, nm = ldx(&w.wmn[i]);
-	if (nm > 64u) {                                                        // (longer lists: the one-thread form)
-		if (lane == 0) { if (bt_scratch_in_lds(w)) bt_fill_visit<true>(t, w, i); else bt_fill_visit<false>(t, w, i); w.need_fill = false; }
-		WSYNC();
-		return;
-	}
 	const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(w.wmk) + (size_t)i * w.mks;
 	unsigned long long *visit = reinterpret_cast<unsigned long long *>(w.visit);
 	const unsigned wl = ldx(&w.wlen[i]), start = ldx(&w.wst[i]), lim = wl < D ? wl : D;
-	const unsigned long long v = lane < nm ? ldx(&mk[lane]) : ~0ull;
-	const unsigned step = (unsigned)(v >> 32), b = (unsigned)v;
-	const unsigned long long ms = __ballot(lane >= nm || step >= lim || b == start);
-	unsigned n = ms ? (unsigned)__builtin_ctzll(ms) : 64u;
+	unsigned long long key[NCH];
+	unsigned n = 64u * NCH;
+#pragma unroll
+	for (int u = 0; u < NCH; u++) {
+		const unsigned j = lane + 64u * u;
+		const unsigned long long v = j < nm ? ldx(&mk[j]) : ~0ull;
+		const unsigned step = (unsigned)(v >> 32), b = (unsigned)v;
+		const unsigned long long ms = __ballot(j >= nm || step >= lim || b == start);
+		if (ms && n == 64u * NCH) n = 64u * u + (unsigned)__builtin_ctzll(ms);      // the first mark the walk stops at
+		key[u] = ((unsigned long long)b << 32) | step;
+	}
 	bool over = false;
 	if (n > w.visit_cap) { n = w.visit_cap; over = true; }
-	const unsigned long long key = lane < n ? ((unsigned long long)b << 32) | step : ~0ull;
-	unsigned rank = 0;
-	for (unsigned y = 0; y < n; y++) rank += __shfl(key, y) < key ? 1u : 0u;      // (the pairs are distinct: every step occurs once)
-	if (lane < n) stx(&visit[rank], key);
+	unsigned rank[NCH];
+#pragma unroll
+	for (int u = 0; u < NCH; u++) { rank[u] = 0; if (lane + 64u * u >= n) key[u] = ~0ull; }
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {                                        // (the pairs are distinct: every step occurs once)
+		const unsigned upto = n > 64u * c ? (n - 64u * c < 64u ? n - 64u * c : 64u) : 0u;
+		for (unsigned y = 0; y < upto; y++) {
+			const unsigned long long ky = __shfl(key[c], y);
+#pragma unroll
+			for (int u = 0; u < NCH; u++) rank[u] += ky < key[u] ? 1u : 0u;
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < NCH; u++) if (lane + 64u * u < n) stx(&visit[rank[u]], key[u]);
 	if (lane == 0) { w.nvisit = n; w.need_fill = false; if (over) t.err |= BT_ERR_SCRATCH; }
 	WSYNC();
+}
+__device__ __forceinline__ void wave_fill_visit(Txn &t, BulgeWork &w, unsigned D, unsigned lane)
+{
+	const unsigned nm = ldx(&w.wmn[w.fill_i]);
+	if (nm <= 64u) wave_fill_visit_t<1>(t, w, D, lane);
+#ifndef SBL_VAR_NOFV3
+	else if (nm <= 192u) wave_fill_visit_t<3>(t, w, D, lane);                // (62 strains: ~90 marks per window, lists in the arena -- one thread's sort there was 330 k cycles per transaction)
+#endif
+	else {                                                                 // (longer than any window of D <= 150 steps: the one-thread form)
+		if (lane == 0) { if (bt_scratch_in_lds(w)) bt_fill_visit<true>(t, w, w.fill_i); else bt_fill_visit<false>(t, w, w.fill_i); w.need_fill = false; }
+		WSYNC();
+	}
 }
 
 // ---- marks-only window scan, one LANE per instance (64 instances in flight): what AnyBulges needs of a window -- mark at step 0,
@@ -863,23 +956,44 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	for (unsigned i = lane; i < slots; i += 64) { stx(&sh.skey[i], BT_NONE); stx(&sh.sval[i], BT_NONE); }
 	WSYNC();
 	bool bad = false;
-	// (the first 64 marks of the NEXT instance are requested while this one is worked on: with dozens of instances the lists live in the
-	// arena, and every instance used to begin with a memory round trip of its own)
-	unsigned long long vpre = ~0ull;
+	// (the marks of the NEXT instance -- up to ABPF x 64 of them: a whole window -- are requested while this one is worked on: with dozens
+	// of instances the lists live in the arena, and every instance used to begin with a memory round trip of its own, and with another
+	// one per further chunk of 64 marks (62 strains: ~90 marks per window); a chunk that starts in the middle of a block of 64 -- after
+	// an event -- is put together from two of the registers)
+#ifndef ABPF_N
+#define ABPF_N 1             // (3 = a whole window of the next instance in flight: -0.7 % at 62 strains, + 0.3 ms of k_commit at 8 -- registers)
+#endif
+	enum { ABPF = ABPF_N };
+	unsigned long long vpre[ABPF];
+#pragma unroll
+	for (int u = 0; u < ABPF; u++) vpre[u] = ~0ull;
 	unsigned pre_i = n;
-	auto first_chunk = [&](unsigned ii) { const unsigned long long *m0 = wmk + (size_t)ii * mks; return lane < ldx(&wmn[ii]) ? ldx(&m0[lane]) : ~0ull; };
+	auto chunk_at = [&](unsigned ii, unsigned u) { const unsigned long long *m0 = wmk + (size_t)ii * mks; const unsigned jj = lane + 64u * u; return jj < ldx(&wmn[ii]) ? ldx(&m0[jj]) : ~0ull; };
 	for (unsigned i = 0; i < n && !bad; i++) {
 		const char ec = ldx(&endc[i]);
 		if (ec == ' ') continue;
 		const unsigned long long *mk = wmk + (size_t)i * mks;
 		const unsigned wl = ldx(&wlen[i]);
 		const unsigned start = ldx(&wst[i]), lim = wl < D ? wl : D, nm = ldx(&wmn[i]);
-		const unsigned long long v0 = pre_i == i ? vpre : first_chunk(i);
-		if (i + 1 < n) { vpre = first_chunk(i + 1); pre_i = i + 1; }
+		unsigned long long vc[ABPF];
+#pragma unroll
+		for (int u = 0; u < ABPF; u++) vc[u] = pre_i == i ? vpre[u] : chunk_at(i, (unsigned)u);
+		if (i + 1 < n) {
+#pragma unroll
+			for (int u = 0; u < ABPF; u++) vpre[u] = chunk_at(i + 1, (unsigned)u);
+			pre_i = i + 1;
+		}
 		unsigned pos = 0;
 		while (pos < nm) {
 			unsigned j = pos + lane;
-			unsigned long long v = pos == 0 ? v0 : j < nm ? ldx(&mk[j]) : ~0ull;
+			unsigned long long v;
+			const unsigned c0 = pos >> 6, l0 = pos & 63u;
+			if (c0 + 1u < (unsigned)ABPF || (c0 < (unsigned)ABPF && l0 == 0u)) {
+				const unsigned lj = (l0 + lane) & 63u;
+				const unsigned long long lo = c0 == 0u ? vc[0] : c0 == 1u ? vc[ABPF > 1 ? 1 : 0] : vc[ABPF > 2 ? 2 : 0], hi = c0 == 0u ? vc[ABPF > 1 ? 1 : 0] : vc[ABPF > 2 ? 2 : 0];
+				const unsigned long long va = __shfl(lo, lj), vb = __shfl(hi, lj);
+				v = l0 + lane < 64u ? va : c0 + 1u < (unsigned)ABPF ? vb : ~0ull;
+			} else v = j < nm ? ldx(&mk[j]) : ~0ull;
 			unsigned b = (unsigned)v;
 			bool stop = j >= nm || (unsigned)(v >> 32) >= lim || b == start;
 			unsigned long long ms = __ballot(stop);
@@ -1008,7 +1122,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		// dirties -- O(instances) to compute, and nearly all of them in the dense regime -- is only needed by the reservation check of
 		// an ordered round
 		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = solo && w.wep != nullptr; w.jscan = w.lazy || (w.n > 24u && g.jscan_rounds); w.mscan = (w.n > 24u || (g.test_flags & 16u)) && g.jscan_rounds; if (g.test_flags & 16u) w.mscan_min = (g.test_flags >> 8) & 15u;
-			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; w.wfill = !(g.test_flags & 64u); }      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
+			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; w.wfill = !(g.test_flags & 64u); w.pscan = false; }      // (pscan: measured -1.2 % at 62 strains, +1.4 % of k_commit at 8 -- the handler's registers; the one-launch kernel uses it)      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
 		while (flag) {
@@ -1016,9 +1130,9 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			WSYNC();
 			PH_ADD(3);
 			if (!flag) break;
-			if (flag == 3) { wave_next_j(g, w, lane); continue; }       // large group: the search for the next J, 256 members per step
-			if (flag == 4) { wave_mults(g, t, w, lane); continue; }     // branches with many bifurcations inside: their multiplicities, one look-up per lane
-			if (flag == 5) { wave_fill_visit(t, w, g.D, lane); if (t.err) break; continue; }      // FillVisit(I), one (id, distance) pair per lane
+			if (flag == 3) { wave_next_j(g, w, lane); PH_ADD(24); continue; }       // large group: the search for the next J, 256 members per step
+			if (flag == 4) { wave_mults(g, t, w, lane); PH_ADD(25); continue; }     // branches with many bifurcations inside: their multiplicities, one look-up per lane
+			if (flag == 5) { wave_fill_visit(t, w, g.D, lane); PH_ADD(26); if (t.err) break; continue; }      // FillVisit(I), one (id, distance) pair per lane
 			if (flag == 2) {                                             // the loops need these windows as of now
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, stampv, tid, 2, id);
@@ -1291,13 +1405,14 @@ __device__ __forceinline__ void dense_remove_bulges(const GraphView &g, Txn &t, 
 		}
 		WSYNC();
 		int any = wave_any_bulges(g, t, w, absh, lane, true, DENSE_COUNT_SLOTS, count_tab);
-		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = true; w.jscan = true; }
+		if (lane == 0) { flag = bt_rb_begin(t, w, any) && !t.err ? 1 : 0; w.lazy = true; w.jscan = true; w.pscan = true; }
 		WSYNC();
 		while (flag) {
 			if (lane == 0) { const int r = bt_rb_run(t, w); flag = t.err ? 0 : r; }
 			WSYNC();
 			if (!flag) break;
 			if (flag == 3) { wave_next_j(g, w, lane); continue; }
+			if (flag == 6) { wave_next_pair(g, t, w, lane); continue; }
 			if (flag == 2) {
 				const unsigned nr = w.nreq;
 				for (unsigned x = 0; x < nr; x++) wave_scan_instance(g, w, w.req[x], lane, BT_NONE, 0, 0, id);
@@ -1356,7 +1471,7 @@ __global__ void __launch_bounds__(64) k_dense_stage(GraphView g, uint8_t *arena,
 void sbl_commit_prof_reset()
 {
 	unsigned long long z[64] = {0};
-	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 24 * 8));
+	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 32 * 8));
 	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_hist), z, 64 * 8));
 	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_txn_max), z, 16));
 	{ std::vector<unsigned long long> zz(4096, 0); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_max), zz.data(), 4096 * 8)); }
@@ -1365,12 +1480,13 @@ void sbl_commit_prof_reset()
 }
 void sbl_commit_prof_report(unsigned ts_round)
 {
-	unsigned long long z[24];
+	unsigned long long z[32];
 	HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_phase_cycles), sizeof z));
-	const char *nm[24] = {"list-positions", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "init", "rescan",
+	const char *nm[32] = {"list-positions", "scan", "rb_begin", "rb_run", "dirty-calc", "collapse", "publish", "init", "rescan",
 	                      " c:erase-flanks", " c:erase-span", " c:positions+NE-alloc", " c:replace", " c:copy-marks-data", " c:NN-alloc+stamps", " c:addpoints",
-	                      " b:endchars+sizing", " b:map-build", " b:finish", "bt_setup", " r:FillVisit", " r:Overlap", " r:multiplicities", " r:J walk + search"};
-	for (int i = 0; i < 24; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
+	                      " b:endchars+sizing", " b:map-build", " b:finish", "bt_setup", " r:FillVisit", " r:Overlap", " r:multiplicities", " r:J walk + search",
+	                      " w:next J", " w:multiplicities", " w:FillVisit", "(unused)", "(unused)", "(unused)", "(unused)", "(unused)"};
+	for (int i = 0; i < 32; i++) fprintf(stderr, "[sbl] commit phase %-12s %10.3f Mcycles\n", nm[i], z[i] / 1e6);
 	unsigned long long hh[4][16], mx[2];
 	HIP_TRY(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_txn_hist), sizeof hh));
 	HIP_TRY(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_txn_max), sizeof mx));

@@ -93,6 +93,8 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 	bt_scan_all(t, w);
 	w.lazy = !t.err && w.wep != nullptr;
 	w.jscan = w.lazy;                                              // (exercises the caller-side J search of the kernels)
+	w.wfill = w.lazy;                                              // (... and the caller-side FillVisit)
+	w.pscan = w.lazy;                                              // (... and the caller-side search for the next I that has a J)
 	w.mscan = g.test_lazy_map != 0;                                // (tests/hostsim, HOSTSIM_LAZY_MAP: ... and the caller-side multiplicities)
 	int more = !t.err && bt_rb_begin(t, w) ? 1 : 0;
 	// windows that see the region a collapse rewrites (target start .. end of its look-forward flank) are the only ones whose
@@ -105,6 +107,8 @@ __host__ __device__ inline void ss_commit_run(const GraphView &g, uint32_t widx,
 		if (t.err) break;
 		if (more == 3) bt_rb_next_j(t, w);
 		else if (more == 4) bt_rb_mults(t, w);
+		else if (more == 5) { bt_fill_visit(t, w, w.fill_i); w.need_fill = false; if (t.err) break; }
+		else if (more == 6) bt_rb_next_pair(t, w);
 		else if (more == 2) {                                          // lazy run: the loops need these windows as of now
 			for (uint32_t x = 0; x < w.nreq; x++) {
 				bt_scan_instance(t, w, w.req[x]);
