@@ -846,6 +846,63 @@ __device__ __forceinline__ int ab_lazy_lane0(Txn &t, BulgeWork &w, ABShared &sh,
 }
 
 
+// The same `run` insertions by the lanes that hold the ids (lane f + x holds the x-th id of the run): the first occurrence of an id in
+// the run takes entry size + (number of first occurrences before it) -- the entry indices, and with them the log the Boost restatement
+// replays, are those of the one-thread loop -- and claims a slot of the shadow table with a compare-and-swap (where an id ends up in an
+// open-addressing table does not matter to a look-up).  The first instance of each endChar brings ~15 ids at 8 strains, ~90 at 62: one
+// thread spent 1.5 - 3 k cycles on each.
+__device__ __forceinline__ int ab_lazy_wave(Txn &t, BulgeWork &w, ABShared &sh, unsigned lane, unsigned i, char ec, unsigned f, unsigned run, unsigned b,
+                                            unsigned slots, unsigned shift, bool estimate)
+{
+	ABuild &a = w.abb;
+	unsigned *const key = a.m.key, *const mhead = a.mhead, *const mtail = a.mtail, *const mcnt = a.mcnt, *const log_inst = a.log_inst, *const log_next = a.log_next;
+	unsigned *const skey = sh.skey, *const sval = sh.sval;
+	char *const echar = a.echar;
+	const unsigned size = a.m.size, nlog = a.nlog, cap = a.m.cap, logcap = a.logcap, distinct = sh.distinct;
+	const bool in = lane >= f && lane < f + run;
+	bool first = in;                                                       // no earlier lane of the run holds the same id
+	for (unsigned y = 0; y + 1 < run; y++) { const unsigned by = (unsigned)__shfl((int)b, (int)(f + y)); if (in && lane > f + y && by == b) first = false; }
+	const unsigned long long fm = __ballot(first);
+	const unsigned total = (unsigned)__popcll(fm), mine = (unsigned)__popcll(fm & ((1ull << lane) - 1ull));
+	if (estimate && size + total > distinct) return -2;                    // more distinct ids than estimated: again, with the counting pass (nothing of this attempt is kept)
+	if (size + total > cap || nlog + total > logcap) { if (lane == 0) t.err |= BT_ERR_SCRATCH; return -1; }
+	if (first) {
+		const unsigned kt = size + mine, nl = nlog + mine;
+		stx(&key[kt], b); stx(&echar[kt], ec);
+		stx(&log_inst[nl], i); stx(&log_next[nl], (unsigned)BT_NONE);
+		stx(&mhead[kt], nl); stx(&mtail[kt], nl); stx(&mcnt[kt], 1u);
+	}
+	// slots of the shadow table.  In LDS: compare-and-swap.  In the arena: plain loads and stores only (an atomic is performed in the L2 and
+	// the lanes' later look-ups are ordinary loads through the L1) -- lanes that want the same slot settle it among themselves: the lowest
+	// lane takes it, the others move on.
+	if (BT_IS_LDS(skey)) {
+		if (first) {
+			unsigned hh = (b * 2654435761u) >> shift;
+			for (;;) {
+				if (casx(&skey[hh], (unsigned)BT_NONE, b) == BT_NONE) break;
+				hh = (hh + 1) & (slots - 1);
+			}
+			stx(&sval[hh], ((size + mine) << 8) | (unsigned char)ec);
+		}
+	} else {
+		bool pending = first;
+		unsigned hh = (b * 2654435761u) >> shift;
+		while (__ballot(pending)) {
+			if (pending) { while (ldg(&skey[hh]) != BT_NONE) hh = (hh + 1) & (slots - 1); }      // (slots taken before this run)
+			bool lose = false;
+			for (unsigned y = 0; y < run; y++) {
+				const unsigned hy = (unsigned)__shfl((int)hh, (int)(f + y));
+				const bool py = __shfl((int)pending, (int)(f + y)) != 0;
+				if (pending && py && f + y < lane && hy == hh) lose = true;
+			}
+			if (pending && !lose) { stg(&skey[hh], b); stg(&sval[hh], ((size + mine) << 8) | (unsigned)(unsigned char)ec); pending = false; }
+			else if (pending) hh = (hh + 1) & (slots - 1);
+		}
+	}
+	if (lane == 0) { a.m.size = size + total; a.nlog = nlog + total; }
+	return sh.mode;
+}
+
 #define AB_COUNT_SLOTS 512u
 // count_slots: size of the distinct-id counting set (a power of two >= AB_COUNT_SLOTS; the dense kernel has room for more)
 __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, BulgeWork &w, ABShared &sh, unsigned lane, bool endc_ready = false,
@@ -1016,6 +1073,15 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 			// a run of consecutive new ids (the first instance of every endChar brings ~all its marks) is handed to lane 0 at once
 			unsigned long long ins = __ballot(ev == 1u) >> f;
 			unsigned run = eev == 1u ? (ins == ~0ull ? 64u - f : (unsigned)__builtin_ctzll(~ins)) : 0u;
+			if (w.abb.lazy && eev == 1u && !(g.test_flags & 512u)) {              // the run by the lanes that hold its ids
+				const int m = ab_lazy_wave(t, w, sh, lane, i, ec, f, run, b, slots, shift, estimate);
+				WSYNC();
+				if (lane == 0) sh.mode = m;
+				WSYNC();
+				if (m < 0) { bad = true; break; }
+				pos += f + run;
+				continue;
+			}
 			if (lane >= f && lane < f + run) sh.batch[lane - f] = b;
 			WSYNC();
 			if (lane == 0 && w.abb.lazy) {

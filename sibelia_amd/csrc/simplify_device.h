@@ -24,7 +24,16 @@ template <class T> __device__ __forceinline__ void stg(T *p, T v) { *(SBL_AS1 T 
 template <class T> __device__ __forceinline__ T ldx(const T *p)                                                     // fast scratch or arena (t.alloc2 / falloc)
 { return __builtin_amdgcn_is_shared((const void *)p) ? *(const SBL_AS3 T *)p : *(const SBL_AS1 T *)p; }
 template <class T> __device__ __forceinline__ void stx(T *p, T v) { if (__builtin_amdgcn_is_shared((const void *)p)) *(SBL_AS3 T *)p = v; else *(SBL_AS1 T *)p = v; }
+// compare-and-swap on a word of the fast scratch or the arena; returns what was there
+__device__ __forceinline__ unsigned casx(unsigned *p, unsigned expect, unsigned v)
+{
+	unsigned e = expect;
+	if (__builtin_amdgcn_is_shared((const void *)p)) __atomic_compare_exchange_n((SBL_AS3 unsigned *)p, &e, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+	else __atomic_compare_exchange_n((SBL_AS1 unsigned *)p, &e, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+	return e;
+}
 #else       // (the host pass of hipcc only parses the kernels)
+__device__ __forceinline__ unsigned casx(unsigned *p, unsigned expect, unsigned v) { unsigned o = *p; if (o == expect) *p = v; return o; }
 template <class T> __device__ __forceinline__ T ldg(const T *p) { return *p; }
 template <class T> __device__ __forceinline__ void stg(T *p, T v) { *p = v; }
 template <class T> __device__ __forceinline__ T ldx(const T *p) { return *p; }
