@@ -936,7 +936,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 	// the estimate was too low (ids of low-complexity sequence, whose instances are not homologous; never on the 62-strain workload).
 	// (Round 4's first version let the overflow surface as a scratch error: the id was sent to the big arena, overflowed there again,
 	// was sent again ... -- the `-s far` hierarchy case of the drop-in tests never came back.)
-	const bool estimate = attempt == 0 && n > 32u && g.ab_estimate;
+	const bool estimate = attempt == 0 && g.ab_estimate && (n > 32u || !(g.test_flags & 2048u));      // (round 5: small ids too -- the counting pass was 4 % of a transaction; 2048: measurement switch)
 	if (sh.mode && estimate) {
 		unsigned mx = 0;
 		for (unsigned i = lane; i < n; i += 64) { const unsigned v = ldx(&endc[i]) == ' ' ? 0u : ldx(&wmn[i]); mx = v > mx ? v : mx; }
@@ -945,7 +945,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 		WSYNC();
 		if (lane == 0) {
 			t.fscr_used = mark;
-			const unsigned distinct = 2 * mx + 32;
+			const unsigned distinct = n > 32u ? 2 * mx + 32 : mx + (mx >> 2) + 8;      // (a handful of homologous instances: the longest list plus what the minority branches add)
 			unsigned bits = 6;
 			while ((1u << bits) < 2 * distinct + 2) bits++;
 			sh.bits = bits; sh.distinct = distinct;

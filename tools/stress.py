@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle stress: python tools/stress.py [seconds] [first_seed]
-Environment: SHARD=n (n virtual ranks), N2=1 (synteny blocks + GlueStripes + reports as well), STAGES=3 (three-stage cascades).
+Environment: SHARD=n (n virtual ranks), N2=1 (synteny blocks + GlueStripes + reports as well), STAGES=3 (three-stage cascades),
+MANY=1 (30 - 70 strains of a few kbp: ids with dozens of instances, mark lists and AnyBulges tables in the arena).
 A bounded run of the same loop is part of the GPU suite (tests/test_gpu_stress.py)."""
 import os
 import sys
@@ -22,6 +23,8 @@ def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print, c
         rng = np.random.default_rng(seed)
         n = int(rng.integers(2, 13))
         L0 = int(rng.integers(3_000, 80_000))
+        if os.environ.get("MANY"):
+            n, L0 = int(rng.integers(30, 71)), int(rng.integers(2_000, 9_000))
         k = int(rng.choice([15, 16, 20, 25, 31, 32, 40]))
         D = int(rng.integers(k, 12 * k))
         snp = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
