@@ -24,5 +24,6 @@ timeout 900 python bench.py --config 4 --steps 2 --warmup 1 2>/dev/null | grep '
 timeout 900 python bench.py --config 5 --steps 2 --warmup 1 2>/dev/null | grep '^{' > $out/bench_config5.json
 timeout 300 python bench.py --gpus 2 --dry-collectives 2>/dev/null | grep '^{' > $out/rccl_two_ranks_one_gpu.json
 timeout 600 python tools/longk_profile.py 100 500 > $out/longk_enumerate.jsonl 2>/dev/null
-timeout 1500 python bench.py 2>/dev/null | grep '^{' > $out/bench_default.json
+# (the default line last -- and, for the round's LAST build, by tools/collect_r05_final.sh bench in a second call, with profiles/pmc_latest.json of this build in place: SKIP_DEFAULT=1)
+[ -n "$SKIP_DEFAULT" ] || timeout 1500 python bench.py 2>/dev/null | grep '^{' > $out/bench_default.json
 ls -la $out | head -40; tail -c 500 $out/bench_default.json
