@@ -94,7 +94,20 @@ struct GraphView {
 	// where write stamps are published (bt_idx_wstamp); nullptr = no index (every reader then takes the walking path).
 	unsigned long long *bidx;
 	uint32_t idx_probe, idx_reserve;    // the probe / the reservation of a round read the index (simplify.hip: k_probe_idx, reserve_idx)
+	// Parked transactions (round 5, commit.hip): a launch of k_commit lasts as long as its slowest transaction, and that is one with
+	// several collapses.  A transaction that has made park_cap collapses in a launch and has decided another one PARKS: its LDS state goes
+	// to the end of its arena slice, the id stays pending (the probes take a parked id for live without a verdict), and the next round
+	// in which it owns its claims resumes it where it stopped (k_resume, beside k_commit on a second stream).  park_of[id]: 0 = never
+	// parked; bits 0-19 = its arena slice + 1, bits 20-30 = the round it parked in (it is resumed in a LATER round: both kernels have a
+	// workgroup for every window entry, and an entry must be one kernel's for the whole launch), bit 31 = finished in the round of bits
+	// 20-30 (k_commit leaves it alone in that round, afterwards it is an ordinary id again).  slice_busy[w] != 0: the slice of window
+	// position w holds a parked transaction; the entry at that position works in the shadow slice shadow_base + w (and does not park: it
+	// may be a LOWER id that the parked one has to wait for).  park_cap = 0: off.
+	uint32_t *park_of; uint8_t *slice_busy; uint32_t park_cap, shadow_base;      // (shadow_base + w: the spare slice of window position w)
 };
+#define CTR_PARKED (CTR_DETAIL + 8)      // parked transactions at the moment
+__host__ __device__ __forceinline__ uint32_t bt_round_tag(const GraphView &g) { return (g.round_bits >> 20) & 0x7FFu; }
+__host__ __device__ __forceinline__ bool bt_parked(const GraphView &g, uint32_t id) { if (!g.park_of) return false; const uint32_t pk = g.park_of[id]; return pk != 0 && !(pk >> 31); }
 
 // ------------------------------------------------------------------------------------------- atomics (host + device)
 __host__ __device__ __forceinline__ uint32_t bt_atomic_add(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -482,6 +495,7 @@ struct BulgeWork {
 	// the I loop of a large group (pscan): bt_rb_run returns 6 and the caller moves idI to the next member that is valid AND has a valid later
 	// member with another endChar (pj = the first such J) -- see bt_rb_next_pair; pready = idI / pj are such a pair (or idI is the group's end)
 	bool pscan, pready, pjknown; uint32_t pj;
+	uint32_t ret0;               // parked transactions (GraphView::park_of): value of ret when this launch took the transaction up
 	uint32_t mscan_min;          // ... with more than this many marks inside the two branches together
 	uint32_t mq_i, mq_di, mq_j, mq_dj, mres[2];
 	uint64_t *visit; uint32_t nvisit, visit_cap;      // FillVisit result sorted by (bif, distance)
@@ -532,7 +546,7 @@ __host__ __device__ inline bool bt_setup(Txn &t, BulgeWork &w, bool lite = false
 	// mark lists: in the fast scratch (LDS) for the writer pass of typical ids, lane 0 walks them many times
 	w.mk_overflow = false;
 	w.use_stale = false; w.stale[0] = w.stale[1] = w.stale[2] = w.stale[3] = 0;
-	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0; w.wfill = false; w.fill_i = 0; w.pscan = false; w.pready = false; w.pjknown = false; w.pj = 0;
+	w.lazy = false; w.epoch = 0; w.wep = nullptr; w.nreq = 0; w.jscan = false; w.jready = false; w.mscan = false; w.mscan_min = BT_MSCAN_MIN; w.mready = false; w.nold = 0; w.wfill = false; w.fill_i = 0; w.pscan = false; w.pready = false; w.pjknown = false; w.pj = 0; w.ret0 = 0;
 	const uint32_t lazy_min = g.lazy_min ? g.lazy_min : BT_LAZY_MIN;
 	w.wmk = lite || n > lazy_min ? nullptr : (uint64_t *)t.falloc(n * BT_LDS_MARKS * 8);      // (a lazy run never moves its mark lists: full-size lists from the start)
 	w.mks = BT_LDS_MARKS;

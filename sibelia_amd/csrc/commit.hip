@@ -1124,17 +1124,57 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 #ifndef COMMIT_FAST_BYTES
 #define COMMIT_FAST_BYTES 8192               // LDS scratch of a transaction; with Txn / BulgeWork ~9 KB per workgroup = 17 workgroups per CU (12 KB: 12, and 4 % slower)
 #endif
+// ---- parked transactions (GraphView::park_of): the LDS state of a transaction at the end of its arena slice
+#define PARK_IMG 12288u
+#define PARK_OFF_W ((unsigned)((sizeof(Txn) + 15u) & ~15u))
+#define PARK_OFF_AB (PARK_OFF_W + (unsigned)((sizeof(BulgeWork) + 15u) & ~15u))
+#define PARK_OFF_FAST (PARK_OFF_AB + (unsigned)((sizeof(ABShared) + 15u) & ~15u))
+static_assert(sizeof(Txn) % 4 == 0 && sizeof(BulgeWork) % 4 == 0 && sizeof(ABShared) % 4 == 0, "park_move copies words");
+static_assert(PARK_OFF_FAST + COMMIT_FAST_BYTES <= PARK_IMG, "the LDS image of a transaction must fit PARK_IMG");
+__device__ __forceinline__ void park_move(unsigned *dst, const unsigned *src, unsigned words, unsigned lane) { for (unsigned i = lane; i < words; i += 64) dst[i] = src[i]; }
+__device__ __forceinline__ void park_store(const GraphView &g, Txn &t, BulgeWork &w, ABShared &absh, uint8_t *fast, unsigned fast_bytes, uint8_t *image, unsigned id, unsigned slice)
+{
+	const unsigned lane = threadIdx.x;
+	WSYNC();
+	park_move(reinterpret_cast<unsigned *>(image), reinterpret_cast<const unsigned *>(&t), sizeof(Txn) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_W), reinterpret_cast<const unsigned *>(&w), sizeof(BulgeWork) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_AB), reinterpret_cast<const unsigned *>(&absh), sizeof(ABShared) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_FAST), reinterpret_cast<const unsigned *>(fast), fast_bytes / 4, lane);
+	if (lane == 0) { g.park_of[id] = (slice + 1u) | (bt_round_tag(g) << 20); g.slice_busy[slice] = 1; g.need[id] = 2; atomicAdd(&g.ctr[CTR_PARKED], 1u); }
+}
+// ... and back; what belongs to the round (the graph view with its round stamp, the claim stamp) is renewed
+__device__ __forceinline__ void park_load(const GraphView &g, Txn &t, BulgeWork &w, ABShared &absh, uint8_t *fast, unsigned fast_bytes, const uint8_t *image, unsigned id, unsigned wi, int prof)
+{
+	const unsigned lane = threadIdx.x;
+	park_move(reinterpret_cast<unsigned *>(&t), reinterpret_cast<const unsigned *>(image), sizeof(Txn) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(&w), reinterpret_cast<const unsigned *>(image + PARK_OFF_W), sizeof(BulgeWork) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(&absh), reinterpret_cast<const unsigned *>(image + PARK_OFF_AB), sizeof(ABShared) / 4, lane);
+	park_move(reinterpret_cast<unsigned *>(fast), reinterpret_cast<const unsigned *>(image + PARK_OFF_FAST), fast_bytes / 4, lane);
+	WSYNC();
+	if (lane == 0) { t.g = g; t.stamp = g.round_bits | wi; t.prof = prof != 0; w.ret0 = w.ret - 1; atomicSub(&g.ctr[CTR_PARKED], 1u); }      // (ret0: the collapse it parked with belongs to this launch)
+	WSYNC();
+}
 // The transaction proper (RemoveBulges for one id) on one wave; t, w, flag, absh and fast live in LDS.
 // solo: 0 = ordered round (the probe found bulges, the entry owns its claims), 1 = the id runs with nothing else in flight
 // (big-arena solo round, or the serial chain: stampv == BT_NONE, no reservation exists and none is checked).
+template <bool RESUME = false>
 __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWork &w, int &flag, ABShared &absh, uint8_t *fast, unsigned fast_bytes,
                                             unsigned wi, unsigned id, unsigned stampv, int solo, bool prepass, uint8_t *mine, unsigned arena_bytes, int prof,
-                                            const unsigned *sepl = nullptr /* LDS copy of the separators' slots (SepBounds), or none */)
+                                            const unsigned *sepl = nullptr /* LDS copy of the separators' slots (SepBounds), or none */,
+                                            unsigned park_slice = BT_NONE /* may park (GraphView::park_of): its arena slice; RESUME: it is parked there */)
 {
 	const unsigned lane = threadIdx.x, tid = id + 1;
 	PH_T0();
+	// parking: the last PARK_IMG bytes of the slice are kept for the LDS image (t, w, absh, fast)
+	const bool can_park = park_slice != BT_NONE && g.park_cap != 0 && arena_bytes >= 4u * PARK_IMG;
+	if (can_park) arena_bytes -= PARK_IMG;
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
 	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
+	if (RESUME) {                                                     // the state it parked with; what belongs to the round is renewed
+		park_load(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, wi, prof);
+		if (lane == 0) flag = 1;
+		WSYNC();
+	} else {
 	if (prepass) {
 		if (lane == 0) { t.init(g, id, wi, 1, mine, arena_bytes); t.ext_stamps = true; t.chain = stampv == BT_NONE; }
 		WSYNC();
@@ -1167,12 +1207,17 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		PH_ADD(19);
 		if (flag) {
 			const unsigned m = wave_list_positions(g, h0, h1, w, lane);
-			if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; flag = 0; }      // cannot happen on a consistent graph
+			if (m != w.n && lane == 0) {
+				if (g.park_cap && m < w.n) { w.n = m; if (m < 2) flag = 0; }      // (nodes erased by a parked transaction: see wave_setup)
+				else { t.err |= BT_ERR_SCRATCH; flag = 0; }                   // cannot happen on a consistent graph
+			}
 			WSYNC();
 		}
 	}
+	}
 	PH_ADD(0);
 	if (flag) {
+		if (!RESUME) {
 		wave_scan_all(g, w, lane, stampv, tid, 2, id);
 		WSYNC();
 		if (w.mk_overflow) {                                          // more marks in a window than the LDS lists hold: use the arena
@@ -1191,7 +1236,10 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			                 w.use_stale = !w.lazy && w.n <= 256u && g.lazy_rescan && w.wdel != nullptr; w.wfill = !(g.test_flags & 64u); w.pscan = false; }      // (pscan: measured -1.2 % at 62 strains, +1.4 % of k_commit at 8 -- the handler's registers; the one-launch kernel uses it)      // (many strains: groups of dozens of members, the J search with 64 lanes -- wave_next_j)
 		WSYNC();
 		PH_ADD(2);
+		}
+		bool decided = RESUME;                                        // (a parked transaction stopped with its next collapse decided)
 		while (flag) {
+			if (!RESUME || !decided) {
 			if (lane == 0) { const int r = bt_scratch_in_lds(w) ? bt_rb_run<true>(t, w) : bt_rb_run<false>(t, w); flag = t.err ? 0 : r; }      // (<true>: DS instead of FLAT accesses, bulge_txn.h: BT_ASSUME_LDS)
 			WSYNC();
 			PH_ADD(3);
@@ -1215,6 +1263,13 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				}
 				PH_ADD(8);
 				continue;
+			}
+			}
+			decided = false;
+			// ---- a collapse has been decided (c_src -> c_tgt).  Enough of them for one launch: park (GraphView::park_of)
+			if (can_park && !w.lazy && w.ret - w.ret0 > g.park_cap) {      // (ret counts the collapse just decided)
+				park_store(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, park_slice);      // (arena_bytes: already without the image)
+				return;                                                    // (no Cleanup, no counters: the transaction is not over)
 			}
 			if (w.lazy) {
 				wave_collapse_any(g, t, w, lane, stampv, prof);
@@ -1335,6 +1390,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			atomicMax(&g_round_max[(g.tslot >> 2) & 4095u], (dur << 24) | ((unsigned long long)(w.n < 255u ? w.n : 255u) << 16) | ((unsigned long long)(w.nold < 255u ? w.nold : 255u) << 8) | (w.ret < 255u ? w.ret : 255u));
 		}
 		atomicAdd(&g.ctr[CTR_COMMITTED], 1u); atomicAdd(&g.ctr[CTR_TXN], 1u);
+		if (RESUME) { __threadfence(); g.slice_busy[park_slice] = 0; g.park_of[id] = 0x80000000u | (bt_round_tag(g) << 20); }      // (everything this transaction wrote into the slice is out before somebody else takes it)
 		if (t.err) {
 			if (!t.wrote && t.err == BT_ERR_SCRATCH) { ss_mark_big(g, id); return; }
 			atomicOr(&g.ctr[CTR_ERR], t.err);
@@ -1343,7 +1399,8 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	}
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof_every)
+template <bool RESUME_KERNEL>
+__device__ __forceinline__ void commit_kernel(const GraphView &g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof_every)
 {
 	const int prof = prof_every && blockIdx.x % (unsigned)prof_every == 0u;      // SBL_PHASES=N: every Nth entry is timed (all of them distort what they measure)
 	__shared__ Txn t;
@@ -1352,7 +1409,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	__shared__ ABShared absh;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[COMMIT_FAST_BYTES];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
 	const unsigned wi = blockIdx.x, lane = threadIdx.x;
-	round_stamp(g, 2);
+	if (!RESUME_KERNEL) round_stamp(g, 2);
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi;
@@ -1376,7 +1433,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	__shared__ unsigned s_sep[64];                                    // the separators' slots (SepBounds), when there are at most 64
 	const unsigned *sepl = g.sep && g.nsep <= 64 ? s_sep : nullptr;
 	if (sepl) s_sep[lane] = lane < g.nsep ? g.sep[lane] : BT_NONE;
-	commit_body(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)wi * arena_bytes, arena_bytes, prof, sepl);
+	// parked here in an earlier round (GraphView::park_of): resume in the slice it parked in; a fresh entry whose own slice holds somebody's
+	// parked state waits a round
+	// parked here in an earlier round: k_resume's (same launch configuration, behind this kernel); a fresh entry whose own slice holds
+	// somebody's parked state waits a round
+	if (RESUME_KERNEL) {
+		const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)g.park_of[id]);
+		if (!pk || (pk >> 31) || ((pk >> 20) & 0x7FFu) == bt_round_tag(g)) return;      // not parked / parked in this very launch
+		const unsigned slice = (pk & 0xFFFFFu) - 1u;
+		commit_body<true>(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, 0, false, arena + (size_t)slice * arena_bytes, arena_bytes, prof, sepl, slice);
+	} else {
+		if (!solo && g.park_cap) {
+			const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)g.park_of[id]);
+			if (pk && (!(pk >> 31) || ((pk >> 20) & 0x7FFu) == bt_round_tag(g))) return;      // parked (k_resume's), or finished in this round
+		}
+		const bool shadow = !solo && g.park_cap && __builtin_amdgcn_readfirstlane((int)g.slice_busy[wi]) != 0;      // my slice holds a parked transaction: the spare one
+		commit_body<false>(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)(shadow ? g.shadow_base + wi : wi) * arena_bytes, arena_bytes, prof, sepl,
+		                   !solo && g.park_cap && !shadow ? wi : (unsigned)BT_NONE);
+	}
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof_every)
+{
+	commit_kernel<false>(g, nwin, arena, arena_bytes, solo, claims, live, prof_every);
+}
+
+// the parked transactions of the window that own their claims this round (GraphView::park_of): the rest of their loops.  A kernel of its
+// own, beside k_commit on a second stream: with both bodies in one kernel every transaction spilled (scratch 232 -> 616 B), and a call
+// made the kernel's scratch 880 B (commit 32 -> 52 ms either way)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_resume(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, const unsigned *claims, const uint8_t *live, int prof_every)
+{
+	commit_kernel<true>(g, nwin, arena, arena_bytes, 0, claims, live, prof_every);
 }
 
 // Serial chain: one wave runs what is pending in the id range of the window strictly in ascending order, one transaction

@@ -454,13 +454,25 @@ __global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, ui
 	if (!snapshot) round_stamp(g, 0);
 	if (wi >= nwin) return;
 	const unsigned id = g.win[wi], tid = snapshot ? 0xFFFFFFFEu : id + 1;
-	if (!snapshot && g.need[id] == 2) { if (lane == 0) { live[wi] = 1; if (instbuf) instbuf[(size_t)wi * istride] = BT_NONE; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
+	// found live by an earlier probe and not touched since (a push resets it to 1) -- or parked (GraphView::park_of: need = 2 as well; a
+	// push to a parked id comes from a lower transaction that rewrote what it had read, which is an order violation and ends the attempt).
+	// A parked id still hands its instances to the reservation: it reserves every round until it is through.
+	const bool known_live = !snapshot && g.need[id] == 2;
+	if (known_live && !(instbuf && (bt_parked(g, id) || (g.test_flags & 16384u)))) { if (lane == 0) { live[wi] = 1; if (instbuf) instbuf[(size_t)wi * istride] = BT_NONE; if (g.test_flags & 32u) atomicAdd(&g_idx_stats[0], 1u); } return; }          // found live by an earlier probe and not touched since (a push resets it to 1)
 	const unsigned n = wave_list_nodes(g, g.head[0][id], g.head[1][id], lane, nullptr, [&](unsigned off, unsigned, unsigned s, unsigned el, unsigned) {
 		if (off < max_inst) { s_sel[off] = el; s_dir[off] = (uint8_t)s; }
 	});
 	int r = 0;
+	if (known_live) {                                                    // no verdict: the instances only
+		if (lane == 0) live[wi] = 1;
+		unsigned *ib = instbuf + (size_t)wi * istride;
+		const bool give = n <= max_inst && n + 1u <= istride;
+		if (give) { WSYNC(); for (unsigned i = lane; i < n; i += 64) ib[1 + i] = (s_sel[i] << 1) | s_dir[i]; }
+		if (lane == 0) ib[0] = give ? n : BT_NONE;
+		return;
+	}
 	if (n >= 2) {
-		if (n > max_inst || n != g.lsize[0][id] + g.lsize[1][id]) r = -1;      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
+		if (n > max_inst || (!g.park_cap && n != g.lsize[0][id] + g.lsize[1][id])) r = -1;      // (with parked transactions about, the ids they erased marks of keep their dead nodes until those are through)      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
 		else { WSYNC(); r = probe_idx(g, vt, s_sel, s_dir, s_own, s_mkstep, s_mkid, walk_marks, n, lane, id, tid); }
 	}
 	if (lane == 0) {
@@ -491,9 +503,9 @@ __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigne
 	if ((g.idx_probe || snapshot) && live[wi] != PROBE_UNSERVED) return;      // decided by k_probe_idx
 	const unsigned id = g.win[wi], tid = snapshot ? 0xFFFFFFFEu : id + 1;
 	if (!snapshot && g.need[id] == 2) { if (threadIdx.x == 0) live[wi] = 1; return; }     // found live by an earlier probe and not touched since (a push resets it to 1)
-	if (threadIdx.x == 0) { t.init(g, id, wi, snapshot ? 0u : 3u, arena + (size_t)wi * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }      // (snapshot: the stamps are the previous iteration's -- no order check)
+	if (threadIdx.x == 0) { t.init(g, id, wi, snapshot ? 0u : 3u, arena + (size_t)(!snapshot && g.slice_busy && g.slice_busy[wi] ? g.shadow_base + wi : wi) * arena_bytes, arena_bytes); t.ext_stamps = true; t.fscr = fast; t.fscr_cap = sizeof fast; }      // (a slice that holds a parked transaction: the spare one, GraphView::park_of)      // (snapshot: the stamps are the previous iteration's -- no order check)
 	WSYNC();
-	wave_setup(g, t, w, true, lane, ok);
+	wave_setup<true>(g, t, w, true, lane, ok);
 	for (unsigned i = threadIdx.x; i < VT_SLOTS; i += 64 * PROBE_WAVES) { vt.key[i] = BT_NONE; vt.mask[i] = 0; }
 	WSYNC();
 	// the windows go straight into the verdict table, a batch at a time (probe_windows)

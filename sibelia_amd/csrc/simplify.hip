@@ -22,12 +22,13 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf, snap_list, snap_live;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf, snap_list, snap_live, park_of, slice_busy;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
 	DevBuf lin, elin, lmpos[2], lmid[2], cnt1k, off1k;      // linearised marks of the later snapshots
 	DevBuf flag, segidx, seg_head, seg_len, seg_succ_elem, succ[2], dist[2], newidx, ch_out, op_out;
+	hipStream_t park_stream = nullptr; hipEvent_t park_ev[2] = {nullptr, nullptr};      // k_resume beside k_commit (GraphView::park_of)
 	unsigned *h_ctr = nullptr;            // pinned, mapped: CTR_COUNT counters + the sequence number of the last post (k_select_write)
 	unsigned *d_hctr = nullptr;           // its device address
 	unsigned post_seq = 0;
@@ -336,6 +337,10 @@ struct DeviceBackend {
 	}
 	void reset_round_state(bool stamps_too)
 	{
+		if (stamps_too && g.park_cap) {                                // (start of an iteration / of a replay: nothing is parked)
+			HIP_TRY(hipMemsetAsync(st->park_of.p, 0, ((size_t)nid_ + 1) * 4, c->stream));
+			HIP_TRY(hipMemsetAsync(st->slice_busy.p, 0, park_slices, c->stream));
+		}
 		HIP_TRY(hipMemsetAsync(st->own.p, 0xFF, ((size_t)nid_ + 1) * 4, c->stream));
 		if (stamps_too) {
 			HIP_TRY(hipMemsetAsync(st->rmax.p, 0, nres * 4, c->stream));
@@ -466,14 +471,28 @@ struct DeviceBackend {
 			st->big_arena.ensure(big_arena_bytes);
 			k_commit<<<1, 64, 0, c->stream>>>(g, 1, st->big_arena.as<uint8_t>(), big_arena_bytes, 1, nullptr, nullptr, prof);
 		} else
+		{
+			// parked transactions resume beside the fresh ones: a second stream between two events (only in rounds that have any -- the
+			// counters of the previous round say so: what is parked now was parked then)
+			const bool resume = g.park_cap && st->h_ctr[CTR_PARKED] != 0;
+			if (resume) {
+				HIP_TRY(hipEventRecord(st->park_ev[0], c->stream));
+				HIP_TRY(hipStreamWaitEvent(st->park_stream, st->park_ev[0], 0));
+				k_resume<<<nwin, 64, 0, st->park_stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
+				HIP_TRY(hipEventRecord(st->park_ev[1], st->park_stream));
+			}
 			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
+			if (resume) HIP_TRY(hipStreamWaitEvent(c->stream, st->park_ev[1], 0));
+		}
 		if (sampled) HIP_TRY(hipEventRecord(ev[3], c->stream));
 		timed_commit = sampled;
 		HIP_TRY(hipGetLastError());
 	}
 	// serial chain over what is pending in the id range of the window (k_chain); timed with the commit phase
+	size_t park_slices = 0;
 	bool chain(uint32_t nwin, uint32_t round)
 	{
+		if (g.park_cap && st->h_ctr[CTR_PARKED]) return false;      // parked transactions resume in an ordered round (the chain kernel has another LDS layout)
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		st->big_arena.ensure(big_arena_bytes);
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 4;
@@ -538,11 +557,12 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->snap_list, &st->snap_live, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->snap_list, &st->snap_live, &st->park_of, &st->slice_busy, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
 	for (DevBuf *b : bufs) b->release();
+	if (st->park_stream) { (void)hipStreamDestroy(st->park_stream); for (auto &e : st->park_ev) if (e) (void)hipEventDestroy(e); }
 	if (st->h_ctr) (void)hipHostFree(st->h_ctr);
 	if (st->h_init) (void)hipHostFree(st->h_init);
 	for (auto &e : st->ev) if (e) (void)hipEventDestroy(e);
@@ -750,12 +770,17 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	// the driver widens the window up to 4x while rounds are capacity-bound (simplify_driver.h); an explicit sbl_set_window pins it
 	uint32_t window_max = c->window ? window : (uint32_t)std::min<size_t>((size_t)window * 4, std::max<size_t>(window, (48ull << 30) / be.arena_bytes));
 	window_max = std::max<uint32_t>(window, std::min<uint32_t>(window_max, be.nid_ ? be.nid_ : 1));
+	// parked transactions (GraphView::park_of): SBL_PARK=n collapses per launch and transaction (0: off)
+	unsigned park_cap = 2;                                               // (8 x 4.6 Mbp: 59.5 ms without, 56.9 with 2, 57.5 with 3, 61 with 1 -- every parked transaction costs its dependants a round)
+	if (const char *e = getenv("SBL_PARK")) park_cap = (unsigned)std::max(0, atoi(e));
+	if (c->comm || dense) park_cap = 0;                                  // (one GPU, ordered rounds)
 	auto round_buffers = [&](uint32_t w) {
 		st->win.ensure((size_t)w * 4 + 16);
-		st->arena.ensure((size_t)w * be.arena_bytes);
+		st->arena.ensure((size_t)w * be.arena_bytes * (park_cap ? 2u : 1u));      // (second half: the SHADOW slices -- where the entry of a window position works while its own slice holds a parked transaction)
 		st->claims.ensure((size_t)w * (CLAIM_CAP + 1) * 4);
 		st->live.ensure((size_t)w + 64);
 		st->instbuf.ensure((size_t)w * 129 * 4);                          // (DeviceBackend::istride() <= 129)
+		st->slice_busy.ensure((size_t)w + 64);
 	};
 	be.snap_slice = window_max;
 	try { if (!dense) round_buffers(window_max); }
@@ -785,6 +810,16 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	if (be.idx_nblk) st->bidx.ensure((size_t)be.idx_nblk * BT_IDX_WORDS * 8);
 	be.bind();
 	be.g.k = k; be.g.D = D;
+	{
+		const unsigned cap = park_cap;
+		be.g.park_cap = cap; be.g.park_of = nullptr; be.g.slice_busy = nullptr; be.g.shadow_base = 0; be.park_slices = 0;
+		if (cap) {
+			if (!st->park_stream) { HIP_TRY(hipStreamCreateWithFlags(&st->park_stream, hipStreamNonBlocking)); for (auto &e : st->park_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+			st->park_of.ensure(((size_t)be.nid_ + 1) * 4);
+			be.park_slices = (size_t)window_max + 64;
+			be.g.park_of = st->park_of.as<unsigned>(); be.g.slice_busy = st->slice_busy.as<uint8_t>(); be.g.shadow_base = window_max;
+		}
+	}
 	if (((D + k + 2u + 126u) >> 6) > 16u) be.g.idx_probe = 0;           // windows of more than 16 blocks: k_probe_idx could serve nobody (every entry walks, as before round 5)
 	be.g.test_flags = getenv("SBL_TEST_FLAGS") ? (unsigned)atoi(getenv("SBL_TEST_FLAGS")) : 0u;
 	be.g.lazy_rescan = getenv("SBL_EAGER_RESCAN") ? 0u : 1u;            // measurement switch: dirty windows rescanned right after every collapse (round 3)

@@ -144,6 +144,7 @@ __device__ __forceinline__ unsigned wave_list_positions(const GraphView &g, unsi
 	});
 }
 // bt_setup with the positions listed by all lanes; `ok` lives in LDS
+template <bool PARK_AWARE = false>
 __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork &w, bool lite, unsigned lane, int &ok)
 {
 	const unsigned h0 = g.head[0][t.id], h1 = g.head[1][t.id];              // in flight while lane 0 lays the scratch out
@@ -151,7 +152,12 @@ __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork
 	WSYNC();
 	if (!ok) return false;
 	unsigned m = wave_list_positions(g, h0, h1, w, lane);
-	if (m != w.n && lane == 0) { t.err |= BT_ERR_SCRATCH; ok = 0; }          // cannot happen on a consistent graph
+	if (m != w.n && lane == 0) {
+		// (list sizes = live nodes between transactions -- except around a PARKED transaction, GraphView::park_of: the nodes it erased stay
+		// in their lists, counted, until it is through (Cleanup, bifurcationstorage.cpp:33-41, belongs to the end of RemoveBulges))
+		if (PARK_AWARE && g.park_cap && m < w.n) { w.n = m; if (m < 2) ok = 0; }      // (the probes of the ordered rounds: nothing is parked when a snapshot runs)
+		else { t.err |= BT_ERR_SCRATCH; ok = 0; }                         // cannot happen on a consistent graph
+	}
 	WSYNC();
 	return ok != 0;
 }
