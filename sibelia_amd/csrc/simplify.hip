@@ -771,7 +771,13 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	uint32_t window_max = c->window ? window : (uint32_t)std::min<size_t>((size_t)window * 4, std::max<size_t>(window, (48ull << 30) / be.arena_bytes));
 	window_max = std::max<uint32_t>(window, std::min<uint32_t>(window_max, be.nid_ ? be.nid_ : 1));
 	// parked transactions (GraphView::park_of): SBL_PARK=n collapses per launch and transaction (0: off)
-	unsigned park_cap = 2;                                               // (8 x 4.6 Mbp: 59.5 ms without, 56.9 with 2, 57.5 with 3, 61 with 1 -- every parked transaction costs its dependants a round)
+	// (8 x 4.6 Mbp: 59.5 ms without, 56.9 with 2, 57.5 with 3, 61 with 1 -- every parked transaction costs its dependants a round; 62 strains,
+	// where an id has dozens of instances and a transaction up to 28 collapses: 2.44 s without, 2.36 with 2, 2.18 with 3, 2.135 with 4, 2.15 with 5.
+	// But ids with dozens of instances are also the regime of the serial chain -- one or two transactions per round, which chain() does not
+	// enter while anything is parked, and something always is when every transaction parks seven times: 57 strains x 8 kbp at D = 369 took
+	// 17 734 rounds, 238 s instead of seconds (tools/stress.py MANY=1, seed 67000; still exact).  Until chain() makes parking stop, it is OFF
+	// by default there; SBL_PARK=4 is what the 2.15 s of profiles/r05_bench_config4.json were measured with.)
+	unsigned park_cap = ninst > 12 * (size_t)std::max<uint32_t>(1, be.nid_) ? 0u : 2u;
 	if (const char *e = getenv("SBL_PARK")) park_cap = (unsigned)std::max(0, atoi(e));
 	if (c->comm || dense) park_cap = 0;                                  // (one GPU, ordered rounds)
 	auto round_buffers = [&](uint32_t w) {
