@@ -44,7 +44,7 @@ enum { CTR_STRIDE = 32,
        CTR_NE = 0 * CTR_STRIDE, CTR_NN = 1 * CTR_STRIDE, CTR_ERR = 2 * CTR_STRIDE, CTR_BULGES = 3 * CTR_STRIDE, CTR_VIOL = 4 * CTR_STRIDE,
        CTR_NWIN = 5 * CTR_STRIDE, CTR_LO = 6 * CTR_STRIDE, CTR_COMMITTED = 7 * CTR_STRIDE, CTR_BIG = 8 * CTR_STRIDE, CTR_PUSHED = 9 * CTR_STRIDE,
        CTR_TXN = 10 * CTR_STRIDE, CTR_DETAIL = 11 * CTR_STRIDE, CTR_COUNT = 12 * CTR_STRIDE };
-enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4 };
+enum { BT_ERR_SCRATCH = 1, BT_ERR_ELEM_CAP = 2, BT_ERR_NODE_CAP = 4, BT_ERR_LAYOUT = 8 /* a parked image from another LDS layout (commit.hip: park_load) */ };
 
 // optional cycle counters of the decision loops (simplify.hip defines them for SBL_PHASES=1; nothing elsewhere)
 #ifndef BT_PROF_ADD
@@ -104,8 +104,16 @@ struct GraphView {
 	// position w holds a parked transaction; the entry at that position works in the shadow slice shadow_base + w (and does not park: it
 	// may be a LOWER id that the parked one has to wait for).  park_cap = 0: off.
 	uint32_t *park_of; uint8_t *slice_busy; uint32_t park_cap, shadow_base;      // (shadow_base + w: the spare slice of window position w)
+	// Round 6: park_hold != 0 -- nothing NEW parks (the driver has asked for the serial chain, which starts once what is parked has drained;
+	// parked transactions still resume, and run to their end).  any_parked != 0 -- something was parked when this launch started (the host
+	// knows from the counters of the round before): only then may a list hold fewer live nodes than its size says (the deferred Cleanup
+	// of a parked transaction); otherwise that is list corruption and stays a hard error.  park_list: window positions of the parked
+	// entries of this round (appended by k_reserve, ctr[CTR_PLIST] of them): k_resume's grid is the parked transactions, not the window.
+	uint32_t park_hold, any_parked; uint32_t *park_list;
 };
 #define CTR_PARKED (CTR_DETAIL + 8)      // parked transactions at the moment
+#define CTR_PLIST (CTR_DETAIL + 10)      // entries of GraphView::park_list in this round (reset behind every round by k_select_write)
+// (the tag is 11 bits of a 12-bit round: finished markers are swept every 1024 rounds, DeviceBackend::commit, so that none survives to the round with the same tag)
 __host__ __device__ __forceinline__ uint32_t bt_round_tag(const GraphView &g) { return (g.round_bits >> 20) & 0x7FFu; }
 __host__ __device__ __forceinline__ bool bt_parked(const GraphView &g, uint32_t id) { if (!g.park_of) return false; const uint32_t pk = g.park_of[id]; return pk != 0 && !(pk >> 31); }
 

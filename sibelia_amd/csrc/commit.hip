@@ -1126,11 +1126,16 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 #endif
 // ---- parked transactions (GraphView::park_of): the LDS state of a transaction at the end of its arena slice
 #define PARK_IMG 12288u
+// The image holds raw LDS addresses (t.fscr, the w.* arrays laid out in `fast`, absh.skey / sval): it is only valid in a kernel that
+// places t, w, absh and fast where the parking kernel had them.  k_commit and k_resume instantiate the same declarations
+// (commit_kernel), so they do; the image records the four addresses and park_load refuses (BT_ERR_LAYOUT) an image from another layout.
+#define PARK_OFF_LAYOUT (PARK_IMG - 16u)
 #define PARK_OFF_W ((unsigned)((sizeof(Txn) + 15u) & ~15u))
 #define PARK_OFF_AB (PARK_OFF_W + (unsigned)((sizeof(BulgeWork) + 15u) & ~15u))
 #define PARK_OFF_FAST (PARK_OFF_AB + (unsigned)((sizeof(ABShared) + 15u) & ~15u))
 static_assert(sizeof(Txn) % 4 == 0 && sizeof(BulgeWork) % 4 == 0 && sizeof(ABShared) % 4 == 0, "park_move copies words");
-static_assert(PARK_OFF_FAST + COMMIT_FAST_BYTES <= PARK_IMG, "the LDS image of a transaction must fit PARK_IMG");
+static_assert(PARK_OFF_FAST + COMMIT_FAST_BYTES <= PARK_OFF_LAYOUT, "the LDS image of a transaction must fit PARK_IMG");
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 __device__ __forceinline__ void park_move(unsigned *dst, const unsigned *src, unsigned words, unsigned lane) { for (unsigned i = lane; i < words; i += 64) dst[i] = src[i]; }
 __device__ __forceinline__ void park_store(const GraphView &g, Txn &t, BulgeWork &w, ABShared &absh, uint8_t *fast, unsigned fast_bytes, uint8_t *image, unsigned id, unsigned slice)
 {
@@ -1140,12 +1145,21 @@ __device__ __forceinline__ void park_store(const GraphView &g, Txn &t, BulgeWork
 	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_W), reinterpret_cast<const unsigned *>(&w), sizeof(BulgeWork) / 4, lane);
 	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_AB), reinterpret_cast<const unsigned *>(&absh), sizeof(ABShared) / 4, lane);
 	park_move(reinterpret_cast<unsigned *>(image + PARK_OFF_FAST), reinterpret_cast<const unsigned *>(fast), fast_bytes / 4, lane);
-	if (lane == 0) { g.park_of[id] = (slice + 1u) | (bt_round_tag(g) << 20); g.slice_busy[slice] = 1; g.need[id] = 2; atomicAdd(&g.ctr[CTR_PARKED], 1u); }
+	if (lane == 0) {
+		unsigned *lay = reinterpret_cast<unsigned *>(image + PARK_OFF_LAYOUT);
+		lay[0] = lds_addr(&t); lay[1] = lds_addr(&w); lay[2] = lds_addr(&absh); lay[3] = lds_addr(fast);
+		g.park_of[id] = (slice + 1u) | (bt_round_tag(g) << 20); g.slice_busy[slice] = 1; g.need[id] = 2; atomicAdd(&g.ctr[CTR_PARKED], 1u);
+	}
 }
 // ... and back; what belongs to the round (the graph view with its round stamp, the claim stamp) is renewed
-__device__ __forceinline__ void park_load(const GraphView &g, Txn &t, BulgeWork &w, ABShared &absh, uint8_t *fast, unsigned fast_bytes, const uint8_t *image, unsigned id, unsigned wi, int prof)
+__device__ __forceinline__ bool park_load(const GraphView &g, Txn &t, BulgeWork &w, ABShared &absh, uint8_t *fast, unsigned fast_bytes, const uint8_t *image, unsigned id, unsigned wi, int prof)
 {
 	const unsigned lane = threadIdx.x;
+	{
+		const unsigned *lay = reinterpret_cast<const unsigned *>(image + PARK_OFF_LAYOUT);
+		const bool same = lay[0] == lds_addr(&t) && lay[1] == lds_addr(&w) && lay[2] == lds_addr(&absh) && lay[3] == lds_addr(fast);
+		if (!same) { if (lane == 0) atomicOr(&g.ctr[CTR_ERR], BT_ERR_LAYOUT); return false; }      // (uniform: one wave, the same four words)
+	}
 	park_move(reinterpret_cast<unsigned *>(&t), reinterpret_cast<const unsigned *>(image), sizeof(Txn) / 4, lane);
 	park_move(reinterpret_cast<unsigned *>(&w), reinterpret_cast<const unsigned *>(image + PARK_OFF_W), sizeof(BulgeWork) / 4, lane);
 	park_move(reinterpret_cast<unsigned *>(&absh), reinterpret_cast<const unsigned *>(image + PARK_OFF_AB), sizeof(ABShared) / 4, lane);
@@ -1153,6 +1167,7 @@ __device__ __forceinline__ void park_load(const GraphView &g, Txn &t, BulgeWork 
 	WSYNC();
 	if (lane == 0) { t.g = g; t.stamp = g.round_bits | wi; t.prof = prof != 0; w.ret0 = w.ret - 1; atomicSub(&g.ctr[CTR_PARKED], 1u); }      // (ret0: the collapse it parked with belongs to this launch)
 	WSYNC();
+	return true;
 }
 // The transaction proper (RemoveBulges for one id) on one wave; t, w, flag, absh and fast live in LDS.
 // solo: 0 = ordered round (the probe found bulges, the entry owns its claims), 1 = the id runs with nothing else in flight
@@ -1171,7 +1186,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 	// ---- the probe of this round found bulges (solo entries were not probed: verdict pass first)
 	if (lane == 0) { g.need[id] = 0; g.touch[id] = 1; flag = 1; }
 	if (RESUME) {                                                     // the state it parked with; what belongs to the round is renewed
-		park_load(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, wi, prof);
+		if (!park_load(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, wi, prof)) return;      // (an image of another LDS layout: CTR_ERR, the stage ends with an internal error)
 		if (lane == 0) flag = 1;
 		WSYNC();
 	} else {
@@ -1208,7 +1223,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 		if (flag) {
 			const unsigned m = wave_list_positions(g, h0, h1, w, lane);
 			if (m != w.n && lane == 0) {
-				if (g.park_cap && m < w.n) { w.n = m; if (m < 2) flag = 0; }      // (nodes erased by a parked transaction: see wave_setup)
+				if (t.g.any_parked && m < w.n) { w.n = m; if (m < 2) flag = 0; }      // (nodes erased by a parked transaction: see wave_setup)
 				else { t.err |= BT_ERR_SCRATCH; flag = 0; }                   // cannot happen on a consistent graph
 			}
 			WSYNC();
@@ -1267,7 +1282,7 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			}
 			decided = false;
 			// ---- a collapse has been decided (c_src -> c_tgt).  Enough of them for one launch: park (GraphView::park_of)
-			if (can_park && !w.lazy && w.ret - w.ret0 > g.park_cap) {      // (ret counts the collapse just decided)
+			if (can_park && !t.g.park_hold && !w.lazy && w.ret - w.ret0 > g.park_cap) {      // (ret counts the collapse just decided; park_hold: the driver waits for what is parked to drain -- read from the LDS copy of the view: one more live kernel argument tipped k_commit's scratch from 232 to 584 B)
 				park_store(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, park_slice);      // (arena_bytes: already without the image)
 				return;                                                    // (no Cleanup, no counters: the transaction is not over)
 			}
@@ -1408,8 +1423,13 @@ __device__ __forceinline__ void commit_kernel(const GraphView &g, unsigned nwin,
 	__shared__ int flag;
 	__shared__ ABShared absh;
 	__shared__ __attribute__((aligned(16))) uint8_t fast[COMMIT_FAST_BYTES];     // window summaries, mark lists, FillVisit list and AnyBulges map of typical ids
-	const unsigned wi = blockIdx.x, lane = threadIdx.x;
+	unsigned wi = blockIdx.x;
+	const unsigned lane = threadIdx.x;
 	if (!RESUME_KERNEL) round_stamp(g, 2);
+	if (RESUME_KERNEL) {                                              // one workgroup per parked entry of the window (GraphView::park_list, filled by k_reserve)
+		if (wi >= __builtin_amdgcn_readfirstlane((int)g.ctr[CTR_PLIST])) return;
+		wi = (unsigned)__builtin_amdgcn_readfirstlane((int)g.park_list[wi]);
+	}
 	if (wi >= nwin) return;
 	if (!solo && !live[wi]) return;                                   // retired by the probe
 	const unsigned id = g.win[wi], stampv = g.round_bits | wi;
@@ -1463,6 +1483,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_resume(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, const unsigned *claims, const uint8_t *live, int prof_every)
 {
 	commit_kernel<true>(g, nwin, arena, arena_bytes, 0, claims, live, prof_every);
+}
+
+// finished markers of park_of (bit 31 | round tag) are only read in the round they were written in; the tag is 11 bits of a 12-bit round,
+// so they are swept before a round with the same tag comes round again (DeviceBackend::commit, every 1024 rounds)
+__global__ void __launch_bounds__(256) k_park_sweep(unsigned *__restrict__ park_of, unsigned n)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && (park_of[i] >> 31)) park_of[i] = 0u;
 }
 
 // Serial chain: one wave runs what is pending in the id range of the window strictly in ascending order, one transaction

@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, ui
 		return;
 	}
 	if (n >= 2) {
-		if (n > max_inst || (!g.park_cap && n != g.lsize[0][id] + g.lsize[1][id])) r = -1;      // (with parked transactions about, the ids they erased marks of keep their dead nodes until those are through)      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
+		if (n > max_inst || (!g.any_parked && n != g.lsize[0][id] + g.lsize[1][id])) r = -1;      // (with parked transactions about, the ids they erased marks of keep their dead nodes until those are through)      // (lists are clean between rounds: live nodes = list sizes; anything else is the walking path's to report)
 		else { WSYNC(); r = probe_idx(g, vt, s_sel, s_dir, s_own, s_mkstep, s_mkid, walk_marks, n, lane, id, tid); }
 	}
 	if (lane == 0) {
@@ -681,6 +681,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
 		__syncthreads();
 		if (threadIdx.x == 0) { post[CTR_COUNT] = post_seq; __threadfence_system(); }
 	}
+	if (s_last && threadIdx.x == 0) g.ctr[CTR_PLIST] = 0;              // (the list of parked window entries is per round: k_reserve appends, k_resume reads)
 }
 
 // ---- the reservation walks of an instance from the BLOCK INDEX (round 5) ------------------------------------------------------------
@@ -822,6 +823,7 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	unsigned *const my_list = rsv_dyn + (1u << seen_bits) + (size_t)(threadIdx.x >> 6) * list_cap;      // the marked slots of a group of instances, compacted (reserve_idx_emit)
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
+	if (g.park_list && threadIdx.x == 0 && bt_parked(g, id)) g.park_list[atomicAdd(&g.ctr[CTR_PLIST], 1u)] = w;      // k_resume's work list: the parked entries of this window
 	// the instances: handed over by the probe of this round (k_probe_idx: one coalesced read), or ListPositions by 64 lanes (wave_list_nodes)
 	const unsigned given = instbuf ? instbuf[(size_t)w * istride] : BT_NONE;
 	if (given != BT_NONE && given <= RESUME_SLOTS) {

@@ -22,7 +22,7 @@ struct SimplifyState {
 	DevBuf ch, op, nx, pv, nodeof[2];
 	DevBuf nslot, nnext, nidst, nclr, ndead, head[2], lsize[2];
 	DevBuf ctr, need, big, touch, ck_touch, own, lock, rmax, wmax, win;
-	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf, snap_list, snap_live, park_of, slice_busy;
+	DevBuf arena, snap_arena, big_arena, claims, live, robuf, bidx, instbuf, snap_list, snap_live, park_of, slice_busy, park_list;
 	DevBuf ck_ch, ck_op, ck_nx, ck_pv, ck_bif[2], ck_nodeof[2], ck_nslot, ck_nnext, ck_ndead, ck_head[2], ck_lsize[2];
 	DevBuf keys, skeys, selem, sorttmp, scantmp, perm, permin;
 	DevBuf nmark, maux[2], iota, sel, tstamp;
@@ -157,6 +157,7 @@ struct DeviceBackend {
 		HIP_TRY(hipMemcpyAsync(st->ctr.as<unsigned>() + CTR_NN, &v[1], 4, hipMemcpyHostToDevice, c->stream));
 		index_build();                                              // (the block index is derived state: rebuilt from the restored arrays)
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		parked_known = 0;                                           // (reset_round_state clears the device side before the first round)
 	}
 	// segment ranking of the current list (shared with the copy-back): returns the list length, leaves flag / segidx / seg_head / dist[cur] filled
 	unsigned long long rank_segments(unsigned ne, int *cur_out)
@@ -340,6 +341,7 @@ struct DeviceBackend {
 		if (stamps_too && g.park_cap) {                                // (start of an iteration / of a replay: nothing is parked)
 			HIP_TRY(hipMemsetAsync(st->park_of.p, 0, ((size_t)nid_ + 1) * 4, c->stream));
 			HIP_TRY(hipMemsetAsync(st->slice_busy.p, 0, park_slices, c->stream));
+			parked_known = 0; g.park_hold = 0;
 		}
 		HIP_TRY(hipMemsetAsync(st->own.p, 0xFF, ((size_t)nid_ + 1) * 4, c->stream));
 		if (stamps_too) {
@@ -423,6 +425,7 @@ struct DeviceBackend {
 	void probe(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
+		g.any_parked = parked_known != 0;                            // (exact: nothing parks or resumes between the counters of the round before and this launch)
 		begin_round();
 		solo_round = false;
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
@@ -447,7 +450,7 @@ struct DeviceBackend {
 		HIP_TRY(hipGetLastError());
 	}
 	bool solo_round = false;                                          // the current round skipped the probe (mark_live): no instance hand-over
-	void mark_live(uint32_t nwin) { begin_round(); solo_round = true; HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
+	void mark_live(uint32_t nwin) { g.any_parked = parked_known != 0; begin_round(); solo_round = true; HIP_TRY(hipMemsetAsync(st->live.p, 1, nwin, c->stream)); }
 	void reserve(uint32_t nwin, uint32_t round)
 	{
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
@@ -474,11 +477,13 @@ struct DeviceBackend {
 		{
 			// parked transactions resume beside the fresh ones: a second stream between two events (only in rounds that have any -- the
 			// counters of the previous round say so: what is parked now was parked then)
-			const bool resume = g.park_cap && st->h_ctr[CTR_PARKED] != 0;
+			const bool resume = g.park_cap && parked_known != 0;
+			if (g.park_cap && (round & 1023u) == 0u) k_park_sweep<<<nblocks((size_t)nid_ + 1, 256), 256, 0, c->stream>>>(st->park_of.as<unsigned>(), nid_ + 1);      // (bt_round_tag)
 			if (resume) {
+				// one workgroup per parked transaction at most (k_reserve has listed those of this window: GraphView::park_list)
 				HIP_TRY(hipEventRecord(st->park_ev[0], c->stream));
 				HIP_TRY(hipStreamWaitEvent(st->park_stream, st->park_ev[0], 0));
-				k_resume<<<nwin, 64, 0, st->park_stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
+				k_resume<<<std::min<uint32_t>(parked_known, nwin), 64, 0, st->park_stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
 				HIP_TRY(hipEventRecord(st->park_ev[1], st->park_stream));
 			}
 			k_commit<<<nwin, 64, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, 0, st->claims.as<unsigned>(), st->live.as<uint8_t>(), prof);
@@ -490,9 +495,12 @@ struct DeviceBackend {
 	}
 	// serial chain over what is pending in the id range of the window (k_chain); timed with the commit phase
 	size_t park_slices = 0;
+	uint32_t parked_known = 0;                                        // ctr[CTR_PARKED] as of the last counters(): transactions parked when the next launches start
 	bool chain(uint32_t nwin, uint32_t round)
 	{
-		if (g.park_cap && st->h_ctr[CTR_PARKED]) return false;      // parked transactions resume in an ordered round (the chain kernel has another LDS layout)
+		// parked transactions resume in an ordered round (the chain kernel has another LDS layout): the driver has asked for the chain, so
+		// nothing NEW parks from here on (GraphView::park_hold) -- what is parked runs to its end in the next rounds and the chain starts then
+		if (g.park_cap && parked_known) { g.park_hold = 1; return false; }
 		g.round_bits = (SS_ROUND_MAX - round) << 20;
 		st->big_arena.ensure(big_arena_bytes);
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 4;
@@ -514,6 +522,7 @@ struct DeviceBackend {
 		}
 		SimplifyCounters r;
 		memcpy(r.v, st->h_ctr, sizeof r.v);
+		parked_known = r.v[CTR_PARKED];
 		return r;
 	}
 	bool grow(uint32_t err)
@@ -557,7 +566,7 @@ void sbl_simplify_free(sbl_ctx *c)
 	if (!st) return;
 	DevBuf *bufs[] = { &st->ch, &st->op, &st->nx, &st->pv, &st->nodeof[0], &st->nodeof[1], &st->nslot, &st->nnext, &st->nidst, &st->nclr, &st->ndead,
 	                   &st->head[0], &st->head[1], &st->lsize[0], &st->lsize[1], &st->ctr, &st->need, &st->big, &st->touch, &st->ck_touch, &st->own, &st->lock, &st->rmax, &st->wmax, &st->win,
-	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->snap_list, &st->snap_live, &st->park_of, &st->slice_busy, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
+	                   &st->arena, &st->snap_arena, &st->big_arena, &st->claims, &st->live, &st->robuf, &st->bidx, &st->instbuf, &st->snap_list, &st->snap_live, &st->park_of, &st->slice_busy, &st->park_list, &st->ck_ch, &st->ck_op, &st->ck_nx, &st->ck_pv, &st->ck_bif[0], &st->ck_bif[1],
 	                   &st->ck_nodeof[0], &st->ck_nodeof[1], &st->ck_nslot, &st->ck_nnext, &st->ck_ndead, &st->ck_head[0], &st->ck_head[1], &st->ck_lsize[0], &st->ck_lsize[1],
 	                   &st->lin, &st->elin, &st->lmpos[0], &st->lmpos[1], &st->lmid[0], &st->lmid[1], &st->cnt1k, &st->off1k, &st->sel, &st->tstamp, &st->nmark, &st->maux[0], &st->maux[1], &st->iota, &st->keys, &st->skeys, &st->selem, &st->sorttmp, &st->scantmp, &st->perm, &st->permin, &st->flag, &st->segidx, &st->seg_head, &st->seg_len, &st->seg_succ_elem,
 	                   &st->succ[0], &st->succ[1], &st->dist[0], &st->dist[1], &st->newidx, &st->ch_out, &st->op_out };
@@ -777,9 +786,12 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	// enter while anything is parked, and something always is when every transaction parks seven times: 57 strains x 8 kbp at D = 369 took
 	// 17 734 rounds, 238 s instead of seconds (tools/stress.py MANY=1, seed 67000; still exact).  Until chain() makes parking stop, it is OFF
 	// by default there; SBL_PARK=4 is what the 2.15 s of profiles/r05_bench_config4.json were measured with.)
-	unsigned park_cap = ninst > 12 * (size_t)std::max<uint32_t>(1, be.nid_) ? 0u : 2u;
+	// Round 6: the serial chain and parking compose (DeviceBackend::chain stops NEW parking, what is parked drains), so the many-instances
+	// regime parks too -- with the cap that was measured best there (4: 2.135 s at 62 strains against 2.36 with 2) -- and so do the
+	// replicated commits of a job on several GPUs (SBL_PARK_COMM=0: debugging switch, the round-5 behaviour).
+	unsigned park_cap = ninst > 12 * (size_t)std::max<uint32_t>(1, be.nid_) ? 4u : 2u;
 	if (const char *e = getenv("SBL_PARK")) park_cap = (unsigned)std::max(0, atoi(e));
-	if (c->comm || dense) park_cap = 0;                                  // (one GPU, ordered rounds)
+	if (dense || (c->comm && getenv("SBL_PARK_COMM") && atoi(getenv("SBL_PARK_COMM")) == 0)) park_cap = 0;
 	auto round_buffers = [&](uint32_t w) {
 		st->win.ensure((size_t)w * 4 + 16);
 		st->arena.ensure((size_t)w * be.arena_bytes * (park_cap ? 2u : 1u));      // (second half: the SHADOW slices -- where the entry of a window position works while its own slice holds a parked transaction)
@@ -787,15 +799,24 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		st->live.ensure((size_t)w + 64);
 		st->instbuf.ensure((size_t)w * 129 * 4);                          // (DeviceBackend::istride() <= 129)
 		st->slice_busy.ensure((size_t)w + 64);
+		st->park_list.ensure((size_t)w * 4 + 64);
 	};
 	be.snap_slice = window_max;
-	try { if (!dense) round_buffers(window_max); }
-	catch (const SblError &) {                                        // a smaller or partly occupied GPU: the pinned window always was enough
-		if (window_max == window) throw;
-		(void)hipGetLastError();
-		window_max = window;
-		be.snap_slice = window;
-		round_buffers(window);
+	if (!dense) {
+		// a smaller or partly occupied GPU: first without the shadow slices (parking is a ~5 % optimisation, a 4 x smaller window is not),
+		// then with the pinned window, which always was enough
+		try { round_buffers(window_max); }
+		catch (const SblError &) {
+			(void)hipGetLastError();
+			bool ok = false;
+			if (park_cap) { park_cap = 0; try { round_buffers(window_max); ok = true; } catch (const SblError &) { (void)hipGetLastError(); } }
+			if (!ok) {
+				if (window_max == window) throw;
+				window_max = window;
+				be.snap_slice = window;
+				round_buffers(window);
+			}
+		}
 	}
 	for (auto &e : st->ev) if (!e) HIP_TRY(hipEventCreate(&e));
 	be.ev = st->ev;
@@ -819,11 +840,13 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	{
 		const unsigned cap = park_cap;
 		be.g.park_cap = cap; be.g.park_of = nullptr; be.g.slice_busy = nullptr; be.g.shadow_base = 0; be.park_slices = 0;
+		be.g.park_hold = 0; be.g.any_parked = 0; be.g.park_list = nullptr;
 		if (cap) {
 			if (!st->park_stream) { HIP_TRY(hipStreamCreateWithFlags(&st->park_stream, hipStreamNonBlocking)); for (auto &e : st->park_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
 			st->park_of.ensure(((size_t)be.nid_ + 1) * 4);
 			be.park_slices = (size_t)window_max + 64;
 			be.g.park_of = st->park_of.as<unsigned>(); be.g.slice_busy = st->slice_busy.as<uint8_t>(); be.g.shadow_base = window_max;
+			be.g.park_list = st->park_list.as<unsigned>();
 		}
 	}
 	if (((D + k + 2u + 126u) >> 6) > 16u) be.g.idx_probe = 0;           // windows of more than 16 blocks: k_probe_idx could serve nobody (every entry walks, as before round 5)

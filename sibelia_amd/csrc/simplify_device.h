@@ -155,7 +155,7 @@ __device__ __forceinline__ bool wave_setup(const GraphView &g, Txn &t, BulgeWork
 	if (m != w.n && lane == 0) {
 		// (list sizes = live nodes between transactions -- except around a PARKED transaction, GraphView::park_of: the nodes it erased stay
 		// in their lists, counted, until it is through (Cleanup, bifurcationstorage.cpp:33-41, belongs to the end of RemoveBulges))
-		if (PARK_AWARE && g.park_cap && m < w.n) { w.n = m; if (m < 2) ok = 0; }      // (the probes of the ordered rounds: nothing is parked when a snapshot runs)
+		if (PARK_AWARE && g.any_parked && m < w.n) { w.n = m; if (m < 2) ok = 0; }      // (the probes of the ordered rounds: nothing is parked when a snapshot runs)
 		else { t.err |= BT_ERR_SCRATCH; ok = 0; }                         // cannot happen on a consistent graph
 	}
 	WSYNC();

@@ -5,25 +5,43 @@ default, 3) leaves the state the oracle leaves.  The workloads have multi-collap
 the same place), indels (non-pristine blocks, deferred Cleanup visible to the probes of neighbouring ids), many chromosomes, wide
 windows (the walking probe for every entry: the arena slice of a parked transaction must survive it), replays with checkpoints, and
 the many-instances regime (mark lists and AnyBulges tables in the arena)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(seqs, stages):
+def _run(seqs, stages, ranks=0):
+    """ranks > 0: the same job on that many virtual ranks of device 0 (sharded enumeration, split probes, REPLICATED commits: every rank
+    parks and resumes the same transactions)"""
     from sibelia_amd import BlockFinder
-    bf = BlockFinder(seqs, device=0)
+    if ranks:
+        from sibelia_amd.dist import LocalShardedFinder
+        bf = LocalShardedFinder(seqs, [0] * ranks)
+    else:
+        bf = BlockFinder(seqs, device=0)
     try:
         out = []
         for k, D in stages:
             n = bf.simplify_stage(k, D, 4)
             st = bf.stats()
+            if ranks:
+                assert len({int(x["rounds"]) for x in st}) == 1, "the ranks took different numbers of rounds"
+                st = st[0]
             seq, pos = bf.state()
             out.append((n, int(st["rounds"]), seq, pos))
         return out
     finally:
         bf.close()
+
+
+def _bounded_rounds(parked, plain, what):
+    """parking trades rounds for shorter launches; a setting that multiplies the rounds is the livelock of round 5 (17 734 rounds where the
+    serial chain would not start while anything was parked), not a trade"""
+    for a, b in zip(parked, plain):
+        assert a[1] <= 4 * max(b[1], 8), "%s: %d rounds with parking against %d without" % (what, a[1], b[1])
 
 
 def _same_state(a, b, what):
@@ -57,6 +75,23 @@ def test_parking_changes_nothing(monkeypatch, k, D):
         _same_state(a, ref, "SBL_PARK=" + cap)
         rounds[cap] = a[0][1]
     assert rounds["1"] > rounds["0"], "SBL_PARK=1 parked nothing (%s): the test does not exercise what it is for" % rounds
+    assert max(rounds.values()) <= 4 * rounds["0"], "parking multiplied the rounds: %s" % rounds
+
+
+@pytest.mark.parametrize("k,D", [(25, 150), (15, 60)])
+def test_parking_changes_nothing_on_three_virtual_ranks(monkeypatch, k, D):
+    """round 5 switched parking off whenever a communicator was attached (the virtual-rank cases crashed); it is on everywhere now"""
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=120_000, n=8, seed=41, snp=0.03, inv_min=1000, inv_max=6000)
+    ref = _oracle(seqs, [(k, D)])
+    rounds = {}
+    for cap in ("0", "1", "2"):
+        monkeypatch.setenv("SBL_PARK", cap)
+        a = _run(seqs, [(k, D)], ranks=3)
+        _same_state(a, ref, "three ranks, SBL_PARK=" + cap)
+        rounds[cap] = a[0][1]
+    assert rounds["1"] > rounds["0"], "SBL_PARK=1 parked nothing on three ranks (%s)" % rounds
+    assert max(rounds.values()) <= 4 * rounds["0"], "parking multiplied the rounds: %s" % rounds
 
 
 def test_parking_over_a_cascade_with_many_chromosomes(monkeypatch):
@@ -71,9 +106,13 @@ def test_parking_over_a_cascade_with_many_chromosomes(monkeypatch):
             seqs.append(s[p:q]); p = q
     stages = [(22, 100), (25, 150), (30, 150)]
     ref = _oracle(seqs, stages)
+    monkeypatch.setenv("SBL_PARK", "0")
+    plain = _run(seqs, stages)
     for cap in ("1", "2"):
         monkeypatch.setenv("SBL_PARK", cap)
-        _same_state(_run(seqs, stages), ref, "cascade, SBL_PARK=" + cap)
+        a = _run(seqs, stages)
+        _same_state(a, ref, "cascade, SBL_PARK=" + cap)
+        _bounded_rounds(a, plain, "cascade, SBL_PARK=" + cap)
 
 
 def test_parking_with_walking_probes_and_reservations(monkeypatch):
@@ -82,9 +121,13 @@ def test_parking_with_walking_probes_and_reservations(monkeypatch):
     seqs = W.gen_strains(L0=100_000, n=6, seed=13, snp=0.03, inv_min=1000, inv_max=4000)
     ref = _oracle(seqs, [(25, 150)])
     monkeypatch.setenv("SBL_NO_BLOCK_INDEX", "1")
+    monkeypatch.setenv("SBL_PARK", "0")
+    plain = _run(seqs, [(25, 150)])
     for cap in ("1", "2"):
         monkeypatch.setenv("SBL_PARK", cap)
-        _same_state(_run(seqs, [(25, 150)]), ref, "walking probes, SBL_PARK=" + cap)
+        a = _run(seqs, [(25, 150)])
+        _same_state(a, ref, "walking probes, SBL_PARK=" + cap)
+        _bounded_rounds(a, plain, "walking probes, SBL_PARK=" + cap)
 
 
 def test_parking_survives_checkpointed_replays(monkeypatch):
@@ -100,6 +143,63 @@ def test_parking_with_dozens_of_instances(monkeypatch):
     from sibelia_amd import workloads as W
     seqs = W.gen_strains(L0=8_000, n=48, seed=5, inv_min=100, inv_max=400)
     ref = _oracle(seqs, [(25, 150)])
+    monkeypatch.setenv("SBL_PARK", "0")
+    plain = _run(seqs, [(25, 150)])
+    for cap in ("1", "2", "4"):
+        monkeypatch.setenv("SBL_PARK", cap)
+        a = _run(seqs, [(25, 150)])
+        _same_state(a, ref, "48 strains, SBL_PARK=" + cap)
+        _bounded_rounds(a, plain, "48 strains, SBL_PARK=" + cap)
+
+
+def _stress_case(seed, many):
+    """the case tools/stress.py draws for `seed` (MANY=1: 30 - 70 strains of a few kbp)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress
+    return stress.draw_case(seed, many=many)[:2]
+
+
+def test_the_serial_chain_starts_although_transactions_are_parked(monkeypatch):
+    """tools/stress.py MANY=1, seed 67000 (57 strains x 8 kbp, k = 31, D = 369): dense conflict neighbourhoods, the serial chain's regime.
+    Round 5: chain() refused while anything was parked and every transaction parked several times -- 17 734 rounds, 238 s (exact).
+    Now the driver's request for the chain stops NEW parking (GraphView::park_hold), what is parked drains, the chain starts."""
+    import time
+    seqs, stages = _stress_case(67000, True)
+    ref = _oracle(seqs, stages)
+    for cap in ("2", "4", None):                       # None: the default of this regime
+        if cap is None:
+            monkeypatch.delenv("SBL_PARK", raising=False)
+        else:
+            monkeypatch.setenv("SBL_PARK", cap)
+        t0 = time.time()
+        a = _run(seqs, stages)
+        dt = time.time() - t0
+        _same_state(a, ref, "seed 67000, SBL_PARK=%s" % cap)
+        assert all(x[1] < 300 for x in a), "seed 67000, SBL_PARK=%s: %s rounds" % (cap, [x[1] for x in a])
+        assert dt < 10.0, "seed 67000, SBL_PARK=%s: %.1f s" % (cap, dt)
+
+
+def test_parking_in_a_dense_low_complexity_graph_with_few_instances_per_id(monkeypatch):
+    """at most a dozen instances per id (round 5's fence `instances > 12 ids` did not cover it) but dense conflict neighbourhoods: a few
+    strains of low-complexity sequence at a small k -- chain mode with parking on"""
+    rng = np.random.default_rng(77)
+    unit = rng.integers(0, 4, 400)
+    base = np.concatenate([unit if rng.random() < 0.7 else rng.integers(0, 4, 400) for _ in range(60)])
+    seqs = []
+    for s in range(5):
+        g = base.copy()
+        m = rng.random(len(g)) < 0.02
+        g[m] = (g[m] + rng.integers(1, 4, int(m.sum()))) % 4
+        seqs.append(bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[g]))
+    stages = [(12, 80)]
+    ref = _oracle(seqs, stages)
+    monkeypatch.setenv("SBL_NO_DENSE_PATH", "1")       # (the ordered rounds, not the one-launch path)
+    monkeypatch.setenv("SBL_PARK", "0")
+    plain = _run(seqs, stages)
+    _same_state(plain, ref, "dense, SBL_PARK=0")
     for cap in ("1", "2"):
         monkeypatch.setenv("SBL_PARK", cap)
-        _same_state(_run(seqs, [(25, 150)]), ref, "48 strains, SBL_PARK=" + cap)
+        a = _run(seqs, stages)
+        _same_state(a, ref, "dense, SBL_PARK=" + cap)
+        _bounded_rounds(a, plain, "dense, SBL_PARK=" + cap)

@@ -14,25 +14,36 @@ from sibelia_amd import BlockFinder, workloads as W        # noqa: E402
 from oracle.oracle import Oracle                            # noqa: E402
 
 
+def draw_case(seed, many=False, stages3=False):
+    """the case of `seed`: (sequences, stages, rng, n, L0, snp) -- rng is left where the optional draws of run() continue"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 13))
+    L0 = int(rng.integers(3_000, 80_000))
+    if many:
+        n, L0 = int(rng.integers(30, 71)), int(rng.integers(2_000, 9_000))
+    k = int(rng.choice([15, 16, 20, 25, 31, 32, 40]))
+    D = int(rng.integers(k, 12 * k))
+    snp = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
+    seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
+                         inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
+    stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
+    if stages3:                                                 # every case is a three-stage cascade (state carried across copy-backs)
+        stages = [(k, D), (int(min(40, k + 5)), D + 50), (int(min(48, k + 10)), D + 100)]
+    return seqs, stages, rng, n, L0, snp
+
+
+# a case whose GPU time is more than SLOW_FACTOR x the single-threaded oracle's (and more than SLOW_FLOOR seconds: launch overheads dominate
+# tiny cases) is reported like a mismatch: exact-but-pathological runs -- round 5's seed 67000 took 238 s against 4.2 s -- must not pass
+SLOW_FACTOR, SLOW_FLOOR = 20.0, 3.0
+
+
 def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print, count=None):
     """draws cases from `seed` on for `budget` seconds -- or exactly `count` cases when given (the GPU suite: no wall-clock dependence);
     returns (cases, mismatching seeds)"""
     t0 = time.time()
     done, bad = 0, []
     while (done < count) if count is not None else (time.time() - t0 < budget):
-        rng = np.random.default_rng(seed)
-        n = int(rng.integers(2, 13))
-        L0 = int(rng.integers(3_000, 80_000))
-        if os.environ.get("MANY"):
-            n, L0 = int(rng.integers(30, 71)), int(rng.integers(2_000, 9_000))
-        k = int(rng.choice([15, 16, 20, 25, 31, 32, 40]))
-        D = int(rng.integers(k, 12 * k))
-        snp = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
-        seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
-                             inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
-        stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
-        if stages3:                                                 # every case is a three-stage cascade (state carried across copy-backs)
-            stages = [(k, D), (int(min(40, k + 5)), D + 50), (int(min(48, k + 10)), D + 100)]
+        seqs, stages, rng, n, L0, snp = draw_case(seed, bool(os.environ.get("MANY")), stages3)
         head = "case %d n %d L0 %d stages %s snp %s" % (seed, n, L0, stages, snp)
         if nshard:                                                  # the same run through nshard virtual ranks (sharded enumeration)
             from sibelia_amd.dist import LocalShardedFinder
@@ -69,6 +80,9 @@ def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print, c
         if not ok:
             bad.append(seed)
             log(head + extra + " MISMATCH")
+        elif tg > SLOW_FLOOR and tg > SLOW_FACTOR * tc:
+            bad.append(seed)
+            log(head + extra + " SLOW bulges %d rounds %d replays %d gpu %.2fs cpu %.2fs (more than %.0f x the oracle)" % (a, st["rounds"], st["replays"], tg, tc, SLOW_FACTOR))
         else:
             log(head + extra + " ok bulges %d rounds %d replays %d gpu %.2fs cpu %.2fs" % (a, st["rounds"], st["replays"], tg, tc))
         bf.close()
