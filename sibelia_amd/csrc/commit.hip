@@ -1467,7 +1467,7 @@ __device__ __forceinline__ void commit_kernel(const GraphView &g, unsigned nwin,
 			const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)g.park_of[id]);
 			if (pk && (!(pk >> 31) || ((pk >> 20) & 0x7FFu) == bt_round_tag(g))) return;      // parked (k_resume's), or finished in this round
 		}
-		const bool shadow = !solo && g.park_cap && __builtin_amdgcn_readfirstlane((int)g.slice_busy[wi]) != 0;      // my slice holds a parked transaction: the spare one
+		const bool shadow = !solo && g.park_cap && __builtin_amdgcn_readfirstlane((int)g.slice_busy[g.shadow_base + 64u + wi]) != 0;      // my slice held a parked transaction when the round's commits started (k_reserve's copy: k_resume may be releasing it right now): the spare one
 		commit_body<false>(g, t, w, flag, absh, fast, (unsigned)sizeof fast, wi, id, stampv, solo, solo != 0, arena + (size_t)(shadow ? g.shadow_base + wi : wi) * arena_bytes, arena_bytes, prof, sepl,
 		                   !solo && g.park_cap && !shadow ? wi : (unsigned)BT_NONE);
 	}

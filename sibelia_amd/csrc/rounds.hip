@@ -823,7 +823,14 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	unsigned *const my_list = rsv_dyn + (1u << seen_bits) + (size_t)(threadIdx.x >> 6) * list_cap;      // the marked slots of a group of instances, compacted (reserve_idx_emit)
 	if (threadIdx.x == 0) nclaims = 0;
 	unsigned id = g.win[w], st = g.round_bits | w;
-	if (g.park_list && threadIdx.x == 0 && bt_parked(g, id)) g.park_list[atomicAdd(&g.ctr[CTR_PLIST], 1u)] = w;      // k_resume's work list: the parked entries of this window
+	if (g.park_list && threadIdx.x == 0) {
+		if (bt_parked(g, id)) g.park_list[atomicAdd(&g.ctr[CTR_PLIST], 1u)] = w;      // k_resume's work list: the parked entries of this window
+		// slice_busy as of the START of the round's commit launches (second half of the array): whether the entry at position w works in
+		// its own slice (and may park) or in the shadow slice must not depend on whether k_resume, running beside k_commit, has already
+		// released the slice -- either outcome is exact, but the rounds differ, and the ranks of a job on several GPUs (replicated
+		// commits, collectives sized by the window) must stay in step: that race was round 5's crash with a communicator attached
+		g.slice_busy[g.shadow_base + 64u + w] = g.slice_busy[w];
+	}
 	// the instances: handed over by the probe of this round (k_probe_idx: one coalesced read), or ListPositions by 64 lanes (wave_list_nodes)
 	const unsigned given = instbuf ? instbuf[(size_t)w * istride] : BT_NONE;
 	if (given != BT_NONE && given <= RESUME_SLOTS) {

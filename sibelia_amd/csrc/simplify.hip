@@ -798,7 +798,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 		st->claims.ensure((size_t)w * (CLAIM_CAP + 1) * 4);
 		st->live.ensure((size_t)w + 64);
 		st->instbuf.ensure((size_t)w * 129 * 4);                          // (DeviceBackend::istride() <= 129)
-		st->slice_busy.ensure((size_t)w + 64);
+		st->slice_busy.ensure(2 * ((size_t)w + 64));                      // (second half: the copy k_reserve takes for k_commit)
 		st->park_list.ensure((size_t)w * 4 + 64);
 	};
 	be.snap_slice = window_max;

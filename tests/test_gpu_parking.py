@@ -161,23 +161,27 @@ def _stress_case(seed, many):
 
 
 def test_the_serial_chain_starts_although_transactions_are_parked(monkeypatch):
-    """tools/stress.py MANY=1, seed 67000 (57 strains x 8 kbp, k = 31, D = 369): dense conflict neighbourhoods, the serial chain's regime.
-    Round 5: chain() refused while anything was parked and every transaction parked several times -- 17 734 rounds, 238 s (exact).
-    Now the driver's request for the chain stops NEW parking (GraphView::park_hold), what is parked drains, the chain starts."""
-    import time
+    """The regime of tools/stress.py MANY=1, seed 67000 (57 strains x 8 kbp, k = 31, D = 369: a transaction's neighbourhood is a tenth of
+    a genome, the rounds are serial and the driver asks for the chain from id 7 on), cut to 24 strains x 3 kbp so that it runs in seconds.
+    Round 5 blamed parking for that case's 17 734 rounds; measured in round 6 it takes as many WITHOUT parking (docs/history/r06.md: the
+    serial chain stops at the first id it made pending itself, ~10 ids per round, whatever the park cap).  What parking must not do is
+    add to it: chain() used to refuse while anything was parked and nothing stopped new parking -- now the request for the chain stops
+    it (GraphView::park_hold), what is parked drains, and the chain runs."""
     seqs, stages = _stress_case(67000, True)
+    seqs = [s[:3000] for s in seqs[:24]]
     ref = _oracle(seqs, stages)
-    for cap in ("2", "4", None):                       # None: the default of this regime
+    monkeypatch.setenv("SBL_PARK", "0")
+    plain = _run(seqs, stages)
+    _same_state(plain, ref, "chain regime, SBL_PARK=0")
+    for cap in ("1", "2", "4", None):                  # None: the default of this regime
         if cap is None:
             monkeypatch.delenv("SBL_PARK", raising=False)
         else:
             monkeypatch.setenv("SBL_PARK", cap)
-        t0 = time.time()
         a = _run(seqs, stages)
-        dt = time.time() - t0
-        _same_state(a, ref, "seed 67000, SBL_PARK=%s" % cap)
-        assert all(x[1] < 300 for x in a), "seed 67000, SBL_PARK=%s: %s rounds" % (cap, [x[1] for x in a])
-        assert dt < 10.0, "seed 67000, SBL_PARK=%s: %.1f s" % (cap, dt)
+        _same_state(a, ref, "chain regime, SBL_PARK=%s" % cap)
+        for x, y in zip(a, plain):
+            assert x[1] <= 1.5 * y[1] + 16, "chain regime, SBL_PARK=%s: %d rounds against %d without parking" % (cap, x[1], y[1])
 
 
 def test_parking_in_a_dense_low_complexity_graph_with_few_instances_per_id(monkeypatch):
