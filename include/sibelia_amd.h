@@ -86,6 +86,11 @@ typedef struct {
 	uint64_t ro_ranks;
 	double verdict_ms;
 	uint64_t verdict_bytes;
+	/* k > 32 (round 6): which enumeration ran -- 0 none (k <= 32), 1 window fingerprints + bucketed table + exact verification
+	 * (longk_fp.hip), 2 exact rank doubling on request / on several GPUs (longk.hip), 3 rank doubling after a failed verification --
+	 * and the occurrences of bifurcation k-mers that were compared with their group's representative on the sequence (k/4 B each) */
+	uint64_t longk_path;
+	uint64_t fp_verified;
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libsibelia_amd.so")
-SOURCES = ["sbl_api.hip", "simplify.hip", "graphbuild.hip", "snapshot.hip", "rounds.hip", "commit.hip", "longk.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
+SOURCES = ["sbl_api.hip", "simplify.hip", "graphbuild.hip", "snapshot.hip", "rounds.hip", "commit.hip", "longk.hip", "longk_fp.hip", "shard.hip", "fasta_load.hip", "synteny.hip", "postprocess.hip"]
 HEADERS = ["sbl_common.h", "sbl_ctx.h", "sbl_comm.h", "kmer_kernels.h", "kmer_bucket_kernels.h", "bulge_txn.h", "simplify_steps.h", "simplify_driver.h",
            "simplify_device.h", "simplify_walks.h", "simplify_kernels.h",
            os.path.join("..", "..", "include", "sibelia_amd.h")]

@@ -1,0 +1,671 @@
+// longk_fp.hip -- bifurcation enumeration for vertex sizes k > 32 through WINDOW FINGERPRINTS and the radix-bucketed table of the
+// k <= 32 path, made exact by verification ("fingerprint slots 32 B ... + k/4 B per verified occurrence").
+//
+// Replaces IndexedSequence::EnumerateBifurcationsSArrayInRAM (reference src/vertexenumeration.cpp:263-364) for k > 32, like the exact
+// rank doubling of longk.hip (kept as the fall-back and as the A/B: SBL_LONGK_DOUBLING=1), in a handful of streaming passes instead
+// of ~40 radix sorts of every suffix:
+//   F1 k_fp_tiles     per tile of 1024 elements: the polynomial hash of the tile (two hash functions x two directions) and of its
+//                     first r / last T - r symbols (r = k mod T) -- 0.25 B read per element
+//   F2 k_fp_tilescan  prefix (left to right) and suffix (right to left) hashes at the tile boundaries (one workgroup)
+//   F3 k_fp_records   per window start g: F(w) = P[g+k] - P[g] B^k and F(rc(w)) = 3 G_k - (S[g] - B^k S[g+k]) from block scans of the
+//                     tile at g and of the tile range at g + k (nothing per element is kept in HBM); the record of the CANONICAL
+//                     orientation (smaller fingerprint pair): {mix64(h1), h2, element | prev/next masks | orientation} -- 24 B written
+//   F4 partition      by the hash prefix of the first key, as at k <= 32
+//   F5 k_fp_classify  one LDS open-addressing table per bucket keyed by the 125-bit pair (slot claimed on the first key by ds cmpswap,
+//                     identity settled on the second), masks OR-ed, Bifurcation() test (vertexenumeration.cpp:67-70,:330) per
+//                     distinct fingerprint, representative window + member positions of the bifurcation k-mers
+//   F6 k_fp_verify    EVERY member of a bifurcation group is compared with the group's representative on the 2-bit sequence
+//                     (k / 4 B per occurrence).  Two different k-mers with one fingerprint can only MERGE groups (masks are OR-ed:
+//                     bits are added, never lost), so an unverified table has false positives only, and all positives are verified:
+//                     a mismatch (never observed: 2^-125 per pair of windows) abandons the path and the exact rank doubling runs.
+//   F7 ranking        ids = lexicographic rank among the bifurcation k-mers (:348-355) -- a few per cent of the windows at most:
+//                     MSD refinement over chunks of <= 27 symbols of the representatives (library sorts on this SUBSET only)
+//   F8 k_fp_marks     bif[0][g] / bif[1][g+k-1] of the member positions (marking, indexedsequence.cpp:49-67)
+// Hash functions: h1 = sum x_i B1^(k-1-i) mod 2^61 - 1, h2 = sum x_i B2^(k-1-i) mod 2^64 (odd B2): the second one costs three
+// 32-bit multiplies, and its known weakness (Thue-Morse strings) is not shared by the first.
+// Integer work only: no MFMA.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#include "sbl_ctx.h"
+#include "kmer_bucket_kernels.h"
+
+typedef unsigned long long u64;
+static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------- fingerprint arithmetic
+#define FP_M61 0x1FFFFFFFFFFFFFFFull
+struct Fp { u64 a, b; };                          // a: mod 2^61 - 1, b: mod 2^64
+__host__ __device__ __forceinline__ u64 mul61(u64 x, u64 y)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	const u64 lo = x * y, hi = __umul64hi(x, y);
+#else
+	const unsigned __int128 p = (unsigned __int128)x * y;
+	const u64 lo = (u64)p, hi = (u64)(p >> 64);
+#endif
+	u64 r = (lo & FP_M61) + ((lo >> 61) | (hi << 3));      // 2^61 = 1 (mod M): x y = (hi 2^3 + lo >> 61) 2^61 + (lo & M)
+	r = (r & FP_M61) + (r >> 61);
+	return r >= FP_M61 ? r - FP_M61 : r;
+}
+__host__ __device__ __forceinline__ u64 add61(u64 x, u64 y) { const u64 r = x + y; return r >= FP_M61 ? r - FP_M61 : r; }
+__host__ __device__ __forceinline__ u64 sub61(u64 x, u64 y) { return x >= y ? x - y : x + FP_M61 - y; }
+__host__ __device__ __forceinline__ Fp fp_mul(Fp x, Fp y) { return Fp{mul61(x.a, y.a), x.b * y.b}; }
+__host__ __device__ __forceinline__ Fp fp_add(Fp x, Fp y) { return Fp{add61(x.a, y.a), x.b + y.b}; }
+__host__ __device__ __forceinline__ Fp fp_sub(Fp x, Fp y) { return Fp{sub61(x.a, y.a), x.b - y.b}; }
+__host__ __device__ __forceinline__ Fp fp_sym(unsigned s) { return Fp{(u64)s, (u64)s}; }
+__host__ __device__ __forceinline__ Fp fp_horner(Fp h, Fp base, unsigned s) { return Fp{add61(mul61(h.a, base.a), (u64)s), h.b * base.b + s}; }   // h B + s
+
+#define FP_TILE 1024u                             // elements per tile = 256 threads x FP_RUN
+#define FP_RUN 4u
+#define FP_THREADS 256u
+// constants of one enumeration (host-computed, passed by value)
+struct FpConst {
+	Fp B;                                         // the bases
+	Fp c2[6];                                     // (B^FP_RUN)^(2^i), i = 0 .. 5: steps of the wave scans
+	Fp c64;                                       // (B^FP_RUN)^64: from wave to wave
+	Fp Bk, G3;                                    // B^k; 3 (B^k - 1) / (B - 1) = 3 sum_{j<k} B^j
+	Fp Br, BTr;                                   // B^r, B^(T - r) with r = k mod T
+	Fp t2[6], t64, tT;                            // the same steps for the scan over tiles: base B^T, and (B^T)^256 for its carry
+	unsigned k, q, r;                             // k = q T + r
+};
+
+__device__ __forceinline__ Fp fp_shfl(Fp x, int src) { return Fp{(u64)__shfl((long long)x.a, src), (u64)__shfl((long long)x.b, src)}; }
+__device__ __forceinline__ Fp fp_shfl_up(Fp x, unsigned d) { return Fp{(u64)__shfl_up((long long)x.a, d), (u64)__shfl_up((long long)x.b, d)}; }
+__device__ __forceinline__ Fp fp_shfl_down(Fp x, unsigned d) { return Fp{(u64)__shfl_down((long long)x.a, d), (u64)__shfl_down((long long)x.b, d)}; }
+
+// Scan of 256 chunk hashes, one per thread, all chunks of the same length (weight C per chunk, its powers c2[] / c64):
+//   DIR = +1   excl[t] = sum_{u < t} x_u C^(t-1-u)      total = sum_u x_u C^(255-u)        (prefix: left to right)
+//   DIR = -1   excl[t] = sum_{u > t} x_u C^(u-t-1)      total = sum_u x_u C^u              (suffix: right to left)
+// lds: 8 Fp of scratch.  All 256 threads call it.
+template <int DIR>
+__device__ __forceinline__ Fp scan256(Fp x, const Fp *c2, Fp c64, Fp *lds, Fp &total)
+{
+	const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	Fp inc = x;
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		const unsigned d = 1u << i;
+		const Fp y = DIR > 0 ? fp_shfl_up(inc, d) : fp_shfl_down(inc, d);
+		const bool in = DIR > 0 ? lane >= d : lane + d < 64u;
+		if (in) inc = fp_add(inc, fp_mul(y, c2[i]));
+	}
+	// inc: inclusive within the wave.  Exclusive within the wave: the neighbour's inclusive value
+	Fp exc = DIR > 0 ? fp_shfl_up(inc, 1) : fp_shfl_down(inc, 1);
+	if (DIR > 0 ? lane == 0 : lane == 63u) exc = Fp{0, 0};
+	if (DIR > 0 ? lane == 63u : lane == 0) lds[wv] = inc;                 // the wave's total
+	__syncthreads();
+	// what the waves before (after) this one contribute: sum over them, each a further C^64 away; then C^(distance inside the wave)
+	Fp carry{0, 0};
+	if (DIR > 0) { for (unsigned v = 0; v < wv; v++) carry = fp_add(fp_mul(carry, c64), lds[v]); }
+	else { for (unsigned v = 3; v > wv; v--) carry = fp_add(fp_mul(carry, c64), lds[v]); }
+	Fp tot{0, 0};
+	if (DIR > 0) { for (unsigned v = 0; v < 4; v++) tot = fp_add(fp_mul(tot, c64), lds[v]); }
+	else { for (unsigned v = 4; v-- > 0;) tot = fp_add(fp_mul(tot, c64), lds[v]); }
+	total = tot;
+	// C^(number of chunks between the wave boundary and this thread): a product scan of C over the lanes
+	Fp pw = c2[0];                                                     // C^(l+1) after the scan (l = distance from the wave's first chunk)
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		const unsigned d = 1u << i;
+		const Fp y = DIR > 0 ? fp_shfl_up(pw, d) : fp_shfl_down(pw, d);
+		const bool in = DIR > 0 ? lane >= d : lane + d < 64u;
+		if (in) pw = fp_mul(pw, y);
+	}
+	// exclusive: the carry is C^dist away from this thread's exclusive value, dist = chunks of this wave before (after) the thread
+	Fp pwe = DIR > 0 ? fp_shfl_up(pw, 1) : fp_shfl_down(pw, 1);         // C^dist for dist >= 1
+	if (DIR > 0 ? lane == 0 : lane == 63u) pwe = Fp{1, 1};
+	__syncthreads();                                                   // (lds is reused by the caller)
+	return fp_add(exc, fp_mul(carry, pwe));
+}
+
+// FP_RUN symbols from element e (2 bit each, first in the high bits of the byte); elements beyond the packed array read 0
+__device__ __forceinline__ unsigned fp_syms(const u64 *__restrict__ pk, size_t nwords, size_t e)
+{
+	const size_t w = e >> 5; const unsigned o = (unsigned)(e & 31u);
+	const u64 w0 = w < nwords ? pk[w] : 0ull;
+	u64 x = w0 << (2 * o);
+	if (o > 32u - FP_RUN) { const u64 w1 = w + 1 < nwords ? pk[w + 1] : 0ull; x |= w1 >> (64 - 2 * o); }
+	return (unsigned)(x >> (64 - 2 * FP_RUN));
+}
+__device__ __forceinline__ unsigned fp_sym_at(unsigned four, unsigned j) { return (four >> (2 * (FP_RUN - 1 - j))) & 3u; }
+
+// F1: per tile t (FP_TILE elements from t T): out[4 t + 0] forward hash of the tile, + 1 backward hash, + 2 forward hash of its first r
+// symbols, + 3 backward hash of its symbols r .. T-1 (weights B^(j - r))
+__global__ void __launch_bounds__(FP_THREADS) k_fp_tiles(const u64 *__restrict__ pk, size_t nwords, unsigned ntiles_ext, FpConst C, Fp *__restrict__ out)
+{
+	__shared__ Fp lds[8];
+	const unsigned t = blockIdx.x, tid = threadIdx.x;
+	if (t >= ntiles_ext) return;
+	const unsigned four = fp_syms(pk, nwords, (size_t)t * FP_TILE + (size_t)tid * FP_RUN);
+	// whole tile
+	Fp hf{0, 0}, hb{0, 0};
+#pragma unroll
+	for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(four, j));
+#pragma unroll
+	for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(four, j));
+	Fp totF, totB;
+	// hash(first r symbols) = the exclusive prefix of the thread that holds element r, continued over its first r mod RUN symbols;
+	// likewise the suffix hash from element r
+	const unsigned r = C.r, rt = r / FP_RUN, rj = r % FP_RUN;
+	const Fp exF = scan256<+1>(hf, C.c2, C.c64, lds, totF);
+	const Fp exB = scan256<-1>(hb, C.c2, C.c64, lds, totB);
+	__shared__ Fp part[2];
+	if (tid == rt) {
+		Fp pf = exF;                                                   // hash of the elements before this thread's chunk
+		for (unsigned j = 0; j < rj; j++) pf = fp_horner(pf, C.B, fp_sym_at(four, j));
+		Fp pb = exB;                                                   // suffix hash from the element after this thread's chunk
+		for (unsigned j = FP_RUN; j-- > rj;) pb = fp_horner(pb, C.B, fp_sym_at(four, j));
+		part[0] = pf; part[1] = pb;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		out[4 * (size_t)t + 0] = totF; out[4 * (size_t)t + 1] = totB;
+		out[4 * (size_t)t + 2] = r ? part[0] : Fp{0, 0};
+		out[4 * (size_t)t + 3] = part[1];                             // (r = 0: thread 0, all FP_RUN symbols: the whole tile)
+	}
+}
+
+// F2: PT[t] = forward prefix hash at element t T (PT[0] = 0), ST[t] = suffix hash from element t T (ST[n] = 0), t = 0 .. n.
+// One workgroup, chunks of 256 tiles with a carry; base of the scan = B^T.
+__global__ void __launch_bounds__(FP_THREADS) k_fp_tilescan(const Fp *__restrict__ tiles, unsigned n, FpConst C, Fp *__restrict__ PT, Fp *__restrict__ ST)
+{
+	__shared__ Fp lds[8];
+	__shared__ Fp s_pw[FP_THREADS + 1];                                // (B^T)^i, i = 0 .. 256
+	const unsigned tid = threadIdx.x;
+	{	// powers of B^T by a product scan
+		Fp tot;
+		(void)tot;
+		// sequential doubling through LDS is enough here: 256 entries, once
+		if (tid == 0) { s_pw[0] = Fp{1, 1}; for (unsigned i = 1; i <= FP_THREADS; i++) s_pw[i] = fp_mul(s_pw[i - 1], C.t2[0]); }
+		__syncthreads();
+	}
+	Fp carry{0, 0};
+	if (tid == 0) PT[0] = carry;
+	for (unsigned base = 0; base < n; base += FP_THREADS) {
+		const unsigned i = base + tid;
+		const Fp x = i < n ? tiles[4 * (size_t)i + 0] : Fp{0, 0};
+		Fp tot;
+		const Fp ex = scan256<+1>(x, C.t2, C.t64, lds, tot);
+		// inclusive prefix after tile i: (ex + carry (B^T)^tid) B^T + x
+		const Fp before = fp_add(ex, fp_mul(carry, s_pw[tid]));
+		if (i < n) PT[i + 1] = fp_add(fp_mul(before, C.t2[0]), x);
+		carry = fp_add(fp_mul(carry, s_pw[FP_THREADS]), tot);
+	}
+	carry = Fp{0, 0};
+	if (tid == 0) ST[n] = carry;
+	// suffixes: chunks from the right; chunk = tiles [lo, lo + 256) with lo = n - 256 m (the first chunk may reach below 0)
+	for (long long hi = (long long)n; hi > 0; hi -= FP_THREADS) {
+		const long long i = hi - (long long)FP_THREADS + (long long)tid;  // this thread's tile
+		const Fp x = i >= 0 ? tiles[4 * (size_t)i + 1] : Fp{0, 0};
+		Fp tot;
+		const Fp ex = scan256<-1>(x, C.t2, C.t64, lds, tot);
+		// suffix from tile i: x + B^T (ex + carry (B^T)^(255 - tid))
+		const Fp after = fp_add(ex, fp_mul(carry, s_pw[FP_THREADS - 1 - tid]));
+		if (i >= 0) ST[i] = fp_add(x, fp_mul(after, C.t2[0]));
+		// tiles below 0 are absent (zero symbols at the LOW end of a suffix scan would shift nothing: they are lower, not higher)
+		carry = fp_add(tot, fp_mul(carry, s_pw[FP_THREADS]));
+		// (tot = sum_u x_u C^u with u = tid: the chunk's suffix hash from its first tile -- when the chunk reaches below tile 0 the absent tiles
+		// contribute zeros at the low end, which scales the hash by (B^T)^(missing); that chunk is the last one, its carry is not used)
+	}
+}
+
+#define FP_INVALID KB_INVALID
+// canonical-orientation key pair of a window and its value (element | masks << 32 | orientation flags << 48), see kmer_bucket_kernels.h
+// F3: one workgroup per tile of window starts.
+__global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict__ pk, size_t nwords, const uint8_t *__restrict__ ch, size_t nelem,
+                                                           const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C,
+                                                           const Fp *__restrict__ tiles, const Fp *__restrict__ PT, const Fp *__restrict__ ST, const Fp *__restrict__ pwrun /* (B^RUN)^i, i = 0 .. 256 */,
+                                                           unsigned test_weak /* SBL_TEST_WEAK_FP: fingerprints reduced to this many bits (0 = off) */,
+                                                           u64 *__restrict__ key1, u64 *__restrict__ key2, u64 *__restrict__ vals)
+{
+	__shared__ Fp lds[8];
+	const unsigned t = blockIdx.x, tid = threadIdx.x;
+	const size_t a0 = (size_t)t * FP_TILE, a1 = a0 + C.k;
+	// seeds: forward prefix at the start of each range, suffix hash from the end of each range
+	const Fp seedP0 = PT[t], seedS0 = ST[t + 1];
+	const size_t t1 = (size_t)t + C.q;
+	const Fp seedP1 = fp_add(fp_mul(PT[t1], C.Br), tiles[4 * t1 + 2]);
+	const Fp seedS1 = fp_add(tiles[4 * (t1 + 1) + 3], fp_mul(ST[t1 + 2], C.BTr));
+	Fp P0[FP_RUN], S0[FP_RUN], P1[FP_RUN], S1[FP_RUN];
+	const Fp pwl = pwrun[tid], pwr = pwrun[FP_THREADS - 1 - tid];       // B^(RUN tid), B^(T - RUN (tid + 1))
+#pragma unroll
+	for (int range = 0; range < 2; range++) {
+		const size_t a = range ? a1 : a0;
+		const unsigned four = fp_syms(pk, nwords, a + (size_t)tid * FP_RUN);
+		Fp hf{0, 0}, hb{0, 0};
+#pragma unroll
+		for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(four, j));
+#pragma unroll
+		for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(four, j));
+		Fp tot;
+		const Fp exF = scan256<+1>(hf, C.c2, C.c64, lds, tot);
+		const Fp exB = scan256<-1>(hb, C.c2, C.c64, lds, tot);
+		Fp hh = fp_add(fp_mul(range ? seedP1 : seedP0, pwl), exF);      // prefix hash at the thread's first element
+#pragma unroll
+		for (unsigned j = 0; j < FP_RUN; j++) { if (range) P1[j] = hh; else P0[j] = hh; hh = fp_horner(hh, C.B, fp_sym_at(four, j)); }
+		hh = fp_add(fp_mul(range ? seedS1 : seedS0, pwr), exB);         // suffix hash from the element behind the thread's last one
+#pragma unroll
+		for (unsigned j = FP_RUN; j-- > 0;) { hh = fp_horner(hh, C.B, fp_sym_at(four, j)); if (range) S1[j] = hh; else S0[j] = hh; }
+	}
+	// chromosome of the thread's first element: sepidx[c] < g < sepidx[c+1] (a separator itself belongs to nobody)
+	const size_t g0 = a0 + (size_t)tid * FP_RUN;
+	unsigned c = 0;
+	{ unsigned lo = 0, hi = nchr; const unsigned e = (unsigned)(g0 < nelem ? g0 : nelem - 1); while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (sepidx[mid] < e) lo = mid; else hi = mid; } c = lo; }
+#pragma unroll
+	for (unsigned j = 0; j < FP_RUN; j++) {
+		const size_t g = g0 + j;
+		while (c + 1 < nchr && g >= sepidx[c + 1]) c++;
+		const bool valid = g < nelem && g > sepidx[c] && g + C.k <= sepidx[c + 1];
+		u64 k1 = kmer_hash((u64)g), k2 = 0, v = FP_INVALID;               // invalid records: spread over the buckets, skipped by value
+		if (valid) {
+			Fp hf = fp_sub(P1[j], fp_mul(P0[j], C.Bk));                    // F(w)
+			Fp hr = fp_sub(C.G3, fp_sub(S0[j], fp_mul(S1[j], C.Bk)));      // F(rc(w))
+			if (test_weak) { const u64 m = (1ull << test_weak) - 1; hf.a &= m; hf.b &= m; hr.a &= m; hr.b &= m; }
+			const uint8_t pc = ch[g - 1], nc = ch[g + C.k];
+			unsigned ps = (pc >> 1) & 3u; ps ^= ps >> 1; if (pc == '$') ps = 4u;
+			unsigned ns = (nc >> 1) & 3u; ns ^= ns >> 1; if (nc == '$') ns = 4u;
+			const bool f_le = hf.a < hr.a || (hf.a == hr.a && hf.b <= hr.b), r_le = hr.a < hf.a || (hr.a == hf.a && hr.b <= hf.b);
+			unsigned m = 0, fl = 0;
+			if (f_le) { m |= (1u << ps) | (1u << (8 + ns)); fl |= 1u; }
+			if (r_le) { m |= (1u << (ns == 4 ? 4 : 3 - ns)) | (1u << (8 + (ps == 4 ? 4 : 3 - ps))); fl |= 2u; }
+			const Fp cn = f_le ? hf : hr;
+			k1 = kmer_hash(cn.a); k2 = cn.b;
+			if (k1 == KB_EMPTY_KEY) k1 ^= 1ull;                           // (the table's empty marker; the second key and the verification keep this exact)
+			v = (u64)(unsigned)g | ((u64)m << 32) | ((u64)fl << 48);
+		}
+		key1[g] = k1; key2[g] = k2; vals[g] = v;
+	}
+}
+
+// ------------------------------------------------------------------------------------------- F5: per-bucket tables on 125-bit keys
+struct FpRec { u64 k2, v; };                      // what travels with the first key through the partition
+#define FPB_SLOTS 1024u
+#define FPB_THREADS 256
+#define FPB_MAX_DISTINCT (FPB_SLOTS * 23u / 32u)
+static_assert(FPB_MAX_DISTINCT + FPB_THREADS < FPB_SLOTS, "k_fp_classify: the LDS table could fill up");
+#define FPB_K2_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define FPB_K2_EMPTY_SUB 0xFFFFFFFFFFFFFFFEull      // a real second key equal to the marker is stored as this (exactness comes from the verification)
+enum { FPB_CTR_PAIRS = 0, FPB_CTR_MEM = 32, FPB_CTR_FLAG = 64, FPB_CTR_WORDS = 96 };
+#define FPB_PAL 0x2000u                             // tmask bit: some record of the slot had both orientation flags (fingerprint palindrome)
+// pairs[p] = representative: element | orientation << 32 | palindrome << 33 (orientation 0: the + strand k-mer at the element is the canonical one)
+// members[i] = element | (2 pair + orientation) << 32 | (both flags) << 63
+__global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restrict__ skey1, const FpRec *__restrict__ srec, const unsigned *__restrict__ boff, unsigned nbuckets,
+                                                            unsigned *__restrict__ counters, u64 *__restrict__ pairs, unsigned maxpairs, u64 *__restrict__ members, unsigned maxmembers)
+{
+	__shared__ u64 tkey[FPB_SLOTS], tkey2[FPB_SLOTS], trep[FPB_SLOTS];
+	__shared__ unsigned tmask[FPB_SLOTS], taux[FPB_SLOTS];
+	__shared__ unsigned s_used, s_pairs, s_pbase;
+	const unsigned b = blockIdx.x;
+	if (b >= nbuckets) return;
+	const unsigned lo = boff[b], hi = boff[b + 1];
+	if (lo >= hi) return;
+	for (unsigned i = threadIdx.x; i < FPB_SLOTS; i += FPB_THREADS) { tkey[i] = KB_EMPTY_KEY; tkey2[i] = FPB_K2_EMPTY; trep[i] = ~0ull; tmask[i] = 0; taux[i] = SBL_NONE; }
+	if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; }
+	__syncthreads();
+	// slot of (k1, k2): claimed on k1 by compare-and-swap; its identity is whichever second key arrives first (a second compare-and-swap);
+	// a record with the same first and another second key moves on.  claim = false: look-up only (everything is inserted by then).
+	auto slot_of = [&](u64 k1, u64 k2, bool claim) -> unsigned {
+		if (k2 == FPB_K2_EMPTY) k2 = FPB_K2_EMPTY_SUB;
+		unsigned h = (unsigned)(k1 >> 44) & (FPB_SLOTS - 1);
+		for (unsigned step = 0; step < FPB_SLOTS; step++, h = (h + 1) & (FPB_SLOTS - 1)) {
+			u64 old = claim ? atomicCAS(&tkey[h], KB_EMPTY_KEY, k1) : tkey[h];
+			if (claim && old == KB_EMPTY_KEY) { atomicAdd(&s_used, 1u); old = k1; }
+			if (old != k1) { if (!claim && old == KB_EMPTY_KEY) return SBL_NONE; continue; }
+			const u64 o2 = claim ? atomicCAS(&tkey2[h], FPB_K2_EMPTY, k2) : tkey2[h];
+			if (o2 == k2 || (claim && o2 == FPB_K2_EMPTY)) return h;
+		}
+		if (claim) atomicAdd(&s_used, FPB_SLOTS);
+		return SBL_NONE;
+	};
+	for (unsigned i = lo + threadIdx.x; i < hi; i += FPB_THREADS) {
+		if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;       // too many distinct k-mers for this table: the host re-buckets
+		const FpRec r = srec[i];
+		if (r.v == FP_INVALID) continue;
+		const unsigned h = slot_of(skey1[i], r.k2, true);
+		if (h == SBL_NONE) break;
+		const unsigned fl = (unsigned)(r.v >> 48) & 3u;
+		atomicOr(&tmask[h], ((unsigned)(r.v >> 32) & 0x1FFFu) | (fl == 3u ? FPB_PAL : 0u));
+		// representative: the lowest element of the group (deterministic), with its orientation
+		atomicMin(&trep[h], ((r.v & 0xFFFFFFFFull) << 1) | ((fl & 1u) ? 0ull : 1ull));
+	}
+	__syncthreads();
+	if (s_used > FPB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[FPB_CTR_FLAG], 1u); return; }   // (uniform; the host discards everything)
+	for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+		if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx] & 0x1FFFu)) continue;
+		taux[sidx] = atomicAdd(&s_pairs, 1u);
+	}
+	__syncthreads();
+	const unsigned npairs = s_pairs;
+	if (!npairs) return;
+	if (threadIdx.x == 0) s_pbase = atomicAdd(&counters[FPB_CTR_PAIRS], npairs);
+	__syncthreads();
+	const unsigned pbase = s_pbase;
+	for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+		const unsigned a = taux[sidx];
+		if (a == SBL_NONE) continue;
+		const unsigned pi = pbase + a;
+		if (pi < maxpairs) pairs[pi] = (trep[sidx] >> 1) | ((trep[sidx] & 1ull) << 32) | ((tmask[sidx] & FPB_PAL) ? 1ull << 33 : 0ull);
+		taux[sidx] = pi;
+	}
+	__syncthreads();
+	// member positions of the bifurcation k-mers: one reservation per wave and step
+	for (unsigned i0 = lo; i0 < hi; i0 += FPB_THREADS) {
+		const unsigned i = i0 + threadIdx.x;
+		FpRec r{0, FP_INVALID};
+		if (i < hi) r = srec[i];
+		unsigned pi = SBL_NONE;
+		if (r.v != FP_INVALID) { const unsigned h = slot_of(skey1[i], r.k2, false); if (h != SBL_NONE) pi = taux[h]; }
+		const bool mem = pi != SBL_NONE;
+		const u64 bal = __ballot(mem);
+		if (!bal) continue;
+		const unsigned lane = threadIdx.x & 63u;
+		unsigned base = 0;
+		if (lane == (unsigned)__builtin_ctzll(bal)) base = atomicAdd(&counters[FPB_CTR_MEM], (unsigned)__popcll(bal));
+		base = __shfl(base, __builtin_ctzll(bal));
+		const unsigned at = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+		const unsigned fl = (unsigned)(r.v >> 48) & 3u;
+		if (mem && at < maxmembers) members[at] = (r.v & 0xFFFFFFFFull) | ((u64)(2u * pi + ((fl & 1u) ? 0u : 1u)) << 32) | (fl == 3u ? 1ull << 63 : 0ull);
+	}
+}
+
+// ------------------------------------------------------------------------------------------- sequence access for verification and ranking
+// up to 32 symbols from element e on the + strand, left-aligned in a 64-bit word (first symbol in the top bits), zero-filled
+__device__ __forceinline__ u64 fp_chunk_fwd(const u64 *__restrict__ pk, size_t e, unsigned len)
+{
+	const size_t w = e >> 5; const unsigned o = (unsigned)(e & 31u);
+	u64 x = pk[w] << (2 * o);
+	if (o && o + len > 32u) x |= pk[w + 1] >> (64 - 2 * o);
+	return len >= 32u ? x : x & ~(~0ull >> (2 * len));
+}
+// symbols off .. off + len - 1 of the k-mer string of (window g, orientation o): o = 0 the + strand k-mer, o = 1 its reverse complement
+__device__ __forceinline__ u64 fp_chunk(const u64 *__restrict__ pk, unsigned g, unsigned o, unsigned k, unsigned off, unsigned len)
+{
+	if (!o) return fp_chunk_fwd(pk, (size_t)g + off, len);
+	// rc string symbol i = complement of the window's symbol k-1-i: the chunk is the window's symbols k-off-len .. k-off-1, reversed and complemented
+	const u64 f = fp_chunk_fwd(pk, (size_t)g + (k - off - len), len);    // left-aligned
+	return rc_code(f >> (64 - 2 * len), len) << (64 - 2 * len);
+}
+
+// F6: work item = (member, chunk of 32 symbols): the member's canonical string against the representative's
+__global__ void __launch_bounds__(256) k_fp_verify(const u64 *__restrict__ pk, const u64 *__restrict__ members, unsigned nmem, const u64 *__restrict__ pairs, unsigned k, unsigned nchunks,
+                                                   unsigned *__restrict__ bad)
+{
+	const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= (size_t)nmem * nchunks) return;
+	const unsigned mi = (unsigned)(w / nchunks), cj = (unsigned)(w % nchunks);
+	const u64 m = members[mi];
+	const unsigned g = (unsigned)m, po = (unsigned)(m >> 32) & 0x7FFFFFFFu, o = po & 1u;
+	const u64 rep = pairs[po >> 1];
+	const unsigned gr = (unsigned)rep, orr = (unsigned)(rep >> 32) & 1u;
+	const unsigned off = cj * 32u, len = k - off < 32u ? k - off : 32u;
+	bool ok = fp_chunk(pk, g, o, k, off, len) == fp_chunk(pk, gr, orr, k, off, len);
+	if (m >> 63) ok = ok && fp_chunk(pk, g, 0, k, off, len) == fp_chunk(pk, g, 1, k, off, len);      // claims to be its own reverse complement
+	if (!ok) atomicAdd(bad, 1u);
+}
+
+// F7: the strings to rank: per pair its canonical string and (unless it is its own reverse complement) the reverse complement.
+// ref[i] = element | orientation << 32; payload[i] = 2 pair + (0: canonical, 1: its reverse complement)
+__global__ void __launch_bounds__(256) k_fp_rank_init(const u64 *__restrict__ pairs, unsigned npairs, u64 *__restrict__ ref, unsigned *__restrict__ payload, unsigned *__restrict__ nkeys)
+{
+	const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool in = p < npairs;
+	const u64 rep = in ? pairs[p] : 0ull;
+	const unsigned n = in ? (((rep >> 33) & 1ull) ? 1u : 2u) : 0u;
+	// ordered compaction is not needed: any order of the keys will do (ranks come from the sort)
+	unsigned at = 0;
+	{
+		const unsigned lane = threadIdx.x & 63u;
+		unsigned incl = n;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += v; }
+		unsigned base = 0;
+		if (lane == 63u) base = atomicAdd(nkeys, incl);
+		base = __shfl(base, 63);
+		at = base + incl - n;
+	}
+	if (!in) return;
+	const unsigned g = (unsigned)rep, o = (unsigned)(rep >> 32) & 1u;
+	ref[at] = (u64)g | ((u64)o << 32); payload[at] = 2u * p;
+	if (n == 2u) { ref[at + 1] = (u64)g | ((u64)(o ^ 1u) << 32); payload[at + 1] = 2u * p + 1u; }
+}
+// sort key of a round: (rank so far << 2 csym) | the next csym symbols of the string
+__global__ void __launch_bounds__(256) k_fp_rank_keys(const u64 *__restrict__ pk, const u64 *__restrict__ ref, const unsigned *__restrict__ rank, unsigned n, unsigned k, unsigned off, unsigned csym,
+                                                      u64 *__restrict__ keys, unsigned *__restrict__ idx)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 r = ref[i];
+	const unsigned len = k - off < csym ? k - off : csym;
+	const u64 chunk = fp_chunk(pk, (unsigned)r, (unsigned)(r >> 32) & 1u, k, off, len) >> (64 - 2 * csym);
+	keys[i] = ((u64)rank[i] << (2 * csym)) | chunk;
+	idx[i] = i;
+}
+// head[j] = j where a new group of equal keys starts in the sorted order, else 0 (input of a running maximum)
+__global__ void __launch_bounds__(256) k_fp_rank_heads(const u64 *__restrict__ skeys, unsigned n, unsigned *__restrict__ head, unsigned *__restrict__ nheads)
+{
+	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool h = j < n && (j == 0 || skeys[j] != skeys[j - 1]);
+	if (j < n) head[j] = h ? j : 0u;
+	const u64 bal = __ballot(h);
+	if (bal && (threadIdx.x & 63u) == 0) atomicAdd(nheads, (unsigned)__popcll(bal));
+}
+__global__ void __launch_bounds__(256) k_fp_rank_apply(const unsigned *__restrict__ sidx, const unsigned *__restrict__ gstart, unsigned n, unsigned *__restrict__ rank)
+{
+	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) rank[sidx[j]] = gstart[j];
+}
+// final: every string has its own rank = its id
+__global__ void __launch_bounds__(256) k_fp_rank_ids(const unsigned *__restrict__ rank, const unsigned *__restrict__ payload, const u64 *__restrict__ pairs, unsigned n, unsigned *__restrict__ pairids)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned p = payload[i];
+	pairids[p] = rank[i];
+	if (!(p & 1u) && ((pairs[p >> 1] >> 33) & 1ull)) pairids[p + 1] = rank[i];      // its own reverse complement: one vertex for both orientations
+}
+// F8
+__global__ void __launch_bounds__(256) k_fp_marks(const u64 *__restrict__ members, unsigned n, unsigned k, const unsigned *__restrict__ pairids, unsigned *__restrict__ bif0, unsigned *__restrict__ bif1)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 m = members[i];
+	const unsigned g = (unsigned)m, p = (unsigned)(m >> 32) & 0x7FFFFFFFu;
+	bif0[g] = pairids[p];
+	bif1[g + k - 1] = pairids[p ^ 1u];
+}
+// bucket b = records whose first key's LOW `bits` bits equal b (see k_bucket_bounds)
+__global__ void __launch_bounds__(256) k_fp_bucket_bounds(const u64 *__restrict__ skeys, size_t n, unsigned bits, unsigned *__restrict__ boff)
+{
+	const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nb = (size_t)1 << bits;
+	if (b > nb) return;
+	if (b == nb) { boff[b] = (unsigned)n; return; }
+	size_t lo = 0, hi = n;
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((skeys[mid] & (nb - 1)) < b) lo = mid + 1; else hi = mid; }
+	boff[b] = (unsigned)lo;
+}
+__global__ void __launch_bounds__(256) k_fp_pack_rec(const u64 *__restrict__ k2, const u64 *__restrict__ v, size_t n, FpRec *__restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = FpRec{k2[i], v[i]};
+}
+
+// ------------------------------------------------------------------------------------------- host
+struct LongKFpScratch {
+	DevBuf tiles, PT, ST, pwrun, key1, key2, vals, rec, skey1, srec, tmp, boff, ctr, pairs, members, ref, payload, rank, keys, skeys, idx, sidx, head, gstart, pairids;
+};
+struct LongKFpHolder { LongKFpScratch s; };
+static LongKFpScratch &fp_of(sbl_ctx *c)
+{
+	if (!c->lkfp) c->lkfp = new LongKFpHolder;
+	return c->lkfp->s;
+}
+void sbl_longk_fp_free(sbl_ctx *c)
+{
+	if (!c->lkfp) return;
+	LongKFpScratch &L = c->lkfp->s;
+	for (DevBuf *b : { &L.tiles, &L.PT, &L.ST, &L.pwrun, &L.key1, &L.key2, &L.vals, &L.rec, &L.skey1, &L.srec, &L.tmp, &L.boff, &L.ctr, &L.pairs, &L.members, &L.ref, &L.payload, &L.rank,
+	                   &L.keys, &L.skeys, &L.idx, &L.sidx, &L.head, &L.gstart, &L.pairids })
+		b->release();
+	delete c->lkfp;
+	c->lkfp = nullptr;
+}
+
+static Fp fp_pow(Fp b, unsigned long long e) { Fp r{1, 1}; while (e) { if (e & 1) r = fp_mul(r, b); b = fp_mul(b, b); e >>= 1; } return r; }
+static unsigned fp_bits(unsigned long long v) { unsigned b = 1; while (b < 64 && (v >> b)) b++; return b; }
+struct MaxU32 { __host__ __device__ unsigned operator()(unsigned a, unsigned b) const { return a > b ? a : b; } };
+
+// returns false when the verification found two different k-mers under one fingerprint (the caller then runs the exact rank doubling)
+bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
+{
+	hipStream_t s = c->stream;
+	const size_t E = c->nelem, nwords = (E + 31) / 32;
+	SBL_CHECK(E < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many positions for 32-bit record indices");
+	c->cur_k = k;
+	c->stats.exchange_bytes = 0; c->stats.exchange_ms = 0;
+	sbl_pack(c);
+	LongKFpScratch &L = fp_of(c);
+	// ---- constants
+	FpConst C{};
+	C.B = Fp{0x1D3F5A7C9B2E4F61ull % FP_M61, 0x9E3779B97F4A7C15ull | 1ull};      // fixed bases: results do not depend on them (ids are ranks, groups are verified)
+	C.k = k; C.q = k / FP_TILE; C.r = k % FP_TILE;
+	const Fp Crun = fp_pow(C.B, FP_RUN);
+	{ Fp x = Crun; for (int i = 0; i < 6; i++) { C.c2[i] = x; x = fp_mul(x, x); } C.c64 = x; }
+	C.Bk = fp_pow(C.B, k);
+	{	// G3 = 3 sum_{j<k} B^j, by doubling: S(2n) = S(n) (1 + B^n), S(n+1) = S(n) B + 1
+		Fp sum{0, 0}; Fp one{1, 1};
+		for (int bit = 31; bit >= 0; bit--) {
+			const unsigned long long n = (unsigned long long)k >> (bit + 1);      // length so far
+			if (n) sum = fp_mul(sum, fp_add(one, fp_pow(C.B, n)));                 // (a few dozen modular powers on the host: microseconds)
+			if ((k >> bit) & 1u) sum = fp_add(fp_mul(sum, C.B), one);
+		}
+		C.G3 = fp_add(fp_add(sum, sum), sum);
+	}
+	C.Br = fp_pow(C.B, C.r); C.BTr = fp_pow(C.B, FP_TILE - C.r);
+	const Fp BT = fp_pow(C.B, FP_TILE);
+	{ Fp x = BT; for (int i = 0; i < 6; i++) { C.t2[i] = x; x = fp_mul(x, x); } C.t64 = x; C.tT = fp_pow(BT, FP_THREADS); }
+	const unsigned ntiles = (unsigned)((E + FP_TILE - 1) / FP_TILE), nx = ntiles + C.q + 3;
+	const size_t n = (size_t)ntiles * FP_TILE;                                  // records (one per element slot of the tiles)
+	L.pwrun.ensure((FP_THREADS + 1) * sizeof(Fp));
+	{
+		std::vector<Fp> pw(FP_THREADS + 1);
+		pw[0] = Fp{1, 1};
+		for (unsigned i = 1; i <= FP_THREADS; i++) pw[i] = fp_mul(pw[i - 1], Crun);
+		HIP_TRY(hipMemcpyAsync(L.pwrun.p, pw.data(), pw.size() * sizeof(Fp), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));                                       // (pw is a local)
+	}
+	L.tiles.ensure((size_t)nx * 4 * sizeof(Fp)); L.PT.ensure(((size_t)nx + 1) * sizeof(Fp)); L.ST.ensure(((size_t)nx + 1) * sizeof(Fp));
+	L.key1.ensure(n * 8); L.key2.ensure(n * 8); L.vals.ensure(n * 8); L.rec.ensure(n * 16); L.skey1.ensure(n * 8); L.srec.ensure(n * 16);
+	L.ctr.ensure(256 * 4);
+	HIP_TRY(hipEventRecord(c->ev[0], s));
+	k_fp_tiles<<<nx, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, nx, C, L.tiles.as<Fp>());
+	k_fp_tilescan<<<1, FP_THREADS, 0, s>>>(L.tiles.as<Fp>(), nx, C, L.PT.as<Fp>(), L.ST.as<Fp>());
+	unsigned weak = 0;
+	if (const char *e = getenv("SBL_TEST_WEAK_FP")) weak = (unsigned)std::min(60, std::max(0, atoi(e)));      // test hook: collisions on purpose (the verification must notice)
+	k_fp_records<<<ntiles, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C,
+	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.key2.as<u64>(), L.vals.as<u64>());
+	k_fp_pack_rec<<<nblocks(n, 256), 256, 0, s>>>(L.key2.as<u64>(), L.vals.as<u64>(), n, L.rec.as<FpRec>());
+	HIP_TRY(hipGetLastError());
+
+	unsigned bits = 4;
+	while (bits < 30 && (n >> bits) > FPB_SLOTS * 9 / 16) bits++;
+	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));
+	size_t maxpairs = n / 8 + 4096, maxmembers = n;
+	if (const char *e = getenv("SBL_TEST_MAXPAIRS")) maxpairs = (size_t)std::max(1, atoi(e));
+	unsigned cnt[3] = {0, 0, 0};
+	for (int attempt = 0;; attempt++) {
+		SBL_CHECK(attempt < 8, SBL_ERR_INTERNAL, "k-mer bucket classification did not converge");
+		if (attempt == 0 || (cnt[2] & 1u)) {
+			if (attempt) { SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)"); bits = std::min(bits + 2, 28u); }
+			size_t tmp = 0;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<FpRec>(), L.srec.as<FpRec>(), n, 0, bits, s));
+			L.tmp.ensure(tmp);
+			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<FpRec>(), L.srec.as<FpRec>(), n, 0, bits, s));
+			L.boff.ensure((((size_t)1 << bits) + 1) * 4 + 64);
+			k_fp_bucket_bounds<<<nblocks(((size_t)1 << bits) + 1, 256), 256, 0, s>>>(L.skey1.as<u64>(), n, bits, L.boff.as<unsigned>());
+		}
+		L.pairs.ensure(maxpairs * 8 + 16); L.members.ensure(maxmembers * 8 + 16);
+		HIP_TRY(hipMemsetAsync(L.ctr.p, 0, 256 * 4, s));
+		k_fp_classify<<<(unsigned)((size_t)1 << bits), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<FpRec>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
+		                                                                   L.pairs.as<u64>(), (unsigned)maxpairs, L.members.as<u64>(), (unsigned)maxmembers);
+		HIP_TRY(hipGetLastError());
+		unsigned all[FPB_CTR_WORDS];
+		HIP_TRY(hipMemcpyAsync(all, L.ctr.p, sizeof all, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		cnt[0] = all[FPB_CTR_PAIRS]; cnt[1] = all[FPB_CTR_MEM]; cnt[2] = all[FPB_CTR_FLAG];
+		if (cnt[2] & 1u) continue;
+		if (cnt[0] > maxpairs) { maxpairs = (size_t)cnt[0] + 1024; continue; }
+		break;
+	}
+	HIP_TRY(hipEventRecord(c->ev[1], s));
+	const unsigned npairs = cnt[0], nmem = cnt[1];
+	SBL_CHECK(nmem <= maxmembers, SBL_ERR_INTERNAL, "more member positions than windows");
+
+	// ---- F6: verification of every member of every bifurcation group
+	const unsigned nchunks = (k + 31) / 32;
+	unsigned *d_bad = L.ctr.as<unsigned>() + 128, *d_nkeys = L.ctr.as<unsigned>() + 160, *d_nheads = L.ctr.as<unsigned>() + 192;
+	if (nmem) {
+		const size_t work = (size_t)nmem * nchunks;
+		SBL_CHECK(work / 256 < 0x7FFFFFFFull, SBL_ERR_TOO_LARGE, "verification grid too large");
+		k_fp_verify<<<nblocks(work, 256), 256, 0, s>>>(c->d_pk.as<u64>(), L.members.as<u64>(), nmem, L.pairs.as<u64>(), k, nchunks, d_bad);
+		unsigned bad = 0;
+		HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (bad) {
+			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] long k: %u of %zu chunk comparisons of the fingerprint groups failed -- falling back to exact rank doubling\n", bad, work);
+			return false;
+		}
+	}
+	c->stats.fp_verified = (uint64_t)nmem;
+
+	// ---- F7: ids = lexicographic rank of the bifurcation k-mers
+	unsigned nkeys = 0;
+	L.pairids.ensure((size_t)npairs * 8 + 16);
+	if (npairs) {
+		const size_t cap = 2 * (size_t)npairs;
+		L.ref.ensure(cap * 8); L.payload.ensure(cap * 4); L.rank.ensure(cap * 4); L.keys.ensure(cap * 8); L.skeys.ensure(cap * 8); L.idx.ensure(cap * 4); L.sidx.ensure(cap * 4);
+		L.head.ensure(cap * 4); L.gstart.ensure(cap * 4);
+		k_fp_rank_init<<<nblocks(npairs, 256), 256, 0, s>>>(L.pairs.as<u64>(), npairs, L.ref.as<u64>(), L.payload.as<unsigned>(), d_nkeys);
+		HIP_TRY(hipMemcpyAsync(&nkeys, d_nkeys, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemsetAsync(L.rank.p, 0, cap * 4, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		const unsigned rbits = fp_bits(nkeys ? nkeys - 1 : 0), csym = std::min(27u, (64u - rbits) / 2u);
+		size_t tsort = 0, tscan = 0;
+		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tsort, L.keys.as<u64>(), L.skeys.as<u64>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), nkeys, 0, 64, s));
+		HIP_TRY(rocprim::inclusive_scan(nullptr, tscan, L.head.as<unsigned>(), L.gstart.as<unsigned>(), nkeys, MaxU32(), s));
+		L.tmp.ensure(std::max(tsort, tscan));
+		for (unsigned off = 0; off < k; off += csym) {
+			HIP_TRY(hipMemsetAsync(d_nheads, 0, 4, s));
+			k_fp_rank_keys<<<nblocks(nkeys, 256), 256, 0, s>>>(c->d_pk.as<u64>(), L.ref.as<u64>(), L.rank.as<unsigned>(), nkeys, k, off, csym, L.keys.as<u64>(), L.idx.as<unsigned>());
+			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tsort, L.keys.as<u64>(), L.skeys.as<u64>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), nkeys, 0, std::min(64u, rbits + 2 * csym), s));
+			k_fp_rank_heads<<<nblocks(nkeys, 256), 256, 0, s>>>(L.skeys.as<u64>(), nkeys, L.head.as<unsigned>(), d_nheads);
+			HIP_TRY(rocprim::inclusive_scan(L.tmp.p, tscan, L.head.as<unsigned>(), L.gstart.as<unsigned>(), nkeys, MaxU32(), s));
+			k_fp_rank_apply<<<nblocks(nkeys, 256), 256, 0, s>>>(L.sidx.as<unsigned>(), L.gstart.as<unsigned>(), nkeys, L.rank.as<unsigned>());
+			unsigned heads = 0;
+			HIP_TRY(hipMemcpyAsync(&heads, d_nheads, 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (heads == nkeys) break;                                      // every string stands alone: ranks are final
+			SBL_CHECK(off + csym < k || heads == nkeys, SBL_ERR_INTERNAL, "two bifurcation k-mers compare equal over their whole length");
+		}
+		k_fp_rank_ids<<<nblocks(nkeys, 256), 256, 0, s>>>(L.rank.as<unsigned>(), L.payload.as<unsigned>(), L.pairs.as<u64>(), nkeys, L.pairids.as<unsigned>());
+	}
+	c->bif_count = nkeys;
+	for (int st = 0; st < 2; st++) {
+		c->d_bif[st].ensure(elem_capacity * 4);
+		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
+	}
+	if (nmem) k_fp_marks<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, L.pairids.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+	c->stats.kmer_table_ms = ms;
+	size_t positions = 0;
+	for (uint32_t ch = 0; ch < c->nchr; ch++) { const size_t len = c->sepidx[ch + 1] - c->sepidx[ch] - 1; if (len >= k) positions += len - k + 1; }
+	// algorithmic bytes (k > 32): 2-bit sequence once + one 32-B slot read and written per base position + k/4 B per verified occurrence
+	c->stats.kmer_table_bytes = positions * 64 + E / 4 + (size_t)nmem * (k / 4);
+	c->stats.strand_kmers = 2 * positions;
+	c->stats.bif_count = nkeys;
+	return true;
+}

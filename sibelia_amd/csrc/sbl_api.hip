@@ -212,9 +212,15 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
 	c->dict_keys = nullptr;
-	if (k > 32) {                                                                  // long k: rank doubling (longk.hip), split over the attached GPUs when there are any
-		if (c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr) sbl_run_enumeration_longk_sharded(c, k, elem_capacity);
-		else sbl_run_enumeration_longk(c, k, elem_capacity);
+	if (k > 32) {
+		// long k: window fingerprints through the bucketed table, every bifurcation group verified on the sequence (longk_fp.hip, round 6);
+		// exact rank doubling (longk.hip) if a verification ever fails, on request (SBL_LONGK_DOUBLING=1: the A/B), and -- split over the
+		// attached GPUs -- for a job on several GPUs
+		const bool doubling = getenv("SBL_LONGK_DOUBLING") != nullptr && atoi(getenv("SBL_LONGK_DOUBLING")) != 0;
+		c->stats.longk_path = 0;
+		if (c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr) { sbl_run_enumeration_longk_sharded(c, k, elem_capacity); c->stats.longk_path = 2; }
+		else if (!doubling && sbl_run_enumeration_longk_fp(c, k, elem_capacity)) c->stats.longk_path = 1;
+		else { sbl_run_enumeration_longk(c, k, elem_capacity); c->stats.longk_path = doubling ? 2 : 3; }      // (3: fell back after a failed verification)
 		return;
 	}
 	if (c->comm) { sbl_run_enumeration_sharded(c, k, elem_capacity); return; }    // k-mer table sharded by hash prefix over the attached GPUs
@@ -358,6 +364,7 @@ extern "C" void sbl_destroy(sbl_ctx *c)
 	sbl_simplify_free(c);
 	sbl_comm_release(c);
 	sbl_longk_free(c);
+	sbl_longk_fp_free(c);
 	DevBuf *bufs[] = { &c->d_send, &c->d_recv, &c->d_otable, &c->d_oused, &c->d_allkeys, &c->d_allkeys2, &c->d_gelem[0], &c->d_gelem[1], &c->d_gid[0], &c->d_gid[1], &c->d_stage, &c->d_ch, &c->d_op, &c->d_sepidx, &c->d_amb_elem, &c->d_amb_char, &c->d_pk, &c->d_sp, &c->d_counters,
 	                   &c->d_keys, &c->d_payload, &c->d_skeys, &c->d_spayload, &c->d_pairids, &c->d_sorttmp, &c->d_bif[0], &c->d_bif[1],
 	                   &c->d_chunkcnt, &c->d_chunkoff, &c->d_scantmp, &c->d_save_ch, &c->d_save_op, &c->d_melem[0], &c->d_melem[1], &c->d_mid[0], &c->d_mid[1], &c->d_inst, &c->d_edges, &c->d_valid, &c->d_rec_keys[0], &c->d_rec_keys[1], &c->d_rec_vals[0], &c->d_rec_vals[1], &c->d_boff, &c->d_fa_text, &c->d_fa_lines, &c->d_fa_recs, &c->d_orig_ch };

@@ -86,6 +86,7 @@ struct sbl_ctx {
 	DevBuf d_send, d_recv, d_otable, d_oused, d_allkeys, d_allkeys2, d_gelem[2], d_gid[2], d_stage;
 
 	struct LongKScratch *lk = nullptr;   // k > 32 workspace (longk.hip)
+	struct LongKFpHolder *lkfp = nullptr;   // k > 32 through window fingerprints (longk_fp.hip)
 
 	// ---- simplification workspace lives in simplify.hip (opaque here)
 	struct SimplifyState *simp = nullptr;
@@ -133,6 +134,9 @@ void sbl_comm_release(sbl_ctx *c);
 void sbl_run_enumeration_longk(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k > 32: exact rank doubling
 void sbl_run_enumeration_longk_sharded(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // ... split over the GPUs of c->comm
 void sbl_longk_free(sbl_ctx *c);
+// implemented in longk_fp.hip
+bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity);   // k > 32: window fingerprints + bucketed table + exact verification; false = a verification failed, run the doubling
+void sbl_longk_fp_free(sbl_ctx *c);
 // implemented in simplify.hip
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
 void sbl_simplify_free(sbl_ctx *c);

@@ -1,0 +1,132 @@
+"""k > 32 through window fingerprints (sibelia_amd/csrc/longk_fp.hip, round 6; replaces the suffix-array group scan of
+IndexedSequence::EnumerateBifurcationsSArrayInRAM, reference src/vertexenumeration.cpp:263-364, for long vertex sizes).
+
+The path must return what the oracle (and the exact rank doubling, SBL_LONGK_DOUBLING=1) return -- ids, instances, order -- for every
+k, including the ones that exercise its arithmetic: k below / at / above the tile of the block scans (1024) and its multiples, k = 33
+(one symbol more than a packed word), records shorter than k, of exactly k, records that are each other's reverse complement,
+palindromic k-mers (even k), and many short records.  With SBL_TEST_WEAK_FP=n the fingerprints keep n bits only: different k-mers
+collide on purpose, the verification must notice, the stage falls back to the doubling and still returns the same result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _bf(seqs):
+    from sibelia_amd import BlockFinder
+    return BlockFinder(seqs, device=0)
+
+
+def _same(a, b, what=""):
+    assert a[0] == b[0], "bifurcation counts differ (%d / %d) %s" % (a[0], b[0], what)
+    assert len(a[1]) == len(b[1]) and (a[1] == b[1]).all() and len(a[2]) == len(b[2]) and (a[2] == b[2]).all(), "instances differ " + what
+
+
+def _enumerate(seqs, k, monkeypatch, doubling=False, weak=None):
+    if doubling:
+        monkeypatch.setenv("SBL_LONGK_DOUBLING", "1")
+    if weak is not None:
+        monkeypatch.setenv("SBL_TEST_WEAK_FP", str(weak))
+    bf = _bf(seqs)
+    try:
+        r = bf.enumerate(k)
+        path = int(bf.stats()["longk_path"])
+    finally:
+        bf.close()
+        monkeypatch.delenv("SBL_LONGK_DOUBLING", raising=False)
+        monkeypatch.delenv("SBL_TEST_WEAK_FP", raising=False)
+    return r, path
+
+
+def _mixed(seed=77):
+    from sibelia_amd import workloads as W
+    x = W.random_dna(700, 1, seed=seed + 1)[0]
+    return (W.gen_strains(L0=40_000, n=3, seed=seed, inv_min=400, inv_max=2000) + W.random_dna(30_000, 1, seed=seed + 2)
+            + [b"ACGTTGCA" * 4, x, x.translate(COMP)[::-1], x[:33], x[:34]])
+
+
+@pytest.mark.parametrize("k", [33, 34, 40, 63, 64, 65, 100, 500, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000])
+def test_fingerprint_enumeration_equals_oracle_and_doubling(k, monkeypatch):
+    from oracle.oracle import Oracle
+    seqs = _mixed()
+    want = Oracle(seqs).enumerate(k)
+    got, path = _enumerate(seqs, k, monkeypatch)
+    assert path == 1, "the fingerprint path did not run (longk_path = %d)" % path
+    _same(got, want, "fingerprints against the oracle, k = %d" % k)
+    dbl, path = _enumerate(seqs, k, monkeypatch, doubling=True)
+    assert path == 2
+    _same(dbl, want, "doubling against the oracle, k = %d" % k)
+    assert want[0] > 0
+
+
+@pytest.mark.parametrize("k", [34, 40, 64])
+def test_records_of_exactly_k_their_reverse_complements_and_palindromes(k, monkeypatch):
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    x = W.random_dna(k, 1, seed=5)[0]
+    rc = x.translate(COMP)[::-1]
+    half = W.random_dna(k // 2, 1, seed=8)[0]
+    pal = half + half.translate(COMP)[::-1]                     # its own reverse complement (even k)
+    a, b = W.random_dna(3000, 2, seed=6)
+    seqs = [x, a[:1500] + x + a[1500:], x, b[:700] + rc + b[700:], rc, x + b[:900], a[:800] + x, pal, a[:300] + pal + b[:300], b[1000:1400] + pal + a[2000:2300], pal[:k - 1]]
+    want = Oracle(seqs).enumerate(k)
+    assert want[0] > 0
+    got, path = _enumerate(seqs, k, monkeypatch)
+    assert path == 1
+    _same(got, want, "k = %d" % k)
+
+
+@pytest.mark.parametrize("weak", [6, 14])
+def test_colliding_fingerprints_are_caught_by_the_verification(weak, monkeypatch):
+    """fingerprints cut to a few bits: groups of DIFFERENT k-mers merge, a merged bifurcation group fails its comparison with the
+    representative, and the exact rank doubling takes over (longk_path = 3) -- same result"""
+    from oracle.oracle import Oracle
+    seqs = _mixed(seed=31)
+    for k in (40, 300):
+        want = Oracle(seqs).enumerate(k)
+        got, path = _enumerate(seqs, k, monkeypatch, weak=weak)
+        assert path == 3, "colliding fingerprints went unnoticed (longk_path = %d)" % path
+        _same(got, want, "weak fingerprints, k = %d" % k)
+
+
+def test_many_short_records_and_a_cascade(monkeypatch):
+    """180-record style input (records from 100 bp) through a long-k cascade: state after every stage against the oracle"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    base = W.gen_strains(L0=60_000, n=4, seed=19, snp=0.02, inv_min=500, inv_max=3000)
+    rng = np.random.default_rng(4)
+    seqs = []
+    for s in base:
+        p = 0
+        while p < len(s):
+            q = min(len(s), p + int(rng.integers(100, 9000)))
+            seqs.append(s[p:q]); p = q
+    bf, orc = _bf(seqs), Oracle(seqs)
+    try:
+        for k, D in ((30, 150), (100, 500), (500, 1500)):
+            assert bf.simplify_stage(k, D, 4) == orc.simplify_stage(k, D, 4)
+            if k > 32:
+                assert int(bf.stats()["longk_path"]) == 1
+            (sa, pa), (sb, pb) = bf.state(), orc.state()
+            assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb)), (k, D)
+    finally:
+        bf.close()
+
+
+def test_random_long_k_cases(monkeypatch):
+    """randomised: strain sets with their own record splits, random k in 33 .. 1500"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    rng = np.random.default_rng(2026)
+    for case in range(12):
+        n, L0 = int(rng.integers(2, 7)), int(rng.integers(2_000, 30_000))
+        k = int(rng.choice([33, 35, 48, 64, 96, 127, 128, 129, 200, 256, 511, 777, 1024, 1500]))
+        seqs = W.gen_strains(L0=L0, n=n, seed=1000 + case, snp=float(rng.choice([0.002, 0.01, 0.05])), inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
+        if rng.random() < 0.5:
+            seqs = seqs + [seqs[0][: int(rng.integers(1, 2 * k))], seqs[-1].translate(COMP)[::-1][: int(rng.integers(k, 4 * k))]]
+        want = Oracle(seqs).enumerate(k)
+        got, path = _enumerate(seqs, k, monkeypatch)
+        assert path == 1
+        _same(got, want, "case %d n %d L0 %d k %d" % (case, n, L0, k))

@@ -2,8 +2,7 @@
 1.3 x what the last committed bench line under profiles/ (rNN_bench_default.json) recorded for it.  The loose wall-clock bounds of
 the parity tests (CI stability) would let a 2 x regression of the stage through; this one would not.  Best of three timed steps
 after a warm-up.  Round 5's version SKIPPED itself when rocm-smi showed the GPU busy -- which it always did inside `-m gpu`, right behind
-the parking tests (the sampler's window still held their kernels) -- so it guarded nothing in the driver's run.  Now it synchronises the
-device, polls rocm-smi for up to 30 s until the GPU is idle, and FAILS if it never is: a box somebody else is loading cannot certify
+the parking tests (the sampler's window still held their kernels) -- so it guarded nothing in the driver's run.  Now it polls rocm-smi for up to 30 s until the GPU is idle, and FAILS if it never is: a box somebody else is loading cannot certify
 the number either way.  A second guard bounds the ROUNDS of the stage (the quantity the round-5 livelock blew up)."""
 import glob
 import json
@@ -45,9 +44,7 @@ def _gpu_busy_percent():
 
 
 def _wait_for_an_idle_gpu(limit=30.0):
-    import torch
-    torch.cuda.synchronize()
-    t0, busy = time.time(), None
+    t0, busy = time.time(), None                   # (every BlockFinder call of the tests before this one has synchronised its stream on return)
     while time.time() - t0 < limit:
         busy = _gpu_busy_percent()
         if busy is None or busy <= 20.0:
