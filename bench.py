@@ -146,7 +146,11 @@ def run_config(a):
         alg = alg_bytes_8d(N, float(st["instances"]), float(st["iterations"]), k)
         ph = {kk: v / a.steps for kk, v in sorted(rec["phase_ms"].items())}
         if k > 32:
-            dom, dom_ms, dom_launches = "long-k enumeration (k_lk_* + rocPRIM radix-sort passes: exact rank doubling)", ph.get("enumerate_ms", 0.0), 1
+            path = int(st.get("longk_path", 0))
+            dom = {1: "long-k enumeration (k_fp_*: window fingerprints -> bucketed LDS tables -> verification of every bifurcation group; %d occurrences verified)" % int(st.get("fp_verified", 0)),
+                   3: "long-k enumeration (a fingerprint verification FAILED: exact rank doubling ran, k_lk_* + radix-sort passes)"}.get(
+                       path, "long-k enumeration (k_lk_* + rocPRIM radix-sort passes: exact rank doubling)")
+            dom_ms, dom_launches = ph.get("enumerate_ms", 0.0), 1
         else:
             cand = {"k_commit": ph.get("commit_ms", 0.0), "k_reserve": ph.get("reserve_ms", 0.0), "k_probe": ph.get("probe_ms", 0.0), "k_snapshot": ph.get("snapshot_ms", 0.0),
                     "enumeration (k_kmer_records .. k_scatter_members)": ph.get("enumerate_ms", 0.0)}
@@ -169,7 +173,7 @@ def run_config(a):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_tot / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_step": bytes_tot, "avg_launch_ms": slow["roofline"]["dominant_avg_launch_ms"],
                         "model": "SURVEY.md 8d summed over the stages of the step (per stage under `stages`); `achieved` = those bytes / the step's wall time; "
-                                 "per-kernel times and HBM traffic of this command: profiles/r05_config%d_kernel_stats.csv / _pmc_summary.json" % a.config},
+                                 "per-kernel times and HBM traffic of this command: profiles/r06_config%d_kernel_stats.csv / _pmc_summary.json" % a.config},
            "state_sha256": sha, "matches_reference_fixture": match, "reference_fixture": fx_name}
     # ---- the reference beside it
     cpu_model = "?"

@@ -6,7 +6,7 @@
 // of ~40 radix sorts of every suffix:
 //   F1 k_fp_tiles     per tile of 1024 elements: the polynomial hash of the tile (two hash functions x two directions) and of its
 //                     first r / last T - r symbols (r = k mod T) -- 0.25 B read per element
-//   F2 k_fp_tilescan  prefix (left to right) and suffix (right to left) hashes at the tile boundaries (one workgroup)
+//   F2 k_fp_chunks / k_fp_carries / k_fp_apply  prefix (left to right) and suffix (right to left) hashes at the tile boundaries
 //   F3 k_fp_records   per window start g: F(w) = P[g+k] - P[g] B^k and F(rc(w)) = 3 G_k - (S[g] - B^k S[g+k]) from block scans of the
 //                     tile at g and of the tile range at g + k (nothing per element is kept in HBM); the record of the CANONICAL
 //                     orientation (smaller fingerprint pair): {mix64(h1), h2, element | prev/next masks | orientation} -- 24 B written
@@ -167,58 +167,53 @@ __global__ void __launch_bounds__(FP_THREADS) k_fp_tiles(const u64 *__restrict__
 	}
 }
 
-// F2: PT[t] = forward prefix hash at element t T (PT[0] = 0), ST[t] = suffix hash from element t T (ST[n] = 0), t = 0 .. n.
-// One workgroup, chunks of 256 tiles with a carry; base of the scan = B^T.
-__global__ void __launch_bounds__(FP_THREADS) k_fp_tilescan(const Fp *__restrict__ tiles, unsigned n, FpConst C, Fp *__restrict__ PT, Fp *__restrict__ ST)
+// F2: PT[t] = forward prefix hash at element t T (PT[0] = 0), ST[t] = suffix hash from element t T, t = 0 .. 256 nchunks.  Base of these
+// scans = B^T.  Three small launches: chunks of 256 tiles scanned side by side (k_fp_chunks), the chunks' carries (k_fp_carries: two
+// sequential loops over <= a few thousand chunks, one thread each), carries applied (k_fp_apply).  (One workgroup looping over all
+// tiles was 0.88 ms at 37 k tiles and 21 ms at 880 k.)
+__global__ void __launch_bounds__(FP_THREADS) k_fp_chunks(const Fp *__restrict__ tiles, unsigned n, FpConst C, Fp *__restrict__ PT, Fp *__restrict__ ST, Fp *__restrict__ tot /* 2 per chunk */)
 {
 	__shared__ Fp lds[8];
-	__shared__ Fp s_pw[FP_THREADS + 1];                                // (B^T)^i, i = 0 .. 256
-	const unsigned tid = threadIdx.x;
-	{	// powers of B^T by a product scan
-		Fp tot;
-		(void)tot;
-		// sequential doubling through LDS is enough here: 256 entries, once
-		if (tid == 0) { s_pw[0] = Fp{1, 1}; for (unsigned i = 1; i <= FP_THREADS; i++) s_pw[i] = fp_mul(s_pw[i - 1], C.t2[0]); }
-		__syncthreads();
+	const unsigned c = blockIdx.x, tid = threadIdx.x, i = c * FP_THREADS + tid;
+	const Fp xf = i < n ? tiles[4 * (size_t)i + 0] : Fp{0, 0}, xb = i < n ? tiles[4 * (size_t)i + 1] : Fp{0, 0};
+	Fp tf, tb;
+	const Fp ef = scan256<+1>(xf, C.t2, C.t64, lds, tf);
+	const Fp eb = scan256<-1>(xb, C.t2, C.t64, lds, tb);
+	PT[i] = ef;                                                        // prefix inside the chunk, before tile i
+	ST[i] = fp_add(xb, fp_mul(eb, C.t2[0]));                           // suffix inside the chunk, from the start of tile i
+	if (tid == 0) { tot[2 * c] = tf; tot[2 * c + 1] = tb; }
+}
+// cP[c] = prefix hash at the start of chunk c, cS[c] = suffix hash from the start of chunk c (cS[nchunks] = 0)
+__global__ void __launch_bounds__(128) k_fp_carries(const Fp *__restrict__ tot, unsigned nchunks, FpConst C, Fp *__restrict__ cP, Fp *__restrict__ cS)
+{
+	if (threadIdx.x == 0) {
+		Fp h{0, 0};
+		cP[0] = h;
+		for (unsigned c = 0; c < nchunks; c++) { h = fp_add(fp_mul(h, C.tT), tot[2 * c]); cP[c + 1] = h; }
+	} else if (threadIdx.x == 64) {
+		Fp h{0, 0};
+		cS[nchunks] = h;
+		for (unsigned c = nchunks; c-- > 0;) { h = fp_add(tot[2 * c + 1], fp_mul(h, C.tT)); cS[c] = h; }
 	}
-	Fp carry{0, 0};
-	if (tid == 0) PT[0] = carry;
-	for (unsigned base = 0; base < n; base += FP_THREADS) {
-		const unsigned i = base + tid;
-		const Fp x = i < n ? tiles[4 * (size_t)i + 0] : Fp{0, 0};
-		Fp tot;
-		const Fp ex = scan256<+1>(x, C.t2, C.t64, lds, tot);
-		// inclusive prefix after tile i: (ex + carry (B^T)^tid) B^T + x
-		const Fp before = fp_add(ex, fp_mul(carry, s_pw[tid]));
-		if (i < n) PT[i + 1] = fp_add(fp_mul(before, C.t2[0]), x);
-		carry = fp_add(fp_mul(carry, s_pw[FP_THREADS]), tot);
-	}
-	carry = Fp{0, 0};
-	if (tid == 0) ST[n] = carry;
-	// suffixes: chunks from the right; chunk = tiles [lo, lo + 256) with lo = n - 256 m (the first chunk may reach below 0)
-	for (long long hi = (long long)n; hi > 0; hi -= FP_THREADS) {
-		const long long i = hi - (long long)FP_THREADS + (long long)tid;  // this thread's tile
-		const Fp x = i >= 0 ? tiles[4 * (size_t)i + 1] : Fp{0, 0};
-		Fp tot;
-		const Fp ex = scan256<-1>(x, C.t2, C.t64, lds, tot);
-		// suffix from tile i: x + B^T (ex + carry (B^T)^(255 - tid))
-		const Fp after = fp_add(ex, fp_mul(carry, s_pw[FP_THREADS - 1 - tid]));
-		if (i >= 0) ST[i] = fp_add(x, fp_mul(after, C.t2[0]));
-		// tiles below 0 are absent (zero symbols at the LOW end of a suffix scan would shift nothing: they are lower, not higher)
-		carry = fp_add(tot, fp_mul(carry, s_pw[FP_THREADS]));
-		// (tot = sum_u x_u C^u with u = tid: the chunk's suffix hash from its first tile -- when the chunk reaches below tile 0 the absent tiles
-		// contribute zeros at the low end, which scales the hash by (B^T)^(missing); that chunk is the last one, its carry is not used)
-	}
+}
+__global__ void __launch_bounds__(FP_THREADS) k_fp_apply(unsigned nchunks, const Fp *__restrict__ cP, const Fp *__restrict__ cS, const Fp *__restrict__ pwT /* (B^T)^i, i = 0 .. 256 */,
+                                                         Fp *__restrict__ PT, Fp *__restrict__ ST)
+{
+	const unsigned c = blockIdx.x, tid = threadIdx.x, i = c * FP_THREADS + tid;
+	if (c == nchunks) { if (tid == 0) { PT[i] = cP[nchunks]; ST[i] = Fp{0, 0}; } return; }
+	PT[i] = fp_add(PT[i], fp_mul(cP[c], pwT[tid]));
+	ST[i] = fp_add(ST[i], fp_mul(cS[c + 1], pwT[FP_THREADS - tid]));
 }
 
 #define FP_INVALID KB_INVALID
+struct FpRec { u64 k2, v; };                      // what travels with the first key through the partition
 // canonical-orientation key pair of a window and its value (element | masks << 32 | orientation flags << 48), see kmer_bucket_kernels.h
 // F3: one workgroup per tile of window starts.
 __global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict__ pk, size_t nwords, const uint8_t *__restrict__ ch, size_t nelem,
                                                            const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C,
                                                            const Fp *__restrict__ tiles, const Fp *__restrict__ PT, const Fp *__restrict__ ST, const Fp *__restrict__ pwrun /* (B^RUN)^i, i = 0 .. 256 */,
                                                            unsigned test_weak /* SBL_TEST_WEAK_FP: fingerprints reduced to this many bits (0 = off) */,
-                                                           u64 *__restrict__ key1, u64 *__restrict__ key2, u64 *__restrict__ vals)
+                                                           u64 *__restrict__ key1, struct FpRec *__restrict__ rec)
 {
 	__shared__ Fp lds[8];
 	const unsigned t = blockIdx.x, tid = threadIdx.x;
@@ -275,12 +270,11 @@ __global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict
 			if (k1 == KB_EMPTY_KEY) k1 ^= 1ull;                           // (the table's empty marker; the second key and the verification keep this exact)
 			v = (u64)(unsigned)g | ((u64)m << 32) | ((u64)fl << 48);
 		}
-		key1[g] = k1; key2[g] = k2; vals[g] = v;
+		key1[g] = k1; rec[g] = FpRec{k2, v};
 	}
 }
 
 // ------------------------------------------------------------------------------------------- F5: per-bucket tables on 125-bit keys
-struct FpRec { u64 k2, v; };                      // what travels with the first key through the partition
 #define FPB_SLOTS 1024u
 #define FPB_THREADS 256
 #define FPB_MAX_DISTINCT (FPB_SLOTS * 23u / 32u)
@@ -291,19 +285,36 @@ enum { FPB_CTR_PAIRS = 0, FPB_CTR_MEM = 32, FPB_CTR_FLAG = 64, FPB_CTR_WORDS = 9
 #define FPB_PAL 0x2000u                             // tmask bit: some record of the slot had both orientation flags (fingerprint palindrome)
 // pairs[p] = representative: element | orientation << 32 | palindrome << 33 (orientation 0: the + strand k-mer at the element is the canonical one)
 // members[i] = element | (2 pair + orientation) << 32 | (both flags) << 63
+// A workgroup takes FPB_GROUP consecutive buckets and STAGES what they emit in LDS -- one reservation of output ranges per flush instead
+// of one per wave and step (as k_bucket_classify does; the first version reserved per wave: 1.5 M returning atomics on one address
+// on raw strains at k = 100, where a tenth of the windows are members).
+#define FPB_GROUP 16u
+#define FPB_STAGE_MEM 1536u
+#define FPB_STAGE_PAIRS 384u
 __global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restrict__ skey1, const FpRec *__restrict__ srec, const unsigned *__restrict__ boff, unsigned nbuckets,
                                                             unsigned *__restrict__ counters, u64 *__restrict__ pairs, unsigned maxpairs, u64 *__restrict__ members, unsigned maxmembers)
 {
 	__shared__ u64 tkey[FPB_SLOTS], tkey2[FPB_SLOTS], trep[FPB_SLOTS];
 	__shared__ unsigned tmask[FPB_SLOTS], taux[FPB_SLOTS];
-	__shared__ unsigned s_used, s_pairs, s_pbase;
-	const unsigned b = blockIdx.x;
-	if (b >= nbuckets) return;
-	const unsigned lo = boff[b], hi = boff[b + 1];
-	if (lo >= hi) return;
-	for (unsigned i = threadIdx.x; i < FPB_SLOTS; i += FPB_THREADS) { tkey[i] = KB_EMPTY_KEY; tkey2[i] = FPB_K2_EMPTY; trep[i] = ~0ull; tmask[i] = 0; taux[i] = SBL_NONE; }
-	if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; }
+	__shared__ u64 st_mem[FPB_STAGE_MEM], st_pair[FPB_STAGE_PAIRS];
+	__shared__ unsigned s_used, s_pairs, s_np, s_nm, s_bp, s_bm, s_dp;
+	const unsigned b0 = blockIdx.x * FPB_GROUP, b1 = b0 + FPB_GROUP < nbuckets ? b0 + FPB_GROUP : nbuckets;
+	if (b0 >= nbuckets) return;
+	if (threadIdx.x == 0) { s_np = 0; s_nm = 0; }
 	__syncthreads();
+	// everything staged goes out: one reservation per output array, then coalesced stores with the pair base added
+	auto flush = [&]() {
+		__syncthreads();
+		const unsigned np = s_np, nm = s_nm < FPB_STAGE_MEM ? s_nm : FPB_STAGE_MEM;
+		if (threadIdx.x == 0) { s_bp = np ? atomicAdd(&counters[FPB_CTR_PAIRS], np) : 0u; s_bm = nm ? atomicAdd(&counters[FPB_CTR_MEM], nm) : 0u; }
+		__syncthreads();
+		const unsigned bp = s_bp, bm = s_bm;
+		for (unsigned i = threadIdx.x; i < np; i += FPB_THREADS) if (bp + i < maxpairs) pairs[bp + i] = st_pair[i];
+		for (unsigned i = threadIdx.x; i < nm; i += FPB_THREADS) if (bm + i < maxmembers) members[bm + i] = st_mem[i] + ((u64)(2u * bp) << 32);
+		__syncthreads();
+		if (threadIdx.x == 0) { s_np = 0; s_nm = 0; }
+		__syncthreads();
+	};
 	// slot of (k1, k2): claimed on k1 by compare-and-swap; its identity is whichever second key arrives first (a second compare-and-swap);
 	// a record with the same first and another second key moves on.  claim = false: look-up only (everything is inserted by then).
 	auto slot_of = [&](u64 k1, u64 k2, bool claim) -> unsigned {
@@ -319,55 +330,74 @@ __global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restri
 		if (claim) atomicAdd(&s_used, FPB_SLOTS);
 		return SBL_NONE;
 	};
-	for (unsigned i = lo + threadIdx.x; i < hi; i += FPB_THREADS) {
-		if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;       // too many distinct k-mers for this table: the host re-buckets
-		const FpRec r = srec[i];
-		if (r.v == FP_INVALID) continue;
-		const unsigned h = slot_of(skey1[i], r.k2, true);
-		if (h == SBL_NONE) break;
-		const unsigned fl = (unsigned)(r.v >> 48) & 3u;
-		atomicOr(&tmask[h], ((unsigned)(r.v >> 32) & 0x1FFFu) | (fl == 3u ? FPB_PAL : 0u));
-		// representative: the lowest element of the group (deterministic), with its orientation
-		atomicMin(&trep[h], ((r.v & 0xFFFFFFFFull) << 1) | ((fl & 1u) ? 0ull : 1ull));
+	for (unsigned b = b0; b < b1; b++) {
+		const unsigned lo = boff[b], hi = boff[b + 1];
+		if (lo >= hi) continue;
+		__syncthreads();
+		if (s_nm > FPB_STAGE_MEM / 2 || s_np > FPB_STAGE_PAIRS / 2) flush();
+		for (unsigned i = threadIdx.x; i < FPB_SLOTS; i += FPB_THREADS) { tkey[i] = KB_EMPTY_KEY; tkey2[i] = FPB_K2_EMPTY; trep[i] = ~0ull; tmask[i] = 0; taux[i] = SBL_NONE; }
+		if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; }
+		__syncthreads();
+		for (unsigned i = lo + threadIdx.x; i < hi; i += FPB_THREADS) {
+			if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;       // too many distinct k-mers for this table: the host re-buckets
+			const FpRec r = srec[i];
+			if (r.v == FP_INVALID) continue;
+			const unsigned h = slot_of(skey1[i], r.k2, true);
+			if (h == SBL_NONE) break;
+			const unsigned fl = (unsigned)(r.v >> 48) & 3u;
+			atomicOr(&tmask[h], ((unsigned)(r.v >> 32) & 0x1FFFu) | (fl == 3u ? FPB_PAL : 0u));
+			// representative: the lowest element of the group (deterministic), with its orientation
+			atomicMin(&trep[h], ((r.v & 0xFFFFFFFFull) << 1) | ((fl & 1u) ? 0ull : 1ull));
+		}
+		__syncthreads();
+		if (s_used > FPB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[FPB_CTR_FLAG], 1u); return; }   // (uniform; the host discards everything)
+		for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+			if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx] & 0x1FFFu)) continue;
+			taux[sidx] = atomicAdd(&s_pairs, 1u);
+		}
+		__syncthreads();
+		const unsigned npairs = s_pairs;
+		if (!npairs) continue;
+		// staged when it fits (flushing first if need be); a bucket with more pairs than the stage holds or more records than the member
+		// stage could take (low-complexity input: one k-mer, thousands of occurrences) reserves its ranges itself and writes directly
+		const bool direct = npairs > FPB_STAGE_PAIRS / 2 || hi - lo > FPB_STAGE_MEM / 2;
+		if (direct) {
+			flush();                                                   // pair indices below are final, nothing staged refers to them
+			if (threadIdx.x == 0) s_dp = atomicAdd(&counters[FPB_CTR_PAIRS], npairs);
+			__syncthreads();
+		}
+		const unsigned pbase = direct ? s_dp : s_np;
+		for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+			const unsigned a = taux[sidx];
+			if (a == SBL_NONE) continue;
+			const unsigned pi = pbase + a;
+			const u64 rep = (trep[sidx] >> 1) | ((trep[sidx] & 1ull) << 32) | ((tmask[sidx] & FPB_PAL) ? 1ull << 33 : 0ull);
+			if (direct) { if (pi < maxpairs) pairs[pi] = rep; } else st_pair[pi] = rep;
+			taux[sidx] = pi;                                           // staged pair index, or the final one (direct)
+		}
+		__syncthreads();
+		if (threadIdx.x == 0 && !direct) s_np += npairs;
+		// member positions of the bifurcation k-mers: staged entries carry the STAGED pair index (the flush adds the base)
+		for (unsigned i0 = lo; i0 < hi; i0 += FPB_THREADS) {
+			const unsigned i = i0 + threadIdx.x;
+			FpRec r{0, FP_INVALID};
+			if (i < hi) r = srec[i];
+			unsigned pi = SBL_NONE;
+			if (r.v != FP_INVALID) { const unsigned h = slot_of(skey1[i], r.k2, false); if (h != SBL_NONE) pi = taux[h]; }
+			const bool mem = pi != SBL_NONE;
+			const u64 bal = __ballot(mem);
+			if (!bal) continue;
+			const unsigned lane = threadIdx.x & 63u, first = (unsigned)__builtin_ctzll(bal);
+			unsigned base = 0;
+			if (lane == first) base = direct ? atomicAdd(&counters[FPB_CTR_MEM], (unsigned)__popcll(bal)) : atomicAdd(&s_nm, (unsigned)__popcll(bal));
+			base = __shfl(base, first);
+			const unsigned at = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+			const unsigned fl = (unsigned)(r.v >> 48) & 3u;
+			const u64 rec = (r.v & 0xFFFFFFFFull) | ((u64)(2u * pi + ((fl & 1u) ? 0u : 1u)) << 32) | (fl == 3u ? 1ull << 63 : 0ull);
+			if (mem) { if (direct) { if (at < maxmembers) members[at] = rec; } else if (at < FPB_STAGE_MEM) st_mem[at] = rec; }
+		}
 	}
-	__syncthreads();
-	if (s_used > FPB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[FPB_CTR_FLAG], 1u); return; }   // (uniform; the host discards everything)
-	for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
-		if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx] & 0x1FFFu)) continue;
-		taux[sidx] = atomicAdd(&s_pairs, 1u);
-	}
-	__syncthreads();
-	const unsigned npairs = s_pairs;
-	if (!npairs) return;
-	if (threadIdx.x == 0) s_pbase = atomicAdd(&counters[FPB_CTR_PAIRS], npairs);
-	__syncthreads();
-	const unsigned pbase = s_pbase;
-	for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
-		const unsigned a = taux[sidx];
-		if (a == SBL_NONE) continue;
-		const unsigned pi = pbase + a;
-		if (pi < maxpairs) pairs[pi] = (trep[sidx] >> 1) | ((trep[sidx] & 1ull) << 32) | ((tmask[sidx] & FPB_PAL) ? 1ull << 33 : 0ull);
-		taux[sidx] = pi;
-	}
-	__syncthreads();
-	// member positions of the bifurcation k-mers: one reservation per wave and step
-	for (unsigned i0 = lo; i0 < hi; i0 += FPB_THREADS) {
-		const unsigned i = i0 + threadIdx.x;
-		FpRec r{0, FP_INVALID};
-		if (i < hi) r = srec[i];
-		unsigned pi = SBL_NONE;
-		if (r.v != FP_INVALID) { const unsigned h = slot_of(skey1[i], r.k2, false); if (h != SBL_NONE) pi = taux[h]; }
-		const bool mem = pi != SBL_NONE;
-		const u64 bal = __ballot(mem);
-		if (!bal) continue;
-		const unsigned lane = threadIdx.x & 63u;
-		unsigned base = 0;
-		if (lane == (unsigned)__builtin_ctzll(bal)) base = atomicAdd(&counters[FPB_CTR_MEM], (unsigned)__popcll(bal));
-		base = __shfl(base, __builtin_ctzll(bal));
-		const unsigned at = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-		const unsigned fl = (unsigned)(r.v >> 48) & 3u;
-		if (mem && at < maxmembers) members[at] = (r.v & 0xFFFFFFFFull) | ((u64)(2u * pi + ((fl & 1u) ? 0u : 1u)) << 32) | (fl == 3u ? 1ull << 63 : 0ull);
-	}
+	flush();
 }
 
 // ------------------------------------------------------------------------------------------- sequence access for verification and ranking
@@ -456,6 +486,30 @@ __global__ void __launch_bounds__(256) k_fp_rank_apply(const unsigned *__restric
 	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j < n) rank[sidx[j]] = gstart[j];
 }
+// A small set (the cascade states leave a few hundred bifurcation k-mers): rank by counting in ONE launch -- a wave per string, a lane per
+// other string, compared chunk by chunk (first difference decides) -- instead of k / 27 rounds of {keys, sort, heads, scan, apply, host read}
+#define FP_RANK_SMALL 1024u
+__global__ void __launch_bounds__(64) k_fp_rank_small(const u64 *__restrict__ pk, const u64 *__restrict__ ref, unsigned n, unsigned k, unsigned *__restrict__ rank)
+{
+	const unsigned i = blockIdx.x, lane = threadIdx.x;
+	if (i >= n) return;
+	const u64 ri = ref[i];
+	const unsigned gi = (unsigned)ri, oi = (unsigned)(ri >> 32) & 1u;
+	unsigned below = 0;
+	for (unsigned j = lane; j < n; j += 64) {
+		if (j == i) continue;
+		const u64 rj = ref[j];
+		const unsigned gj = (unsigned)rj, oj = (unsigned)(rj >> 32) & 1u;
+		for (unsigned off = 0; off < k; off += 32) {
+			const unsigned len = k - off < 32u ? k - off : 32u;
+			const u64 a = fp_chunk(pk, gi, oi, k, off, len), b = fp_chunk(pk, gj, oj, k, off, len);
+			if (a != b) { below += b < a; break; }
+		}
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) below += __shfl_down(below, d);
+	if (lane == 0) rank[i] = below;
+}
 // final: every string has its own rank = its id
 __global__ void __launch_bounds__(256) k_fp_rank_ids(const unsigned *__restrict__ rank, const unsigned *__restrict__ payload, const u64 *__restrict__ pairs, unsigned n, unsigned *__restrict__ pairids)
 {
@@ -485,15 +539,9 @@ __global__ void __launch_bounds__(256) k_fp_bucket_bounds(const u64 *__restrict_
 	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((skeys[mid] & (nb - 1)) < b) lo = mid + 1; else hi = mid; }
 	boff[b] = (unsigned)lo;
 }
-__global__ void __launch_bounds__(256) k_fp_pack_rec(const u64 *__restrict__ k2, const u64 *__restrict__ v, size_t n, FpRec *__restrict__ out)
-{
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = FpRec{k2[i], v[i]};
-}
-
 // ------------------------------------------------------------------------------------------- host
 struct LongKFpScratch {
-	DevBuf tiles, PT, ST, pwrun, key1, key2, vals, rec, skey1, srec, tmp, boff, ctr, pairs, members, ref, payload, rank, keys, skeys, idx, sidx, head, gstart, pairids;
+	DevBuf tiles, PT, ST, pwrun, pwT, ctot, cP, cS, key1, rec, skey1, srec, tmp, boff, ctr, pairs, members, ref, payload, rank, keys, skeys, idx, sidx, head, gstart, pairids;
 };
 struct LongKFpHolder { LongKFpScratch s; };
 static LongKFpScratch &fp_of(sbl_ctx *c)
@@ -505,7 +553,7 @@ void sbl_longk_fp_free(sbl_ctx *c)
 {
 	if (!c->lkfp) return;
 	LongKFpScratch &L = c->lkfp->s;
-	for (DevBuf *b : { &L.tiles, &L.PT, &L.ST, &L.pwrun, &L.key1, &L.key2, &L.vals, &L.rec, &L.skey1, &L.srec, &L.tmp, &L.boff, &L.ctr, &L.pairs, &L.members, &L.ref, &L.payload, &L.rank,
+	for (DevBuf *b : { &L.tiles, &L.PT, &L.ST, &L.pwrun, &L.pwT, &L.ctot, &L.cP, &L.cS, &L.key1, &L.rec, &L.skey1, &L.srec, &L.tmp, &L.boff, &L.ctr, &L.pairs, &L.members, &L.ref, &L.payload, &L.rank,
 	                   &L.keys, &L.skeys, &L.idx, &L.sidx, &L.head, &L.gstart, &L.pairids })
 		b->release();
 	delete c->lkfp;
@@ -547,25 +595,29 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	{ Fp x = BT; for (int i = 0; i < 6; i++) { C.t2[i] = x; x = fp_mul(x, x); } C.t64 = x; C.tT = fp_pow(BT, FP_THREADS); }
 	const unsigned ntiles = (unsigned)((E + FP_TILE - 1) / FP_TILE), nx = ntiles + C.q + 3;
 	const size_t n = (size_t)ntiles * FP_TILE;                                  // records (one per element slot of the tiles)
-	L.pwrun.ensure((FP_THREADS + 1) * sizeof(Fp));
+	L.pwrun.ensure((FP_THREADS + 1) * sizeof(Fp)); L.pwT.ensure((FP_THREADS + 1) * sizeof(Fp));
 	{
-		std::vector<Fp> pw(FP_THREADS + 1);
-		pw[0] = Fp{1, 1};
-		for (unsigned i = 1; i <= FP_THREADS; i++) pw[i] = fp_mul(pw[i - 1], Crun);
-		HIP_TRY(hipMemcpyAsync(L.pwrun.p, pw.data(), pw.size() * sizeof(Fp), hipMemcpyHostToDevice, s));
+		std::vector<Fp> pw(2 * (FP_THREADS + 1));
+		pw[0] = pw[FP_THREADS + 1] = Fp{1, 1};
+		for (unsigned i = 1; i <= FP_THREADS; i++) { pw[i] = fp_mul(pw[i - 1], Crun); pw[FP_THREADS + 1 + i] = fp_mul(pw[FP_THREADS + i], BT); }
+		HIP_TRY(hipMemcpyAsync(L.pwrun.p, pw.data(), (FP_THREADS + 1) * sizeof(Fp), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(L.pwT.p, pw.data() + FP_THREADS + 1, (FP_THREADS + 1) * sizeof(Fp), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));                                       // (pw is a local)
 	}
-	L.tiles.ensure((size_t)nx * 4 * sizeof(Fp)); L.PT.ensure(((size_t)nx + 1) * sizeof(Fp)); L.ST.ensure(((size_t)nx + 1) * sizeof(Fp));
-	L.key1.ensure(n * 8); L.key2.ensure(n * 8); L.vals.ensure(n * 8); L.rec.ensure(n * 16); L.skey1.ensure(n * 8); L.srec.ensure(n * 16);
+	const unsigned ntchunks = (nx + FP_THREADS - 1) / FP_THREADS;
+	L.tiles.ensure((size_t)nx * 4 * sizeof(Fp)); L.PT.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp)); L.ST.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp));
+	L.ctot.ensure((size_t)ntchunks * 2 * sizeof(Fp)); L.cP.ensure(((size_t)ntchunks + 1) * sizeof(Fp)); L.cS.ensure(((size_t)ntchunks + 1) * sizeof(Fp));
+	L.key1.ensure(n * 8); L.rec.ensure(n * 16); L.skey1.ensure(n * 8); L.srec.ensure(n * 16);
 	L.ctr.ensure(256 * 4);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
 	k_fp_tiles<<<nx, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, nx, C, L.tiles.as<Fp>());
-	k_fp_tilescan<<<1, FP_THREADS, 0, s>>>(L.tiles.as<Fp>(), nx, C, L.PT.as<Fp>(), L.ST.as<Fp>());
+	k_fp_chunks<<<ntchunks, FP_THREADS, 0, s>>>(L.tiles.as<Fp>(), nx, C, L.PT.as<Fp>(), L.ST.as<Fp>(), L.ctot.as<Fp>());
+	k_fp_carries<<<1, 128, 0, s>>>(L.ctot.as<Fp>(), ntchunks, C, L.cP.as<Fp>(), L.cS.as<Fp>());
+	k_fp_apply<<<ntchunks + 1, FP_THREADS, 0, s>>>(ntchunks, L.cP.as<Fp>(), L.cS.as<Fp>(), L.pwT.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>());
 	unsigned weak = 0;
 	if (const char *e = getenv("SBL_TEST_WEAK_FP")) weak = (unsigned)std::min(60, std::max(0, atoi(e)));      // test hook: collisions on purpose (the verification must notice)
 	k_fp_records<<<ntiles, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C,
-	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.key2.as<u64>(), L.vals.as<u64>());
-	k_fp_pack_rec<<<nblocks(n, 256), 256, 0, s>>>(L.key2.as<u64>(), L.vals.as<u64>(), n, L.rec.as<FpRec>());
+	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.rec.as<FpRec>());
 	HIP_TRY(hipGetLastError());
 
 	unsigned bits = 4;
@@ -587,7 +639,7 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		}
 		L.pairs.ensure(maxpairs * 8 + 16); L.members.ensure(maxmembers * 8 + 16);
 		HIP_TRY(hipMemsetAsync(L.ctr.p, 0, 256 * 4, s));
-		k_fp_classify<<<(unsigned)((size_t)1 << bits), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<FpRec>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
+		k_fp_classify<<<nblocks((size_t)1 << bits, FPB_GROUP), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<FpRec>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
 		                                                                   L.pairs.as<u64>(), (unsigned)maxpairs, L.members.as<u64>(), (unsigned)maxmembers);
 		HIP_TRY(hipGetLastError());
 		unsigned all[FPB_CTR_WORDS];
@@ -631,11 +683,13 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		HIP_TRY(hipMemsetAsync(L.rank.p, 0, cap * 4, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		const unsigned rbits = fp_bits(nkeys ? nkeys - 1 : 0), csym = std::min(27u, (64u - rbits) / 2u);
+		const bool small = nkeys <= FP_RANK_SMALL && getenv("SBL_FP_RANK_ROUNDS") == nullptr;      // (SBL_FP_RANK_ROUNDS=1: test switch, the refinement rounds for every size)
+		if (small) k_fp_rank_small<<<nkeys, 64, 0, s>>>(c->d_pk.as<u64>(), L.ref.as<u64>(), nkeys, k, L.rank.as<unsigned>());
 		size_t tsort = 0, tscan = 0;
 		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tsort, L.keys.as<u64>(), L.skeys.as<u64>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), nkeys, 0, 64, s));
 		HIP_TRY(rocprim::inclusive_scan(nullptr, tscan, L.head.as<unsigned>(), L.gstart.as<unsigned>(), nkeys, MaxU32(), s));
 		L.tmp.ensure(std::max(tsort, tscan));
-		for (unsigned off = 0; off < k; off += csym) {
+		for (unsigned off = 0; off < k && !small; off += csym) {
 			HIP_TRY(hipMemsetAsync(d_nheads, 0, 4, s));
 			k_fp_rank_keys<<<nblocks(nkeys, 256), 256, 0, s>>>(c->d_pk.as<u64>(), L.ref.as<u64>(), L.rank.as<unsigned>(), nkeys, k, off, csym, L.keys.as<u64>(), L.idx.as<unsigned>());
 			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tsort, L.keys.as<u64>(), L.skeys.as<u64>(), L.idx.as<unsigned>(), L.sidx.as<unsigned>(), nkeys, 0, std::min(64u, rbits + 2 * csym), s));

@@ -115,6 +115,23 @@ def test_many_short_records_and_a_cascade(monkeypatch):
         bf.close()
 
 
+@pytest.mark.parametrize("k", [40, 300, 1100])
+def test_ranking_by_refinement_rounds_equals_ranking_by_counting(k, monkeypatch):
+    """a few hundred bifurcation k-mers are ranked in one launch (k_fp_rank_small); SBL_FP_RANK_ROUNDS=1 sends the same set through the
+    MSD refinement rounds that larger sets take"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    seqs = W.gen_strains(L0=6_000, n=3, seed=5, snp=0.004, inv_min=200, inv_max=600)
+    want = Oracle(seqs).enumerate(k)
+    assert 0 < want[0] <= 1024
+    a, path = _enumerate(seqs, k, monkeypatch)
+    assert path == 1
+    monkeypatch.setenv("SBL_FP_RANK_ROUNDS", "1")
+    b, path = _enumerate(seqs, k, monkeypatch)
+    monkeypatch.delenv("SBL_FP_RANK_ROUNDS")
+    _same(a, want, "counting"); _same(b, want, "rounds")
+
+
 def test_random_long_k_cases(monkeypatch):
     """randomised: strain sets with their own record splits, random k in 33 .. 1500"""
     from oracle.oracle import Oracle
