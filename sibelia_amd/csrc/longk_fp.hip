@@ -9,15 +9,15 @@
 //   F2 k_fp_chunks / k_fp_carries / k_fp_apply  prefix (left to right) and suffix (right to left) hashes at the tile boundaries
 //   F3 k_fp_records   per window start g: F(w) = P[g+k] - P[g] B^k and F(rc(w)) = 3 G_k - (S[g] - B^k S[g+k]) from block scans of the
 //                     tile at g and of the tile range at g + k (nothing per element is kept in HBM); the record of the CANONICAL
-//                     orientation (smaller fingerprint pair): {mix64(h1), h2, element | prev/next masks | orientation} -- 24 B written
+//                     orientation (smaller fingerprint pair): {mix64(h1 | 3 bits of h2), element | prev/next masks | orientation | 20 bits of h2} -- 16 B written
 //   F4 partition      by the hash prefix of the first key, as at k <= 32
-//   F5 k_fp_classify  one LDS open-addressing table per bucket keyed by the 125-bit pair (slot claimed on the first key by ds cmpswap,
-//                     identity settled on the second), masks OR-ed, Bifurcation() test (vertexenumeration.cpp:67-70,:330) per
+//   F5 k_fp_classify  one LDS open-addressing table per bucket keyed by the 84-bit fingerprint (slot claimed on the 64-bit key by ds cmpswap,
+//                     identity settled on the 20 further bits), masks OR-ed, Bifurcation() test (vertexenumeration.cpp:67-70,:330) per
 //                     distinct fingerprint, representative window + member positions of the bifurcation k-mers
 //   F6 k_fp_verify    EVERY member of a bifurcation group is compared with the group's representative on the 2-bit sequence
 //                     (k / 4 B per occurrence).  Two different k-mers with one fingerprint can only MERGE groups (masks are OR-ed:
 //                     bits are added, never lost), so an unverified table has false positives only, and all positives are verified:
-//                     a mismatch (never observed: 2^-125 per pair of windows) abandons the path and the exact rank doubling runs.
+//                     a mismatch (never observed: 2^-84 per pair of windows) abandons the path and the exact rank doubling runs.
 //   F7 ranking        ids = lexicographic rank among the bifurcation k-mers (:348-355) -- a few per cent of the windows at most:
 //                     MSD refinement over chunks of <= 27 symbols of the representatives (library sorts on this SUBSET only)
 //   F8 k_fp_marks     bif[0][g] / bif[1][g+k-1] of the member positions (marking, indexedsequence.cpp:49-67)
@@ -57,9 +57,9 @@ __host__ __device__ __forceinline__ Fp fp_sub(Fp x, Fp y) { return Fp{sub61(x.a,
 __host__ __device__ __forceinline__ Fp fp_sym(unsigned s) { return Fp{(u64)s, (u64)s}; }
 __host__ __device__ __forceinline__ Fp fp_horner(Fp h, Fp base, unsigned s) { return Fp{add61(mul61(h.a, base.a), (u64)s), h.b * base.b + s}; }   // h B + s
 
-#define FP_TILE 1024u                             // elements per tile = 256 threads x FP_RUN
-#define FP_RUN 4u
-#define FP_THREADS 256u
+#define FP_TILE 512u                              // elements per tile = one wave x FP_RUN (the scans inside a tile are wave scans: no LDS, no barrier)
+#define FP_RUN 8u
+#define FP_THREADS 256u                           // four tiles per workgroup
 // constants of one enumeration (host-computed, passed by value)
 struct FpConst {
 	Fp B;                                         // the bases
@@ -120,7 +120,27 @@ __device__ __forceinline__ Fp scan256(Fp x, const Fp *c2, Fp c64, Fp *lds, Fp &t
 	return fp_add(exc, fp_mul(carry, pwe));
 }
 
-// FP_RUN symbols from element e (2 bit each, first in the high bits of the byte); elements beyond the packed array read 0
+// The same over the 64 chunks of ONE wave (a tile): shuffles only.  pwl = C^lane (DIR = +1) / C^(63 - lane) (DIR = -1) is not needed here --
+// there is no carry from outside the wave; the caller adds its seed.
+template <int DIR>
+__device__ __forceinline__ Fp scan64(Fp x, const Fp *c2, Fp &total)
+{
+	const unsigned lane = threadIdx.x & 63u;
+	Fp inc = x;
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		const unsigned d = 1u << i;
+		const Fp y = DIR > 0 ? fp_shfl_up(inc, d) : fp_shfl_down(inc, d);
+		const bool in = DIR > 0 ? lane >= d : lane + d < 64u;
+		if (in) inc = fp_add(inc, fp_mul(y, c2[i]));
+	}
+	Fp exc = DIR > 0 ? fp_shfl_up(inc, 1) : fp_shfl_down(inc, 1);
+	if (DIR > 0 ? lane == 0 : lane == 63u) exc = Fp{0, 0};
+	total = fp_shfl(inc, DIR > 0 ? 63 : 0);
+	return exc;
+}
+
+// FP_RUN symbols from element e (2 bit each, first in the high bits of the result); elements beyond the packed array read 0
 __device__ __forceinline__ unsigned fp_syms(const u64 *__restrict__ pk, size_t nwords, size_t e)
 {
 	const size_t w = e >> 5; const unsigned o = (unsigned)(e & 31u);
@@ -131,40 +151,33 @@ __device__ __forceinline__ unsigned fp_syms(const u64 *__restrict__ pk, size_t n
 }
 __device__ __forceinline__ unsigned fp_sym_at(unsigned four, unsigned j) { return (four >> (2 * (FP_RUN - 1 - j))) & 3u; }
 
-// F1: per tile t (FP_TILE elements from t T): out[4 t + 0] forward hash of the tile, + 1 backward hash, + 2 forward hash of its first r
-// symbols, + 3 backward hash of its symbols r .. T-1 (weights B^(j - r))
+// F1: per tile t (FP_TILE elements from t T), one wave: out[4 t + 0] forward hash of the tile, + 1 backward hash, + 2 forward hash of its
+// first r symbols, + 3 backward hash of its symbols r .. T-1 (weights B^(j - r))
 __global__ void __launch_bounds__(FP_THREADS) k_fp_tiles(const u64 *__restrict__ pk, size_t nwords, unsigned ntiles_ext, FpConst C, Fp *__restrict__ out)
 {
-	__shared__ Fp lds[8];
-	const unsigned t = blockIdx.x, tid = threadIdx.x;
+	const unsigned t = blockIdx.x * (FP_THREADS / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if (t >= ntiles_ext) return;
-	const unsigned four = fp_syms(pk, nwords, (size_t)t * FP_TILE + (size_t)tid * FP_RUN);
-	// whole tile
+	const unsigned syms = fp_syms(pk, nwords, (size_t)t * FP_TILE + (size_t)lane * FP_RUN);
 	Fp hf{0, 0}, hb{0, 0};
 #pragma unroll
-	for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(four, j));
+	for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(syms, j));
 #pragma unroll
-	for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(four, j));
+	for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(syms, j));
 	Fp totF, totB;
-	// hash(first r symbols) = the exclusive prefix of the thread that holds element r, continued over its first r mod RUN symbols;
+	// hash(first r symbols) = the exclusive prefix of the lane that holds element r, continued over its first r mod RUN symbols;
 	// likewise the suffix hash from element r
 	const unsigned r = C.r, rt = r / FP_RUN, rj = r % FP_RUN;
-	const Fp exF = scan256<+1>(hf, C.c2, C.c64, lds, totF);
-	const Fp exB = scan256<-1>(hb, C.c2, C.c64, lds, totB);
-	__shared__ Fp part[2];
-	if (tid == rt) {
-		Fp pf = exF;                                                   // hash of the elements before this thread's chunk
-		for (unsigned j = 0; j < rj; j++) pf = fp_horner(pf, C.B, fp_sym_at(four, j));
-		Fp pb = exB;                                                   // suffix hash from the element after this thread's chunk
-		for (unsigned j = FP_RUN; j-- > rj;) pb = fp_horner(pb, C.B, fp_sym_at(four, j));
-		part[0] = pf; part[1] = pb;
+	const Fp exF = scan64<+1>(hf, C.c2, totF);
+	const Fp exB = scan64<-1>(hb, C.c2, totB);
+	if (lane == rt) {
+		Fp pf = exF;                                                   // hash of the elements before this lane's chunk
+		for (unsigned j = 0; j < rj; j++) pf = fp_horner(pf, C.B, fp_sym_at(syms, j));
+		Fp pb = exB;                                                   // suffix hash from the element after this lane's chunk
+		for (unsigned j = FP_RUN; j-- > rj;) pb = fp_horner(pb, C.B, fp_sym_at(syms, j));
+		out[4 * (size_t)t + 2] = r ? pf : Fp{0, 0};
+		out[4 * (size_t)t + 3] = pb;                                  // (r = 0: lane 0, all FP_RUN symbols: the whole tile)
 	}
-	__syncthreads();
-	if (tid == 0) {
-		out[4 * (size_t)t + 0] = totF; out[4 * (size_t)t + 1] = totB;
-		out[4 * (size_t)t + 2] = r ? part[0] : Fp{0, 0};
-		out[4 * (size_t)t + 3] = part[1];                             // (r = 0: thread 0, all FP_RUN symbols: the whole tile)
-	}
+	if (lane == 0) { out[4 * (size_t)t + 0] = totF; out[4 * (size_t)t + 1] = totB; }
 }
 
 // F2: PT[t] = forward prefix hash at element t T (PT[0] = 0), ST[t] = suffix hash from element t T, t = 0 .. 256 nchunks.  Base of these
@@ -206,96 +219,136 @@ __global__ void __launch_bounds__(FP_THREADS) k_fp_apply(unsigned nchunks, const
 }
 
 #define FP_INVALID KB_INVALID
-struct FpRec { u64 k2, v; };                      // what travels with the first key through the partition
+// A record is 16 B, like at k <= 32: key = mix64(h1 | (h2 & 7) << 61) (a bijection of the 64 bits: bucket, table slot and 64 bits of identity),
+// value = element (32) | prev mask (5) | next mask (5) | orientation flags (2) | 20 more bits of h2: an 84-bit fingerprint.  (The first
+// version carried all 125 bits in 24-B records: + 50 % on every pass of the table build for a collision rate that is 1e-6 per run at
+// 1.8 G windows either way far below anything observable -- and the result is exact either way: every positive is verified.)
+#define FP_V_PREV 32
+#define FP_V_NEXT 37
+#define FP_V_FL 42
+#define FP_V_H2 44
+__device__ __forceinline__ bool fp_mask_bif(unsigned m10) { const unsigned p = m10 & 31u, n = (m10 >> 5) & 31u; return (p & 16u) || (n & 16u) || __popc(p & 15u) > 1 || __popc(n & 15u) > 1; }
 // canonical-orientation key pair of a window and its value (element | masks << 32 | orientation flags << 48), see kmer_bucket_kernels.h
-// F3: one workgroup per tile of window starts.
+// F3: one WAVE per tile of window starts, FP_RUN consecutive windows per lane.  The prefix / suffix hashes of the tile's own range and of
+// the range k further on come from two wave scans each (seeds from F2); only the two fingerprints per window are kept in registers.
 __global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict__ pk, size_t nwords, const uint8_t *__restrict__ ch, size_t nelem,
-                                                           const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C,
-                                                           const Fp *__restrict__ tiles, const Fp *__restrict__ PT, const Fp *__restrict__ ST, const Fp *__restrict__ pwrun /* (B^RUN)^i, i = 0 .. 256 */,
+                                                           const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C, unsigned ntiles,
+                                                           const Fp *__restrict__ tiles, const Fp *__restrict__ PT, const Fp *__restrict__ ST, const Fp *__restrict__ pwrun /* (B^RUN)^i, i = 0 .. 64 */,
                                                            unsigned test_weak /* SBL_TEST_WEAK_FP: fingerprints reduced to this many bits (0 = off) */,
-                                                           u64 *__restrict__ key1, struct FpRec *__restrict__ rec)
+                                                           u64 *__restrict__ key1, u64 *__restrict__ rec)
 {
-	__shared__ Fp lds[8];
-	const unsigned t = blockIdx.x, tid = threadIdx.x;
+	const unsigned t = blockIdx.x * (FP_THREADS / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= ntiles) return;
 	const size_t a0 = (size_t)t * FP_TILE, a1 = a0 + C.k;
-	// seeds: forward prefix at the start of each range, suffix hash from the end of each range
-	const Fp seedP0 = PT[t], seedS0 = ST[t + 1];
 	const size_t t1 = (size_t)t + C.q;
-	const Fp seedP1 = fp_add(fp_mul(PT[t1], C.Br), tiles[4 * t1 + 2]);
-	const Fp seedS1 = fp_add(tiles[4 * (t1 + 1) + 3], fp_mul(ST[t1 + 2], C.BTr));
-	Fp P0[FP_RUN], S0[FP_RUN], P1[FP_RUN], S1[FP_RUN];
-	const Fp pwl = pwrun[tid], pwr = pwrun[FP_THREADS - 1 - tid];       // B^(RUN tid), B^(T - RUN (tid + 1))
-#pragma unroll
-	for (int range = 0; range < 2; range++) {
-		const size_t a = range ? a1 : a0;
-		const unsigned four = fp_syms(pk, nwords, a + (size_t)tid * FP_RUN);
+	const Fp pwl = pwrun[lane], pwr = pwrun[63u - lane];                // B^(RUN lane), B^(T - RUN (lane + 1))
+	Fp F[FP_RUN], R[FP_RUN];                                           // first the prefix / suffix hashes at g, then F(w) / F(rc(w))
+	{	// the tile's own range: P[g] and S[g]
+		const unsigned syms = fp_syms(pk, nwords, a0 + (size_t)lane * FP_RUN);
 		Fp hf{0, 0}, hb{0, 0};
 #pragma unroll
-		for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(four, j));
+		for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(syms, j));
 #pragma unroll
-		for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(four, j));
+		for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(syms, j));
 		Fp tot;
-		const Fp exF = scan256<+1>(hf, C.c2, C.c64, lds, tot);
-		const Fp exB = scan256<-1>(hb, C.c2, C.c64, lds, tot);
-		Fp hh = fp_add(fp_mul(range ? seedP1 : seedP0, pwl), exF);      // prefix hash at the thread's first element
+		const Fp exF = scan64<+1>(hf, C.c2, tot), exB = scan64<-1>(hb, C.c2, tot);
+		Fp hh = fp_add(fp_mul(PT[t], pwl), exF);                          // prefix hash at the lane's first element
 #pragma unroll
-		for (unsigned j = 0; j < FP_RUN; j++) { if (range) P1[j] = hh; else P0[j] = hh; hh = fp_horner(hh, C.B, fp_sym_at(four, j)); }
-		hh = fp_add(fp_mul(range ? seedS1 : seedS0, pwr), exB);         // suffix hash from the element behind the thread's last one
+		for (unsigned j = 0; j < FP_RUN; j++) { F[j] = hh; hh = fp_horner(hh, C.B, fp_sym_at(syms, j)); }
+		hh = fp_add(fp_mul(ST[t + 1], pwr), exB);                         // suffix hash from the element behind the lane's last one
 #pragma unroll
-		for (unsigned j = FP_RUN; j-- > 0;) { hh = fp_horner(hh, C.B, fp_sym_at(four, j)); if (range) S1[j] = hh; else S0[j] = hh; }
+		for (unsigned j = FP_RUN; j-- > 0;) { hh = fp_horner(hh, C.B, fp_sym_at(syms, j)); R[j] = hh; }
 	}
-	// chromosome of the thread's first element: sepidx[c] < g < sepidx[c+1] (a separator itself belongs to nobody)
-	const size_t g0 = a0 + (size_t)tid * FP_RUN;
-	unsigned c = 0;
-	{ unsigned lo = 0, hi = nchr; const unsigned e = (unsigned)(g0 < nelem ? g0 : nelem - 1); while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (sepidx[mid] < e) lo = mid; else hi = mid; } c = lo; }
+	{	// the range k further on: P[g + k] and S[g + k], combined at once
+		const Fp seedP = fp_add(fp_mul(PT[t1], C.Br), tiles[4 * t1 + 2]);
+		const Fp seedS = fp_add(tiles[4 * (t1 + 1) + 3], fp_mul(ST[t1 + 2], C.BTr));
+		const unsigned syms = fp_syms(pk, nwords, a1 + (size_t)lane * FP_RUN);
+		Fp hf{0, 0}, hb{0, 0};
+#pragma unroll
+		for (unsigned j = 0; j < FP_RUN; j++) hf = fp_horner(hf, C.B, fp_sym_at(syms, j));
+#pragma unroll
+		for (unsigned j = FP_RUN; j-- > 0;) hb = fp_horner(hb, C.B, fp_sym_at(syms, j));
+		Fp tot;
+		const Fp exF = scan64<+1>(hf, C.c2, tot), exB = scan64<-1>(hb, C.c2, tot);
+		Fp hh = fp_add(fp_mul(seedP, pwl), exF);
+#pragma unroll
+		for (unsigned j = 0; j < FP_RUN; j++) { F[j] = fp_sub(hh, fp_mul(F[j], C.Bk)); hh = fp_horner(hh, C.B, fp_sym_at(syms, j)); }      // F(w) = P[g+k] - P[g] B^k
+		hh = fp_add(fp_mul(seedS, pwr), exB);
+#pragma unroll
+		for (unsigned j = FP_RUN; j-- > 0;) { hh = fp_horner(hh, C.B, fp_sym_at(syms, j)); R[j] = fp_sub(C.G3, fp_sub(R[j], fp_mul(hh, C.Bk))); }   // F(rc(w)) = 3 G_k - (S[g] - B^k S[g+k])
+	}
+	// The lane holds FP_RUN CONSECUTIVE windows; stored like that, one store instruction would touch 64 lines (64 B apart per lane).  The
+	// fingerprints are transposed through LDS (rows of FP_RUN + 1 entries: no bank conflicts) so that lane l finishes windows l, l + 64, ...:
+	// every load of the neighbouring characters and every store of the wave is one contiguous run.
+	// (the canonical orientation is decided first: two words per window travel, its two "<=" flags in the free top bits of the 61-bit one)
+	__shared__ u64 s_t[FP_THREADS / 64u][2][64u * (FP_RUN + 1u)];
+	u64 (*tr)[64u * (FP_RUN + 1u)] = s_t[threadIdx.x >> 6];
 #pragma unroll
 	for (unsigned j = 0; j < FP_RUN; j++) {
-		const size_t g = g0 + j;
-		while (c + 1 < nchr && g >= sepidx[c + 1]) c++;
+		Fp hf = F[j], hr = R[j];
+		if (test_weak) { const u64 m = (1ull << test_weak) - 1; hf.a &= m; hf.b &= m; hr.a &= m; hr.b &= m; }
+		const bool f_le = hf.a < hr.a || (hf.a == hr.a && hf.b <= hr.b), r_le = hr.a < hf.a || (hr.a == hf.a && hr.b <= hf.b);
+		const Fp cn = f_le ? hf : hr;
+		const unsigned at = lane * (FP_RUN + 1u) + j;
+		tr[0][at] = cn.a | ((u64)f_le << 62) | ((u64)r_le << 63); tr[1][at] = cn.b;
+	}
+	// (one wave writes and reads its own rows: no barrier needed beyond the wave's own program order)
+	__builtin_amdgcn_wave_barrier();
+	unsigned c = 0;
+	{	// chromosome of the wave's first window: sepidx[c] < g < sepidx[c+1] (a separator itself belongs to nobody)
+		unsigned lo = 0, hi = nchr; const unsigned e = (unsigned)(a0 < nelem ? a0 : nelem - 1);
+		while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (sepidx[mid] < e) lo = mid; else hi = mid; }
+		c = lo;
+	}
+#pragma unroll
+	for (unsigned j = 0; j < FP_RUN; j++) {
+		const unsigned w = j * 64u + lane;                              // window of the tile this lane finishes in step j
+		const size_t g = a0 + w;
+		while (c + 1 < nchr && g >= sepidx[c + 1]) c++;                 // (ascending within a lane: g grows by 64 per step)
 		const bool valid = g < nelem && g > sepidx[c] && g + C.k <= sepidx[c + 1];
-		u64 k1 = kmer_hash((u64)g), k2 = 0, v = FP_INVALID;               // invalid records: spread over the buckets, skipped by value
+		u64 k1 = kmer_hash((u64)g), v = FP_INVALID;                       // invalid records: spread over the buckets, skipped by value
 		if (valid) {
-			Fp hf = fp_sub(P1[j], fp_mul(P0[j], C.Bk));                    // F(w)
-			Fp hr = fp_sub(C.G3, fp_sub(S0[j], fp_mul(S1[j], C.Bk)));      // F(rc(w))
-			if (test_weak) { const u64 m = (1ull << test_weak) - 1; hf.a &= m; hf.b &= m; hr.a &= m; hr.b &= m; }
+			const unsigned at = (w / FP_RUN) * (FP_RUN + 1u) + (w % FP_RUN);
+			const u64 ca = tr[0][at];
+			const bool f_le = (ca >> 62) & 1ull, r_le = (ca >> 63) & 1ull;
+			const Fp cn{ca & FP_M61, tr[1][at]};
 			const uint8_t pc = ch[g - 1], nc = ch[g + C.k];
 			unsigned ps = (pc >> 1) & 3u; ps ^= ps >> 1; if (pc == '$') ps = 4u;
 			unsigned ns = (nc >> 1) & 3u; ns ^= ns >> 1; if (nc == '$') ns = 4u;
-			const bool f_le = hf.a < hr.a || (hf.a == hr.a && hf.b <= hr.b), r_le = hr.a < hf.a || (hr.a == hf.a && hr.b <= hf.b);
-			unsigned m = 0, fl = 0;
-			if (f_le) { m |= (1u << ps) | (1u << (8 + ns)); fl |= 1u; }
-			if (r_le) { m |= (1u << (ns == 4 ? 4 : 3 - ns)) | (1u << (8 + (ps == 4 ? 4 : 3 - ps))); fl |= 2u; }
-			const Fp cn = f_le ? hf : hr;
-			k1 = kmer_hash(cn.a); k2 = cn.b;
-			if (k1 == KB_EMPTY_KEY) k1 ^= 1ull;                           // (the table's empty marker; the second key and the verification keep this exact)
-			v = (u64)(unsigned)g | ((u64)m << 32) | ((u64)fl << 48);
+			unsigned m = 0, fl = 0;                                       // masks in the canonical orientation: prev in bits 0-4, next in bits 5-9 ({A,C,G,T,#})
+			if (f_le) { m |= (1u << ps) | (1u << (5 + ns)); fl |= 1u; }
+			if (r_le) { m |= (1u << (ns == 4 ? 4 : 3 - ns)) | (1u << (5 + (ps == 4 ? 4 : 3 - ps))); fl |= 2u; }
+			k1 = kmer_hash(cn.a | ((cn.b & 7ull) << 61));
+			if (k1 == KB_EMPTY_KEY) k1 ^= 1ull;                           // (the table's empty marker; the verification keeps this exact)
+			v = (u64)(unsigned)g | ((u64)m << FP_V_PREV) | ((u64)fl << FP_V_FL) | (((cn.b >> 3) & 0xFFFFFull) << FP_V_H2);
 		}
-		key1[g] = k1; rec[g] = FpRec{k2, v};
+		key1[g] = k1; rec[g] = v;
 	}
 }
 
-// ------------------------------------------------------------------------------------------- F5: per-bucket tables on 125-bit keys
+// ------------------------------------------------------------------------------------------- F5: per-bucket tables on the 84-bit fingerprints
 #define FPB_SLOTS 1024u
 #define FPB_THREADS 256
 #define FPB_MAX_DISTINCT (FPB_SLOTS * 23u / 32u)
 static_assert(FPB_MAX_DISTINCT + FPB_THREADS < FPB_SLOTS, "k_fp_classify: the LDS table could fill up");
-#define FPB_K2_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define FPB_K2_EMPTY_SUB 0xFFFFFFFFFFFFFFFEull      // a real second key equal to the marker is stored as this (exactness comes from the verification)
+#define FPB_K2_EMPTY 0xFFFFFFFFu
 enum { FPB_CTR_PAIRS = 0, FPB_CTR_MEM = 32, FPB_CTR_FLAG = 64, FPB_CTR_WORDS = 96 };
-#define FPB_PAL 0x2000u                             // tmask bit: some record of the slot had both orientation flags (fingerprint palindrome)
+#define FPB_PAL 0x400u                              // tmask bit: some record of the slot had both orientation flags (fingerprint palindrome)
 // pairs[p] = representative: element | orientation << 32 | palindrome << 33 (orientation 0: the + strand k-mer at the element is the canonical one)
 // members[i] = element | (2 pair + orientation) << 32 | (both flags) << 63
 // A workgroup takes FPB_GROUP consecutive buckets and STAGES what they emit in LDS -- one reservation of output ranges per flush instead
 // of one per wave and step (as k_bucket_classify does; the first version reserved per wave: 1.5 M returning atomics on one address
-// on raw strains at k = 100, where a tenth of the windows are members).
+// on raw strains at k = 100, where a tenth of the windows are members).  The records of the NEXT bucket are requested before this one
+// is worked on (FPB_REGS per thread in registers: buckets of up to 768 records are read once).
 #define FPB_GROUP 16u
+#define FPB_REGS 3
 #define FPB_STAGE_MEM 1536u
 #define FPB_STAGE_PAIRS 384u
-__global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restrict__ skey1, const FpRec *__restrict__ srec, const unsigned *__restrict__ boff, unsigned nbuckets,
+__global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restrict__ skey, const u64 *__restrict__ sval, const unsigned *__restrict__ boff, unsigned nbuckets,
                                                             unsigned *__restrict__ counters, u64 *__restrict__ pairs, unsigned maxpairs, u64 *__restrict__ members, unsigned maxmembers)
 {
-	__shared__ u64 tkey[FPB_SLOTS], tkey2[FPB_SLOTS], trep[FPB_SLOTS];
-	__shared__ unsigned tmask[FPB_SLOTS], taux[FPB_SLOTS];
+	__shared__ u64 tkey[FPB_SLOTS], trep[FPB_SLOTS];
+	__shared__ unsigned tkey2[FPB_SLOTS], tmask[FPB_SLOTS], taux[FPB_SLOTS];
 	__shared__ u64 st_mem[FPB_STAGE_MEM], st_pair[FPB_STAGE_PAIRS];
 	__shared__ unsigned s_used, s_pairs, s_np, s_nm, s_bp, s_bm, s_dp;
 	const unsigned b0 = blockIdx.x * FPB_GROUP, b1 = b0 + FPB_GROUP < nbuckets ? b0 + FPB_GROUP : nbuckets;
@@ -315,87 +368,116 @@ __global__ void __launch_bounds__(FPB_THREADS) k_fp_classify(const u64 *__restri
 		if (threadIdx.x == 0) { s_np = 0; s_nm = 0; }
 		__syncthreads();
 	};
-	// slot of (k1, k2): claimed on k1 by compare-and-swap; its identity is whichever second key arrives first (a second compare-and-swap);
-	// a record with the same first and another second key moves on.  claim = false: look-up only (everything is inserted by then).
-	auto slot_of = [&](u64 k1, u64 k2, bool claim) -> unsigned {
-		if (k2 == FPB_K2_EMPTY) k2 = FPB_K2_EMPTY_SUB;
+	// slot of a record: claimed on the key by compare-and-swap; its identity is whichever 20 further fingerprint bits arrive first (a second
+	// compare-and-swap); a record with the same key and other bits moves on.  claim = false: look-up only (everything is inserted by then).
+	auto slot_of = [&](u64 k1, unsigned k2, bool claim) -> unsigned {
 		unsigned h = (unsigned)(k1 >> 44) & (FPB_SLOTS - 1);
 		for (unsigned step = 0; step < FPB_SLOTS; step++, h = (h + 1) & (FPB_SLOTS - 1)) {
 			u64 old = claim ? atomicCAS(&tkey[h], KB_EMPTY_KEY, k1) : tkey[h];
 			if (claim && old == KB_EMPTY_KEY) { atomicAdd(&s_used, 1u); old = k1; }
 			if (old != k1) { if (!claim && old == KB_EMPTY_KEY) return SBL_NONE; continue; }
-			const u64 o2 = claim ? atomicCAS(&tkey2[h], FPB_K2_EMPTY, k2) : tkey2[h];
+			const unsigned o2 = claim ? atomicCAS(&tkey2[h], FPB_K2_EMPTY, k2) : tkey2[h];
 			if (o2 == k2 || (claim && o2 == FPB_K2_EMPTY)) return h;
 		}
 		if (claim) atomicAdd(&s_used, FPB_SLOTS);
 		return SBL_NONE;
 	};
+	// the first bucket's records: in flight while the table is cleared
+	u64 rk[FPB_REGS], rv[FPB_REGS];
+	unsigned lo = boff[b0], hi = boff[b0 + 1];
+#pragma unroll
+	for (int r = 0; r < FPB_REGS; r++) { const unsigned i = lo + threadIdx.x + r * FPB_THREADS; rv[r] = i < hi ? sval[i] : FP_INVALID; rk[r] = i < hi ? skey[i] : 0ull; }
 	for (unsigned b = b0; b < b1; b++) {
-		const unsigned lo = boff[b], hi = boff[b + 1];
-		if (lo >= hi) continue;
-		__syncthreads();
-		if (s_nm > FPB_STAGE_MEM / 2 || s_np > FPB_STAGE_PAIRS / 2) flush();
-		for (unsigned i = threadIdx.x; i < FPB_SLOTS; i += FPB_THREADS) { tkey[i] = KB_EMPTY_KEY; tkey2[i] = FPB_K2_EMPTY; trep[i] = ~0ull; tmask[i] = 0; taux[i] = SBL_NONE; }
-		if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; }
-		__syncthreads();
-		for (unsigned i = lo + threadIdx.x; i < hi; i += FPB_THREADS) {
-			if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;       // too many distinct k-mers for this table: the host re-buckets
-			const FpRec r = srec[i];
-			if (r.v == FP_INVALID) continue;
-			const unsigned h = slot_of(skey1[i], r.k2, true);
-			if (h == SBL_NONE) break;
-			const unsigned fl = (unsigned)(r.v >> 48) & 3u;
-			atomicOr(&tmask[h], ((unsigned)(r.v >> 32) & 0x1FFFu) | (fl == 3u ? FPB_PAL : 0u));
-			// representative: the lowest element of the group (deterministic), with its orientation
-			atomicMin(&trep[h], ((r.v & 0xFFFFFFFFull) << 1) | ((fl & 1u) ? 0ull : 1ull));
+		u64 nk_[FPB_REGS], nv_[FPB_REGS];
+		unsigned nlo = 0, nhi = 0;
+		if (b + 1 < b1) {
+			nlo = hi; nhi = boff[b + 2];
+#pragma unroll
+			for (int r = 0; r < FPB_REGS; r++) { const unsigned i = nlo + threadIdx.x + r * FPB_THREADS; nv_[r] = i < nhi ? sval[i] : FP_INVALID; nk_[r] = i < nhi ? skey[i] : 0ull; }
 		}
-		__syncthreads();
-		if (s_used > FPB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[FPB_CTR_FLAG], 1u); return; }   // (uniform; the host discards everything)
-		for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
-			if (tkey[sidx] == KB_EMPTY_KEY || !mask_is_bifurcation(tmask[sidx] & 0x1FFFu)) continue;
-			taux[sidx] = atomicAdd(&s_pairs, 1u);
-		}
-		__syncthreads();
-		const unsigned npairs = s_pairs;
-		if (!npairs) continue;
-		// staged when it fits (flushing first if need be); a bucket with more pairs than the stage holds or more records than the member
-		// stage could take (low-complexity input: one k-mer, thousands of occurrences) reserves its ranges itself and writes directly
-		const bool direct = npairs > FPB_STAGE_PAIRS / 2 || hi - lo > FPB_STAGE_MEM / 2;
-		if (direct) {
-			flush();                                                   // pair indices below are final, nothing staged refers to them
-			if (threadIdx.x == 0) s_dp = atomicAdd(&counters[FPB_CTR_PAIRS], npairs);
+		if (lo < hi) {
 			__syncthreads();
+			if (s_nm > FPB_STAGE_MEM / 2 || s_np > FPB_STAGE_PAIRS / 2) flush();
+			for (unsigned i = threadIdx.x; i < FPB_SLOTS; i += FPB_THREADS) { tkey[i] = KB_EMPTY_KEY; tkey2[i] = FPB_K2_EMPTY; tmask[i] = 0; taux[i] = SBL_NONE; }
+			if (threadIdx.x == 0) { s_used = 0; s_pairs = 0; }
+			__syncthreads();
+			auto insert = [&](u64 k1, u64 v) {
+				const unsigned h = slot_of(k1, (unsigned)(v >> FP_V_H2), true);
+				if (h == SBL_NONE) return;
+				const unsigned fl = (unsigned)(v >> FP_V_FL) & 3u;
+				atomicOr(&tmask[h], ((unsigned)(v >> FP_V_PREV) & 0x3FFu) | (fl == 3u ? FPB_PAL : 0u));
+			};
+#pragma unroll
+			for (int r = 0; r < FPB_REGS; r++) {
+				if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;     // too many distinct k-mers for this table: the host re-buckets
+				if (rv[r] != FP_INVALID) insert(rk[r], rv[r]);
+			}
+			for (unsigned i = lo + threadIdx.x + FPB_REGS * FPB_THREADS; i < hi; i += FPB_THREADS) {
+				if (*(volatile unsigned *)&s_used > FPB_MAX_DISTINCT) break;
+				const u64 v = sval[i];
+				if (v != FP_INVALID) insert(skey[i], v);
+			}
+			__syncthreads();
+			if (s_used > FPB_MAX_DISTINCT) { if (threadIdx.x == 0) atomicOr(&counters[FPB_CTR_FLAG], 1u); return; }   // (uniform; the host discards everything)
+			for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+				if (tkey[sidx] == KB_EMPTY_KEY || !fp_mask_bif(tmask[sidx])) continue;
+				taux[sidx] = atomicAdd(&s_pairs, 1u);
+				trep[sidx] = ~0ull;                                     // (representatives are only taken for the bifurcation k-mers, in the member pass)
+			}
+			__syncthreads();
+			const unsigned npairs = s_pairs;
+			if (npairs) {
+				// staged when it fits (flushing first if need be); a bucket with more pairs than the stage holds or more records than the member
+				// stage could take (low-complexity input: one k-mer, thousands of occurrences) reserves its ranges itself and writes directly
+				const bool direct = npairs > FPB_STAGE_PAIRS / 2 || hi - lo > FPB_STAGE_MEM / 2;
+				if (direct) {
+					flush();                                            // pair indices below are final, nothing staged refers to them
+					if (threadIdx.x == 0) s_dp = atomicAdd(&counters[FPB_CTR_PAIRS], npairs);
+					__syncthreads();
+				}
+				const unsigned pbase = direct ? s_dp : s_np;
+				// member positions of the bifurcation k-mers: staged entries carry the STAGED pair index (the flush adds the base); the
+				// representative of a group = its lowest element (deterministic), with its orientation
+				auto emit = [&](u64 k1, u64 v, bool have) {
+					unsigned pi = SBL_NONE;
+					const unsigned fl = (unsigned)(v >> FP_V_FL) & 3u;
+					if (have) {
+						const unsigned h = slot_of(k1, (unsigned)(v >> FP_V_H2), false);
+						if (h != SBL_NONE && taux[h] != SBL_NONE) { pi = pbase + taux[h]; atomicMin(&trep[h], ((v & 0xFFFFFFFFull) << 1) | ((fl & 1u) ? 0ull : 1ull)); }
+					}
+					const bool mem = pi != SBL_NONE;
+					const u64 bal = __ballot(mem);
+					if (!bal) return;
+					const unsigned lane = threadIdx.x & 63u, first = (unsigned)__builtin_ctzll(bal);
+					unsigned base = 0;
+					if (lane == first) base = direct ? atomicAdd(&counters[FPB_CTR_MEM], (unsigned)__popcll(bal)) : atomicAdd(&s_nm, (unsigned)__popcll(bal));
+					base = __shfl(base, first);
+					const unsigned at = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+					const u64 rec = (v & 0xFFFFFFFFull) | ((u64)(2u * pi + ((fl & 1u) ? 0u : 1u)) << 32) | (fl == 3u ? 1ull << 63 : 0ull);
+					if (mem) { if (direct) { if (at < maxmembers) members[at] = rec; } else if (at < FPB_STAGE_MEM) st_mem[at] = rec; }
+				};
+#pragma unroll
+				for (int r = 0; r < FPB_REGS; r++) emit(rk[r], rv[r], rv[r] != FP_INVALID);
+				for (unsigned i0 = lo + FPB_REGS * FPB_THREADS; i0 < hi; i0 += FPB_THREADS) {      // the rest of a bucket larger than the registers hold (always direct)
+					const unsigned i = i0 + threadIdx.x;
+					const u64 v = i < hi ? sval[i] : FP_INVALID;
+					emit(i < hi ? skey[i] : 0ull, v, v != FP_INVALID);
+				}
+				__syncthreads();
+				for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
+					const unsigned a = taux[sidx];
+					if (a == SBL_NONE) continue;
+					const unsigned pi = pbase + a;
+					const u64 rep = (trep[sidx] >> 1) | ((trep[sidx] & 1ull) << 32) | ((tmask[sidx] & FPB_PAL) ? 1ull << 33 : 0ull);
+					if (direct) { if (pi < maxpairs) pairs[pi] = rep; } else st_pair[pi] = rep;
+				}
+				__syncthreads();
+				if (threadIdx.x == 0 && !direct) s_np += npairs;
+			}
 		}
-		const unsigned pbase = direct ? s_dp : s_np;
-		for (unsigned sidx = threadIdx.x; sidx < FPB_SLOTS; sidx += FPB_THREADS) {
-			const unsigned a = taux[sidx];
-			if (a == SBL_NONE) continue;
-			const unsigned pi = pbase + a;
-			const u64 rep = (trep[sidx] >> 1) | ((trep[sidx] & 1ull) << 32) | ((tmask[sidx] & FPB_PAL) ? 1ull << 33 : 0ull);
-			if (direct) { if (pi < maxpairs) pairs[pi] = rep; } else st_pair[pi] = rep;
-			taux[sidx] = pi;                                           // staged pair index, or the final one (direct)
-		}
-		__syncthreads();
-		if (threadIdx.x == 0 && !direct) s_np += npairs;
-		// member positions of the bifurcation k-mers: staged entries carry the STAGED pair index (the flush adds the base)
-		for (unsigned i0 = lo; i0 < hi; i0 += FPB_THREADS) {
-			const unsigned i = i0 + threadIdx.x;
-			FpRec r{0, FP_INVALID};
-			if (i < hi) r = srec[i];
-			unsigned pi = SBL_NONE;
-			if (r.v != FP_INVALID) { const unsigned h = slot_of(skey1[i], r.k2, false); if (h != SBL_NONE) pi = taux[h]; }
-			const bool mem = pi != SBL_NONE;
-			const u64 bal = __ballot(mem);
-			if (!bal) continue;
-			const unsigned lane = threadIdx.x & 63u, first = (unsigned)__builtin_ctzll(bal);
-			unsigned base = 0;
-			if (lane == first) base = direct ? atomicAdd(&counters[FPB_CTR_MEM], (unsigned)__popcll(bal)) : atomicAdd(&s_nm, (unsigned)__popcll(bal));
-			base = __shfl(base, first);
-			const unsigned at = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-			const unsigned fl = (unsigned)(r.v >> 48) & 3u;
-			const u64 rec = (r.v & 0xFFFFFFFFull) | ((u64)(2u * pi + ((fl & 1u) ? 0u : 1u)) << 32) | (fl == 3u ? 1ull << 63 : 0ull);
-			if (mem) { if (direct) { if (at < maxmembers) members[at] = rec; } else if (at < FPB_STAGE_MEM) st_mem[at] = rec; }
-		}
+		lo = nlo; hi = nhi;
+#pragma unroll
+		for (int r = 0; r < FPB_REGS; r++) { rk[r] = nk_[r]; rv[r] = nv_[r]; }
 	}
 	flush();
 }
@@ -529,6 +611,17 @@ __global__ void __launch_bounds__(256) k_fp_marks(const u64 *__restrict__ member
 	bif0[g] = pairids[p];
 	bif1[g + k - 1] = pairids[p ^ 1u];
 }
+// the two marks of a member position as (element, id) for the compact lists (sbl_compact_marks' output), strand by strand
+__global__ void __launch_bounds__(256) k_fp_mark_pairs(const u64 *__restrict__ members, unsigned n, unsigned k, const unsigned *__restrict__ pairids, unsigned strand,
+                                                       unsigned *__restrict__ elem, unsigned *__restrict__ id)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 m = members[i];
+	const unsigned g = (unsigned)m, p = (unsigned)(m >> 32) & 0x7FFFFFFFu;
+	elem[i] = strand ? g + k - 1 : g;
+	id[i] = pairids[strand ? p ^ 1u : p];
+}
 // bucket b = records whose first key's LOW `bits` bits equal b (see k_bucket_bounds)
 __global__ void __launch_bounds__(256) k_fp_bucket_bounds(const u64 *__restrict__ skeys, size_t n, unsigned bits, unsigned *__restrict__ boff)
 {
@@ -607,17 +700,17 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	const unsigned ntchunks = (nx + FP_THREADS - 1) / FP_THREADS;
 	L.tiles.ensure((size_t)nx * 4 * sizeof(Fp)); L.PT.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp)); L.ST.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp));
 	L.ctot.ensure((size_t)ntchunks * 2 * sizeof(Fp)); L.cP.ensure(((size_t)ntchunks + 1) * sizeof(Fp)); L.cS.ensure(((size_t)ntchunks + 1) * sizeof(Fp));
-	L.key1.ensure(n * 8); L.rec.ensure(n * 16); L.skey1.ensure(n * 8); L.srec.ensure(n * 16);
+	L.key1.ensure(n * 8); L.rec.ensure(n * 8); L.skey1.ensure(n * 8); L.srec.ensure(n * 8);
 	L.ctr.ensure(256 * 4);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
-	k_fp_tiles<<<nx, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, nx, C, L.tiles.as<Fp>());
+	k_fp_tiles<<<nblocks(nx, FP_THREADS / 64), FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, nx, C, L.tiles.as<Fp>());
 	k_fp_chunks<<<ntchunks, FP_THREADS, 0, s>>>(L.tiles.as<Fp>(), nx, C, L.PT.as<Fp>(), L.ST.as<Fp>(), L.ctot.as<Fp>());
 	k_fp_carries<<<1, 128, 0, s>>>(L.ctot.as<Fp>(), ntchunks, C, L.cP.as<Fp>(), L.cS.as<Fp>());
 	k_fp_apply<<<ntchunks + 1, FP_THREADS, 0, s>>>(ntchunks, L.cP.as<Fp>(), L.cS.as<Fp>(), L.pwT.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>());
 	unsigned weak = 0;
 	if (const char *e = getenv("SBL_TEST_WEAK_FP")) weak = (unsigned)std::min(60, std::max(0, atoi(e)));      // test hook: collisions on purpose (the verification must notice)
-	k_fp_records<<<ntiles, FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C,
-	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.rec.as<FpRec>());
+	k_fp_records<<<nblocks(ntiles, FP_THREADS / 64), FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C, ntiles,
+	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.rec.as<u64>());
 	HIP_TRY(hipGetLastError());
 
 	unsigned bits = 4;
@@ -631,15 +724,15 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		if (attempt == 0 || (cnt[2] & 1u)) {
 			if (attempt) { SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)"); bits = std::min(bits + 2, 28u); }
 			size_t tmp = 0;
-			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<FpRec>(), L.srec.as<FpRec>(), n, 0, bits, s));
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<u64>(), L.srec.as<u64>(), n, 0, bits, s));
 			L.tmp.ensure(tmp);
-			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<FpRec>(), L.srec.as<FpRec>(), n, 0, bits, s));
+			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<u64>(), L.srec.as<u64>(), n, 0, bits, s));
 			L.boff.ensure((((size_t)1 << bits) + 1) * 4 + 64);
 			k_fp_bucket_bounds<<<nblocks(((size_t)1 << bits) + 1, 256), 256, 0, s>>>(L.skey1.as<u64>(), n, bits, L.boff.as<unsigned>());
 		}
 		L.pairs.ensure(maxpairs * 8 + 16); L.members.ensure(maxmembers * 8 + 16);
 		HIP_TRY(hipMemsetAsync(L.ctr.p, 0, 256 * 4, s));
-		k_fp_classify<<<nblocks((size_t)1 << bits, FPB_GROUP), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<FpRec>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
+		k_fp_classify<<<nblocks((size_t)1 << bits, FPB_GROUP), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<u64>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
 		                                                                   L.pairs.as<u64>(), (unsigned)maxpairs, L.members.as<u64>(), (unsigned)maxmembers);
 		HIP_TRY(hipGetLastError());
 		unsigned all[FPB_CTR_WORDS];
@@ -710,6 +803,23 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
 	}
 	if (nmem) k_fp_marks<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, L.pairids.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
+	// The ordered (element, id) lists of the marks (what sbl_compact_marks makes by scanning every element of both mark arrays twice):
+	// with few members -- a cascade state has hundreds, 900 Mbp of random sequence 40 -- sorting them is next to nothing (6.5 ms of
+	// scans at 900 Mbp).  A window is a member once, so no element appears twice in a strand's list.  (SBL_FP_DENSE_MARKS=1: test switch.)
+	if ((size_t)nmem * 16 <= E && getenv("SBL_FP_DENSE_MARKS") == nullptr) {
+		for (int st = 0; st < 2; st++) {
+			c->d_melem[st].ensure((size_t)nmem * 4 + 16); c->d_mid[st].ensure((size_t)nmem * 4 + 16);
+			c->nmarks[st] = nmem;
+			if (!nmem) continue;
+			L.keys.ensure((size_t)nmem * 4 + 16); L.skeys.ensure((size_t)nmem * 4 + 16);
+			k_fp_mark_pairs<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, L.pairids.as<unsigned>(), (unsigned)st, L.keys.as<unsigned>(), L.skeys.as<unsigned>());
+			size_t tmp = 0;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.keys.as<unsigned>(), c->d_melem[st].as<unsigned>(), L.skeys.as<unsigned>(), c->d_mid[st].as<unsigned>(), nmem, 0, 32, s));
+			L.tmp.ensure(tmp);
+			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, L.keys.as<unsigned>(), c->d_melem[st].as<unsigned>(), L.skeys.as<unsigned>(), c->d_mid[st].as<unsigned>(), nmem, 0, 32, s));
+		}
+		c->marks_compact_ready = true;
+	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	float ms = 0;

@@ -212,6 +212,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	SBL_CHECK(k >= 2, SBL_ERR_BAD_ARG, "vertex size k must be at least 2");
 	c->dict_keys = nullptr;
+	c->marks_compact_ready = false;
 	if (k > 32) {
 		// long k: window fingerprints through the bucketed table, every bifurcation group verified on the sequence (longk_fp.hip, round 6);
 		// exact rank doubling (longk.hip) if a verification ever fails, on request (SBL_LONGK_DOUBLING=1: the A/B), and -- split over the
@@ -317,6 +318,7 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 // ordered compaction of one strand's marks into (element, id) arrays
 void sbl_compact_marks(sbl_ctx *c, int strand)
 {
+	if (c->marks_compact_ready) return;                          // (the enumeration sorted its few member positions instead of scanning every element)
 	hipStream_t s = c->stream;
 	size_t E = c->nelem;
 	unsigned nchunks = nblocks(E, 1024);

@@ -67,6 +67,7 @@ struct sbl_ctx {
 	DevBuf d_chunkcnt, d_chunkoff, d_scantmp;
 	DevBuf d_melem[2], d_mid[2];         // compacted marks per strand (element, id), ascending element
 	uint32_t nmarks[2] = {0, 0};
+	bool marks_compact_ready = false;    // the enumeration that just ran left d_melem / d_mid / nmarks itself (longk_fp.hip: few members): sbl_compact_marks has nothing to do
 	uint32_t bif_count = 0;
 	uint32_t cur_k = 0;
 	const unsigned long long *dict_keys = nullptr;   // k <= 32: the sorted strand-specific bifurcation codes of the last enumeration (id = rank); nullptr for long k

@@ -91,9 +91,14 @@ def test_colliding_fingerprints_are_caught_by_the_verification(weak, monkeypatch
         _same(got, want, "weak fingerprints, k = %d" % k)
 
 
-def test_many_short_records_and_a_cascade(monkeypatch):
-    """180-record style input (records from 100 bp) through a long-k cascade: state after every stage against the oracle"""
+@pytest.mark.parametrize("dense_marks", [False, True])
+def test_many_short_records_and_a_cascade(monkeypatch, dense_marks):
+    """180-record style input (records from 100 bp) through a long-k cascade: state after every stage against the oracle.  The ordered mark
+    lists of a stage come from sorting the few member positions (the default where there are few) or from the scan of the dense mark
+    arrays (SBL_FP_DENSE_MARKS=1): the same lists either way."""
     from oracle.oracle import Oracle
+    if dense_marks:
+        monkeypatch.setenv("SBL_FP_DENSE_MARKS", "1")
     from sibelia_amd import workloads as W
     base = W.gen_strains(L0=60_000, n=4, seed=19, snp=0.02, inv_min=500, inv_max=3000)
     rng = np.random.default_rng(4)

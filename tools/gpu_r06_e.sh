@@ -14,3 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3stats -- python $R/bench.py --config 3 --no-cpu-baseline > $out/c3stats.log 2>&1
 find $out -name '*_kernel_trace.csv' -size +20M -delete
 f=$(find $out/c3stats -name '*kernel_stats.csv' | head -1); head -25 "$f" | cut -c1-200
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5stats -- python $R/bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline > $out/c5stats.log 2>&1
+find $out -name '*_kernel_trace.csv' -size +20M -delete
+f=$(find $out/c5stats -name '*kernel_stats.csv' | head -1); head -22 "$f" | cut -c1-160
