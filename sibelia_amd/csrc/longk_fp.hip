@@ -662,7 +662,9 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 {
 	hipStream_t s = c->stream;
 	const size_t E = c->nelem, nwords = (E + 31) / 32;
-	SBL_CHECK(E < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many positions for 32-bit record indices");
+	// (the reference's limit, kept as the drop-in's error behaviour: its suffix array of the superGenome "#c0#..#rc(c0)#..#" is int32,
+	// vertexenumeration.cpp:288-300 -- this path itself would go to 2^32 elements)
+	SBL_CHECK(2 * E - 1 + k < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "input too large for 32-bit suffix ranks");
 	c->cur_k = k;
 	c->stats.exchange_bytes = 0; c->stats.exchange_ms = 0;
 	sbl_pack(c);
@@ -700,6 +702,20 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	const unsigned ntchunks = (nx + FP_THREADS - 1) / FP_THREADS;
 	L.tiles.ensure((size_t)nx * 4 * sizeof(Fp)); L.PT.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp)); L.ST.ensure(((size_t)ntchunks * FP_THREADS + 1) * sizeof(Fp));
 	L.ctot.ensure((size_t)ntchunks * 2 * sizeof(Fp)); L.cP.ensure(((size_t)ntchunks + 1) * sizeof(Fp)); L.cS.ensure(((size_t)ntchunks + 1) * sizeof(Fp));
+	{	// pre-flight (as lk_preflight of the rank doubling): 32 B per element of records + ~8 B of outputs, against what the device has free,
+		// BEFORE the first large allocation -- a clear SBL_ERR_OOM instead of a failure half way through (SBL_TEST_FREE_MEM_MB: test switch)
+		auto miss = [](const DevBuf &b, size_t want) { return want > b.cap ? want + want / 16 + 256 : (size_t)0; };
+		const size_t need = miss(L.key1, n * 8) + miss(L.rec, n * 8) + miss(L.skey1, n * 8) + miss(L.srec, n * 8) + miss(L.members, n * 8 + 16) + miss(L.pairs, (n / 8 + 4096) * 8 + 16) + miss(L.tmp, n / 64 + (1u << 20));
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+			if (const char *e = getenv("SBL_TEST_FREE_MEM_MB")) fr = (size_t)atoll(e) << 20;
+			if (need > fr) {
+				char b[200];
+				snprintf(b, sizeof b, "long-k enumeration of %zu windows needs %zu MB of workspace, %zu MB free on the device", n, need >> 20, fr >> 20);
+				throw SblError{SBL_ERR_OOM, b};
+			}
+		} else (void)hipGetLastError();
+	}
 	L.key1.ensure(n * 8); L.rec.ensure(n * 8); L.skey1.ensure(n * 8); L.srec.ensure(n * 8);
 	L.ctr.ensure(256 * 4);
 	HIP_TRY(hipEventRecord(c->ev[0], s));

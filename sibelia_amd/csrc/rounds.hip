@@ -541,19 +541,31 @@ __global__ void __launch_bounds__(256) k_unpack_need(const unsigned *__restrict_
 	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j < n && (j < mylo || j >= myhi)) need[perm[j]] = buf[j];
 }
-// Probe: what k_probe did to need / touch for the entries the OTHER GPUs probed (live[] all-gathered, 1 B per window entry), and the
-// lowest order violation any of them saw (trail: one word per rank)
-__global__ void __launch_bounds__(256) k_apply_probe(GraphView g, unsigned nwin, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, const unsigned *__restrict__ trail, unsigned nranks)
+// Probe: ONE collective per round (round 6; two before: the verdict bytes, then the violation words).  Every rank packs a record of
+// `stride` bytes -- the lowest order violation it has seen (4 B) + the verdict bytes of its share of the window -- into slot `rank` of
+// robuf (k_pack_probe); the slots are all-gathered; k_apply_probe then does for the entries the OTHER GPUs probed what k_probe did to
+// need / touch / live for its own, and takes the lowest violation anybody saw.  Share of rank p: [nwin p / R, nwin (p + 1) / R).
+__global__ void __launch_bounds__(256) k_pack_probe(const unsigned *__restrict__ ctr, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, unsigned rank, unsigned stride, uint8_t *__restrict__ robuf)
+{
+	uint8_t *slot = robuf + (size_t)rank * stride;
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) *reinterpret_cast<unsigned *>(slot) = ctr[CTR_VIOL];
+	if (w0 + i < w1) slot[4 + i] = live[w0 + i];
+}
+__global__ void __launch_bounds__(256) k_apply_probe(GraphView g, unsigned nwin, uint8_t *__restrict__ live, unsigned w0, unsigned w1, const uint8_t *__restrict__ robuf, unsigned stride, unsigned nranks)
 {
 	const unsigned wi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (wi == 0) { unsigned v = BT_NONE; for (unsigned p = 0; p < nranks; p++) v = trail[p] < v ? trail[p] : v; if (v != BT_NONE) atomicMin(&g.ctr[CTR_VIOL], v); }
+	if (wi == 0) { unsigned v = BT_NONE; for (unsigned p = 0; p < nranks; p++) { const unsigned t = *reinterpret_cast<const unsigned *>(robuf + (size_t)p * stride); v = t < v ? t : v; } if (v != BT_NONE) atomicMin(&g.ctr[CTR_VIOL], v); }
 	if (wi >= nwin || (wi >= w0 && wi < w1)) return;
+	unsigned p = (unsigned)(((unsigned long long)wi * nranks) / nwin);       // owner of the entry: the estimate is at most one off
+	while ((unsigned)(((unsigned long long)nwin * p) / nranks) > wi) p--;
+	while ((unsigned)(((unsigned long long)nwin * (p + 1)) / nranks) <= wi) p++;
+	const uint8_t l = robuf[(size_t)p * stride + 4 + (wi - (unsigned)(((unsigned long long)nwin * p) / nranks))];
+	live[wi] = l;
 	const unsigned id = g.win[wi];
-	const uint8_t l = live[wi];
 	if (l == 0) { g.need[id] = 0; g.touch[id] = 0; }
 	else if (l == 1 && g.need[id] != 2) g.need[id] = 2;
 }
-__global__ void k_probe_trail(const unsigned *__restrict__ ctr, unsigned *__restrict__ trail, unsigned rank) { trail[rank] = ctr[CTR_VIOL]; }
 
 // The lowest pending ids in [lo, limit], ascending; a pending "big" id ends the window (and runs alone if it is the lowest).
 // out: win[], ctr[CTR_NWIN], ctr[CTR_LO] (lowest pending id), ctr[CTR_PUSHED] (solo flag).

@@ -266,6 +266,8 @@ struct DeviceBackend {
 		catch (...) { cm->abort_peers(); throw; }
 		ro_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	}
+	// slot r (es bytes) of every rank r to everybody, in place
+	void allgather_slots(char *buf, uint32_t R, size_t es) { allgather_shares(buf, R, es); }
 	uint32_t snap_slice = 0;                                          // entries per launch of the walking probe's arena (= the round buffers' window_max)
 	void snapshot_idx()
 	{
@@ -432,18 +434,19 @@ struct DeviceBackend {
 		solo_round = false;
 		if (g.tslot < TS_CAP * 4) ts_kind.back() |= 1;
 		if (split_ro()) {
-			// my share of the window; live[] of the other shares and the lowest order violation anybody saw come back in two small all-gathers
+			// my share of the window; live[] of the other shares and the lowest order violation anybody saw come back in ONE small all-gather
+			// (k_pack_probe / k_apply_probe: a record of 4 + ceil(nwin / R) bytes per rank)
 			uint32_t w0 = 0, w1 = nwin;
 			share(nwin, &w0, &w1);
 			const uint32_t R = c->comm->n;
-			st->robuf.ensure((size_t)R * 4 + 64);
+			const uint32_t stride = (4u + (nwin + R - 1) / R + 1u + 3u) & ~3u;
+			st->robuf.ensure((size_t)R * stride + 64);
 			if (w1 > w0 && g.idx_probe) k_probe_idx<<<w1 - w0, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, pidx_vbits, pidx_inst, pidx_marks, nullptr, 0u, 0);      // (shares of a split probe: the other ranks' lists would have to travel too)
 			if (w1 > w0) k_probe<<<w1 - w0, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), w0, 0);
-			k_probe_trail<<<1, 1, 0, c->stream>>>(st->ctr.as<unsigned>(), st->robuf.as<unsigned>(), c->comm->rank);
+			k_pack_probe<<<std::max<uint32_t>(1u, (w1 - w0 + 255) / 256), 256, 0, c->stream>>>(st->ctr.as<unsigned>(), st->live.as<uint8_t>(), w0, w1, c->comm->rank, stride, st->robuf.as<uint8_t>());
 			HIP_TRY(hipGetLastError());
-			allgather_shares(st->live.as<char>(), nwin, 1);
-			allgather_shares(st->robuf.as<char>(), R, 4);
-			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<unsigned>(), R);
+			allgather_slots(st->robuf.as<char>(), R, stride);
+			k_apply_probe<<<(nwin + 255) / 256, 256, 0, c->stream>>>(g, nwin, st->live.as<uint8_t>(), w0, w1, st->robuf.as<uint8_t>(), stride, R);
 		} else {
 			if (g.idx_probe) k_probe_idx<<<nwin, 64, pidx_lds(), c->stream>>>(g, nwin, st->live.as<uint8_t>(), 0u, pidx_vbits, pidx_inst, pidx_marks, st->instbuf.as<unsigned>(), istride(), 0);      // the block index first; k_probe walks what it could not serve
 			k_probe<<<nwin, 64 * PROBE_WAVES, 0, c->stream>>>(g, nwin, st->arena.as<uint8_t>(), arena_bytes, st->live.as<uint8_t>(), 0u, 0);

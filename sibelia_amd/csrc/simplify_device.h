@@ -79,7 +79,8 @@ __device__ __forceinline__ void round_stamp(const GraphView &g, unsigned which)
 // ---- wave-cooperative window scan ---------------------------------------------------------------------------
 // Fills instance i's window cache (bulge_txn.h: BulgeWork) with 64 lanes: the same values bt_scan_instance
 // writes, but 64 consecutive slots are tested per step and only real link breaks re-anchor the walk.
-__device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r, unsigned wm /* wmax[r], loaded with the data */)
+__device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, unsigned tid, unsigned mode, unsigned id, unsigned r, unsigned wm /* wmax[r], loaded with the data */,
+                                           bool rstamp = true /* this lane publishes the read stamp of its 64-slot block (one lane per block does) */)
 {
 	// Exclusivity inside a round needs no per-element lock here: an owner holds every id marked in the range it reserved
 	// (2(D+k+2)+k elements ahead of each instance), its scans reach D+k+2 elements, and k_commit checks after every
@@ -87,7 +88,7 @@ __device__ __forceinline__ void wave_stamp(const GraphView &g, unsigned stampv, 
 	bool bad = false;
 	unsigned other = BT_NONE;
 	(void)stampv;
-	if (mode == 2) atomicMax(&g.rmax[r], tid);
+	if (mode == 2 && rstamp) atomicMax(&g.rmax[r >> BT_RSHIFT], tid);      // (r: an element's block)
 	if (wm > tid) bad = true;
 	if (bad) {
 		atomicMin(&g.ctr[CTR_VIOL], other < id ? other : id);
@@ -251,7 +252,8 @@ __device__ __forceinline__ void scan_consume(const GraphView &g, const BulgeWork
 		}
 		if (mode) {
 			unsigned blk = c >> BT_BLOCK_SHIFT, pb = __shfl_up(blk, 1);
-			if (st && bst.chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk, bst.wmv[u]);
+			// (the write stamp of every element is checked; the READ stamp is published once per 64-slot block: by the first lane and wherever the block changes)
+			if (st && bst.chv[u] != BT_SEP && (lane == 0 || pb != blk)) wave_stamp(g, stampv, tid, mode, id, blk, bst.wmv[u], lane == 0 || (pb >> BT_RSHIFT) != (blk >> BT_RSHIFT));
 		}
 		if (stop < pre) { s.wl = done + stop; s.finished = true; break; }
 		s.cur = __shfl(bst.lnk[u], pre - 1);

@@ -47,12 +47,12 @@ __global__ void __launch_bounds__(64) k_probe_idx(GraphView g, unsigned nwin, ui
 __global__ void __launch_bounds__(64 * PROBE_WAVES) k_probe(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, uint8_t *live, unsigned w0, int snapshot);
 __global__ void __launch_bounds__(256) k_pack_need(const unsigned *__restrict__ perm, const uint8_t *__restrict__ need, unsigned lo, unsigned hi, uint8_t *__restrict__ buf);
 __global__ void __launch_bounds__(256) k_unpack_need(const unsigned *__restrict__ perm, const uint8_t *__restrict__ buf, unsigned n, unsigned mylo, unsigned myhi, uint8_t *__restrict__ need);
-__global__ void __launch_bounds__(256) k_apply_probe(GraphView g, unsigned nwin, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, const unsigned *__restrict__ trail, unsigned nranks);
+__global__ void __launch_bounds__(256) k_apply_probe(GraphView g, unsigned nwin, uint8_t *__restrict__ live, unsigned w0, unsigned w1, const uint8_t *__restrict__ robuf, unsigned stride, unsigned nranks);
 __global__ void __launch_bounds__(SEL_THREADS) k_select_count(GraphView g, unsigned *__restrict__ sel, unsigned lo, unsigned limit, unsigned chunk0, unsigned chunk,
                                                               const uint8_t *__restrict__ live, unsigned probed);
 __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsigned *__restrict__ sel, unsigned *__restrict__ win, unsigned lo, unsigned limit, unsigned W,
                                                               unsigned chunk0, unsigned chunk, unsigned nchunks, volatile unsigned *post, unsigned post_seq);
-__global__ void k_probe_trail(const unsigned *__restrict__ ctr, unsigned *__restrict__ trail, unsigned rank);
+__global__ void __launch_bounds__(256) k_pack_probe(const unsigned *__restrict__ ctr, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, unsigned rank, unsigned stride, uint8_t *__restrict__ robuf);
 __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap,
                                                                  const unsigned *__restrict__ instbuf, unsigned istride);
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof);

@@ -284,7 +284,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 						if (off < nstamp) {
 							unsigned a = atomicMax(&g.wmax[c], tid);
 							if (off == 0 || (c & 63u) == (d ? 63u : 0u)) bt_idx_wstamp(g, c, tid);      // (consecutive slots: one lane per 64-slot block)
-							unsigned rm = g.rmax[c];
+							unsigned rm = g.rmax[bt_ridx_elem(c)];
 							if (a > tid || rm > tid) {
 								atomicMin(&g.ctr[CTR_VIOL], id);
 								if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 4u) == 0u) { g.ctr[CTR_DETAIL + 1] = c; g.ctr[CTR_DETAIL + 2] = (a > rm ? a : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
@@ -321,7 +321,7 @@ __device__ __forceinline__ void wave_publish_collapse(const GraphView &g, unsign
 			if (done + lane < nstamp) {
 				unsigned a = atomicMax(&g.wmax[c], tid);
 				bt_idx_wstamp(g, c, tid);
-				unsigned rm = g.rmax[c];
+				unsigned rm = g.rmax[bt_ridx_elem(c)];
 				if (a > tid || rm > tid) {
 					atomicMin(&g.ctr[CTR_VIOL], id);
 					if (atomicCAS(&g.ctr[CTR_DETAIL], 0u, 4u) == 0u) { g.ctr[CTR_DETAIL + 1] = c; g.ctr[CTR_DETAIL + 2] = (a > rm ? a : rm) - 1; g.ctr[CTR_DETAIL + 3] = id; g.ctr[CTR_DETAIL + 4] = (a > tid ? 1u : 0u) | (rm > tid ? 2u : 0u); }
