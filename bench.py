@@ -34,14 +34,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+# the translation unit of the round kernels' dominant one (k_commit, k_resume, k_chain) and every header it includes: what a PMC summary of
+# those kernels depends on.  (Rounds 1 - 5 hashed every file under csrc/: a host-only change -- a default in simplify.hip -- made the
+# committed summary "formally not of the timed build")
+DIGEST_FILES = ["commit.hip", "simplify_walks.h", "simplify_device.h", "simplify_steps.h", "simplify_kernels.h", "bulge_txn.h", "kmer_kernels.h", "sbl_ctx.h", "sbl_common.h"]
+
+
 def W_source_digest():
-    """sha256 (first 16 hex) over the kernel sources of the library: ties a PMC summary under profiles/ to the build it was taken on"""
+    """sha256 (first 16 hex) over the sources k_commit is compiled from: ties a PMC summary under profiles/ to the build it was taken on"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sibelia_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in DIGEST_FILES:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -157,7 +162,7 @@ def run_config(a):
             dom = max(cand, key=lambda q: cand[q])
             dom_ms, dom_launches = cand[dom], (max(1, int(st["rounds"])) if dom in ("k_commit", "k_reserve", "k_probe") else 1)
         stage_lines.append({"k": k, "D": D, "ms": ms, "strand_kmers": N, "value": N / (ms * 1e-3), "bif_ids": st["bif_count"], "instances": st["instances"], "bulges": st["bulges"],
-                            "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"], "phase_ms": ph,
+                            "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"], "device_bytes": int(st.get("device_bytes", 0)), "phase_ms": ph,
                             "roofline": {"bound": "hbm", "kernel": dom, "algorithmic_bytes_stage": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "dominant_ms": dom_ms, "dominant_launches": dom_launches,
                                          "dominant_avg_launch_ms": dom_ms / dom_launches,
@@ -205,6 +210,20 @@ def run_config(a):
                                          % (v["name"], o["reference_seconds"], int(Nref),
                                             "; the reference is superlinear in the number of strains -- 62 x 460 kbp is 1/10 of this workload's genome length and took 3.2 h, the full size > 30 h" if a.config == 4 else
                                             " = this very workload at full size")}
+        if a.config == 4 and not a.no_cpu_baseline and os.path.exists(ref_dump):
+            # ... and the reference timed HERE, in the same run, on a bounded sample of the same shape (62 strains x 46 kbp: ~2 min of its one thread)
+            sample = W.gen_strains(L0=46_000, n=62, seed=1)
+            with tempfile.TemporaryDirectory() as d:
+                fa = os.path.join(d, "in.fa")
+                W.write_fasta(fa, sample)
+                t1 = time.time()
+                r = subprocess.run([ref_dump, fa, os.path.join(d, "o")] + ["stage:%d:%d:%d" % (k, D, iters) for k, D in stages], capture_output=True, text=True, timeout=1200)
+                secs = [float(x) for x in re.findall(r"seconds=([0-9.]+)", r.stderr)]
+                if r.returncode == 0 and len(secs) == len(stages):
+                    Ns = sum(W.strand_kmers(sample, k) for k, _ in stages)
+                    out["cpu_baseline_live_sample"] = {"value": Ns / sum(secs), "unit": "strand-k-mers/s", "cores": 1, "kind": "reference", "host": host,
+                                                       "sample": "the unmodified reference (oracle/_ref, 1 thread) on 62 strains x 0.046 Mbp from the same generator, timed on this host in this run: "
+                                                                 "%d strand-k-mers in %.1f s (wall %.1f s)" % (Ns, sum(secs), time.time() - t1)}
     print(json.dumps(out), flush=True)
     bf.close()
 
@@ -442,7 +461,7 @@ def main():
                 doc = json.load(open(pmc))
                 traffic = doc["kernels"][dom]["hbm_bytes_per_launch_est"]
                 here = W_source_digest()
-                traffic_source = ("committed PMC passes: profiles/pmc_latest.json (round %s, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, kernel sources %s; "
+                traffic_source = ("committed PMC passes: profiles/pmc_latest.json (round %s, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, digest of commit.hip + the headers it includes %s; "
                                   "this build: %s = %s)" % (doc.get("round"), doc.get("source_digest", "unrecorded"), here,
                                                             "the same sources" if doc.get("source_digest") == here else "DIFFERENT sources: indicative only"))
             except Exception:
@@ -460,7 +479,8 @@ def main():
                        if a.shard_enum else ("replicas (x%d), one job per GPU" % world if world > 1 else "1 GPU"),
                        "exchange_ms": st["exchange_ms"], "exchange_bytes_rank0": st["exchange_bytes"],
                        "bulges": bulges, "bif_ids": st["bif_count"], "instances": st["instances"],
-                       "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"]},
+                       "iterations": st["iterations"], "rounds": st["rounds"], "replays": st["replays"],
+                       "device_bytes": int(st.get("device_bytes", 0)), "device_bytes_per_base": float(st.get("device_bytes", 0)) / max(1, a.strains * a.L0)},
             "phase_ms": {kk: agg[kk] / a.steps for kk in sorted(agg)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

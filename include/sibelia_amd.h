@@ -91,6 +91,8 @@ typedef struct {
 	 * and the occurrences of bifurcation k-mers that were compared with their group's representative on the sequence (k/4 B each) */
 	uint64_t longk_path;
 	uint64_t fp_verified;
+	/* device memory held by the library's buffers of this PROCESS when the stage ended (grow-only workspaces: the peak so far) */
+	uint64_t device_bytes;
 } sbl_stage_stats;
 
 /* Replaces: BlockFinder::BlockFinder(chrList[, tempDir]) + Init (src/blockfinder.cpp:53-76).

@@ -39,7 +39,7 @@ class StageStats(C.Structure):
                 ("commit_event_ms", C.c_double), ("commit_event_launches", C.c_uint64),
                 ("dict_checked", C.c_uint64), ("dict_mismatches", C.c_uint64),
                 ("ro_ranks", C.c_uint64), ("verdict_ms", C.c_double), ("verdict_bytes", C.c_uint64),
-                ("longk_path", C.c_uint64), ("fp_verified", C.c_uint64)]
+                ("longk_path", C.c_uint64), ("fp_verified", C.c_uint64), ("device_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -992,6 +992,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	c->stats.commit_event_ms = be.commit_event_ms; c->stats.commit_event_launches = be.commit_event_launches;
 	c->stats.verdict_ms = be.ro_ms; c->stats.ro_ranks = be.split_ro() ? c->comm->n : 1;
 	c->stats.executed = rep.executed; c->stats.transactions = rep.transactions; c->stats.chain_transactions = rep.chain_transactions;
+	c->stats.device_bytes = sbl_devbuf_total().load();
 	if (be.prof) sbl_commit_prof_report(be.ts_round);
 	*bulges = rep.bulges;
 	return RUN_DONE;
