@@ -29,7 +29,9 @@
 #include <rocprim/rocprim.hpp>
 
 #include "sbl_ctx.h"
+#include "sbl_comm.h"
 #include "kmer_bucket_kernels.h"
+#include <chrono>
 
 typedef unsigned long long u64;
 static inline unsigned nblocks(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
@@ -232,14 +234,14 @@ __device__ __forceinline__ bool fp_mask_bif(unsigned m10) { const unsigned p = m
 // F3: one WAVE per tile of window starts, FP_RUN consecutive windows per lane.  The prefix / suffix hashes of the tile's own range and of
 // the range k further on come from two wave scans each (seeds from F2); only the two fingerprints per window are kept in registers.
 __global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict__ pk, size_t nwords, const uint8_t *__restrict__ ch, size_t nelem,
-                                                           const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C, unsigned ntiles,
+                                                           const unsigned *__restrict__ sepidx, unsigned nchr, FpConst C, unsigned tile0, unsigned ntiles /* this GPU's slice of tiles: [tile0, ntiles) */,
                                                            const Fp *__restrict__ tiles, const Fp *__restrict__ PT, const Fp *__restrict__ ST, const Fp *__restrict__ pwrun /* (B^RUN)^i, i = 0 .. 64 */,
                                                            unsigned test_weak /* SBL_TEST_WEAK_FP: fingerprints reduced to this many bits (0 = off) */,
                                                            u64 *__restrict__ key1, u64 *__restrict__ rec)
 {
-	const unsigned t = blockIdx.x * (FP_THREADS / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	const unsigned t = tile0 + blockIdx.x * (FP_THREADS / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if (t >= ntiles) return;
-	const size_t a0 = (size_t)t * FP_TILE, a1 = a0 + C.k;
+	const size_t a0 = (size_t)t * FP_TILE, a1 = a0 + C.k, out0 = (size_t)tile0 * FP_TILE;      // records are stored relative to the slice
 	const size_t t1 = (size_t)t + C.q;
 	const Fp pwl = pwrun[lane], pwr = pwrun[63u - lane];                // B^(RUN lane), B^(T - RUN (lane + 1))
 	Fp F[FP_RUN], R[FP_RUN];                                           // first the prefix / suffix hashes at g, then F(w) / F(rc(w))
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_fp_records(const u64 *__restrict
 			if (k1 == KB_EMPTY_KEY) k1 ^= 1ull;                           // (the table's empty marker; the verification keeps this exact)
 			v = (u64)(unsigned)g | ((u64)m << FP_V_PREV) | ((u64)fl << FP_V_FL) | (((cn.b >> 3) & 0xFFFFFull) << FP_V_H2);
 		}
-		key1[g] = k1; rec[g] = v;
+		key1[g - out0] = k1; rec[g - out0] = v;
 	}
 }
 
@@ -634,7 +636,7 @@ __global__ void __launch_bounds__(256) k_fp_bucket_bounds(const u64 *__restrict_
 }
 // ------------------------------------------------------------------------------------------- host
 struct LongKFpScratch {
-	DevBuf tiles, PT, ST, pwrun, pwT, ctot, cP, cS, key1, rec, skey1, srec, tmp, boff, ctr, pairs, members, ref, payload, rank, keys, skeys, idx, sidx, head, gstart, pairids;
+	DevBuf tiles, PT, ST, pwrun, pwT, ctot, cP, cS, key1, rec, skey1, srec, rkey, rval, gpairs, gel, gid, tmp, boff, ctr, pairs, members, ref, payload, rank, keys, skeys, idx, sidx, head, gstart, pairids;
 };
 struct LongKFpHolder { LongKFpScratch s; };
 static LongKFpScratch &fp_of(sbl_ctx *c)
@@ -646,7 +648,7 @@ void sbl_longk_fp_free(sbl_ctx *c)
 {
 	if (!c->lkfp) return;
 	LongKFpScratch &L = c->lkfp->s;
-	for (DevBuf *b : { &L.tiles, &L.PT, &L.ST, &L.pwrun, &L.pwT, &L.ctot, &L.cP, &L.cS, &L.key1, &L.rec, &L.skey1, &L.srec, &L.tmp, &L.boff, &L.ctr, &L.pairs, &L.members, &L.ref, &L.payload, &L.rank,
+	for (DevBuf *b : { &L.tiles, &L.PT, &L.ST, &L.pwrun, &L.pwT, &L.ctot, &L.cP, &L.cS, &L.key1, &L.rec, &L.skey1, &L.srec, &L.rkey, &L.rval, &L.gpairs, &L.gel, &L.gid, &L.tmp, &L.boff, &L.ctr, &L.pairs, &L.members, &L.ref, &L.payload, &L.rank,
 	                   &L.keys, &L.skeys, &L.idx, &L.sidx, &L.head, &L.gstart, &L.pairids })
 		b->release();
 	delete c->lkfp;
@@ -690,6 +692,32 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	{ Fp x = BT; for (int i = 0; i < 6; i++) { C.t2[i] = x; x = fp_mul(x, x); } C.t64 = x; C.tT = fp_pow(BT, FP_THREADS); }
 	const unsigned ntiles = (unsigned)((E + FP_TILE - 1) / FP_TILE), nx = ntiles + C.q + 3;
 	const size_t n = (size_t)ntiles * FP_TILE;                                  // records (one per element slot of the tiles)
+	// Several GPUs on one job (a communicator with more than one rank): the table is sharded by HASH PREFIX exactly as at k <= 32
+	// (shard.hip) -- the records are the same 16 B.  Every rank hashes the tiles of the whole sequence (0.25 B per element), makes
+	// the records of ITS slice of tiles, partitions them, ONE all-to-all takes every bucket to its owner (bucket b belongs to rank
+	// (b R) >> bits), owners classify and VERIFY their buckets, the representatives of the bifurcation k-mers (8 B each) are
+	// all-gathered and ranked identically everywhere, the owners' member marks are all-gathered and scattered.  Balanced by
+	// construction -- the sharded rank doubling cut the VALUE range of the first symbols (rank 0 nearly idle).
+	SblComm *cm = c->comm;
+	const bool sh = cm && cm->n > 1;
+	const uint32_t R = sh ? cm->n : 1u, r = sh ? cm->rank : 0u;
+	double xms = 0;
+	auto timed = [&](auto f) { const auto t0 = std::chrono::steady_clock::now(); f(); xms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+	// every rank contributes sbytes bytes; recv holds all of them in rank order; returns the total and where mine starts
+	auto allgatherv = [&](const char *send, size_t sbytes, DevBuf &recv, size_t *mine_at) -> size_t {
+		std::vector<unsigned long long> mine(1, sbytes), all(R);
+		timed([&] { cm->allgather_host(c, mine.data(), 8, all.data()); });
+		std::vector<size_t> rb(R), ro(R), sb(R, sbytes), so(R, 0);
+		size_t tot = 0;
+		for (uint32_t p = 0; p < R; p++) { rb[p] = all[p]; ro[p] = tot; tot += all[p]; }
+		recv.ensure(tot + 16);
+		timed([&] { cm->alltoallv(c, send, sb.data(), so.data(), recv.as<char>(), rb.data(), ro.data()); });
+		c->stats.exchange_bytes += sbytes * (R - 1);
+		if (mine_at) *mine_at = ro[r];
+		return tot;
+	};
+	const unsigned t0 = (unsigned)((uint64_t)ntiles * r / R), t1 = (unsigned)((uint64_t)ntiles * (r + 1) / R);
+	const size_t nmine = (size_t)(t1 - t0) * FP_TILE;
 	L.pwrun.ensure((FP_THREADS + 1) * sizeof(Fp)); L.pwT.ensure((FP_THREADS + 1) * sizeof(Fp));
 	{
 		std::vector<Fp> pw(2 * (FP_THREADS + 1));
@@ -705,18 +733,19 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	{	// pre-flight (as lk_preflight of the rank doubling): 32 B per element of records + ~8 B of outputs, against what the device has free,
 		// BEFORE the first large allocation -- a clear SBL_ERR_OOM instead of a failure half way through (SBL_TEST_FREE_MEM_MB: test switch)
 		auto miss = [](const DevBuf &b, size_t want) { return want > b.cap ? want + want / 16 + 256 : (size_t)0; };
-		const size_t need = miss(L.key1, n * 8) + miss(L.rec, n * 8) + miss(L.skey1, n * 8) + miss(L.srec, n * 8) + miss(L.members, n * 8 + 16) + miss(L.pairs, (n / 8 + 4096) * 8 + 16) + miss(L.tmp, n / 64 + (1u << 20));
+		const size_t nn = nmine + 16;
+		const size_t need = miss(L.key1, nn * 8) + miss(L.rec, nn * 8) + miss(L.skey1, nn * 8) + miss(L.srec, nn * 8) + miss(L.members, nn * 8 + 16) + miss(L.pairs, (nn / 8 + 4096) * 8 + 16) + miss(L.tmp, nn / 64 + (1u << 20));
 		size_t fr = 0, tot = 0;
 		if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
 			if (const char *e = getenv("SBL_TEST_FREE_MEM_MB")) fr = (size_t)atoll(e) << 20;
 			if (need > fr) {
 				char b[200];
-				snprintf(b, sizeof b, "long-k enumeration of %zu windows needs %zu MB of workspace, %zu MB free on the device", n, need >> 20, fr >> 20);
+				snprintf(b, sizeof b, "long-k enumeration of %zu windows needs %zu MB of workspace, %zu MB free on the device", nmine, need >> 20, fr >> 20);
 				throw SblError{SBL_ERR_OOM, b};
 			}
 		} else (void)hipGetLastError();
 	}
-	L.key1.ensure(n * 8); L.rec.ensure(n * 8); L.skey1.ensure(n * 8); L.srec.ensure(n * 8);
+	L.key1.ensure(nmine * 8 + 16); L.rec.ensure(nmine * 8 + 16); L.skey1.ensure(nmine * 8 + 16); L.srec.ensure(nmine * 8 + 16);
 	L.ctr.ensure(256 * 4);
 	HIP_TRY(hipEventRecord(c->ev[0], s));
 	k_fp_tiles<<<nblocks(nx, FP_THREADS / 64), FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, nx, C, L.tiles.as<Fp>());
@@ -725,69 +754,129 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 	k_fp_apply<<<ntchunks + 1, FP_THREADS, 0, s>>>(ntchunks, L.cP.as<Fp>(), L.cS.as<Fp>(), L.pwT.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>());
 	unsigned weak = 0;
 	if (const char *e = getenv("SBL_TEST_WEAK_FP")) weak = (unsigned)std::min(60, std::max(0, atoi(e)));      // test hook: collisions on purpose (the verification must notice)
-	k_fp_records<<<nblocks(ntiles, FP_THREADS / 64), FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C, ntiles,
+	if (t1 > t0) k_fp_records<<<nblocks(t1 - t0, FP_THREADS / 64), FP_THREADS, 0, s>>>(c->d_pk.as<u64>(), nwords, c->d_ch.as<uint8_t>(), E, c->d_sepidx.as<unsigned>(), c->nchr, C, t0, t1,
 	                                          L.tiles.as<Fp>(), L.PT.as<Fp>(), L.ST.as<Fp>(), L.pwrun.as<Fp>(), weak, L.key1.as<u64>(), L.rec.as<u64>());
 	HIP_TRY(hipGetLastError());
 
 	unsigned bits = 4;
-	while (bits < 30 && (n >> bits) > FPB_SLOTS * 9 / 16) bits++;
+	while (bits < 30 && (n >> bits) > FPB_SLOTS * 9 / 16) bits++;                // (the same on every rank: buckets are sized by the WHOLE input)
 	if (const char *e = getenv("SBL_TEST_BUCKET_BITS")) bits = std::min(bits, (unsigned)std::max(1, atoi(e)));
-	size_t maxpairs = n / 8 + 4096, maxmembers = n;
+	size_t maxpairs = n / R / 8 + 4096;
 	if (const char *e = getenv("SBL_TEST_MAXPAIRS")) maxpairs = (size_t)std::max(1, atoi(e));
 	unsigned cnt[3] = {0, 0, 0};
+	const u64 *ckey = nullptr, *cval = nullptr;                                   // what the classification reads: my partitioned records, or what I own of everybody's
+	size_t nown = nmine;
+	auto partition = [&](u64 *kin, u64 *kout, u64 *vin, u64 *vout, size_t m) {
+		if (!m) return;
+		size_t tmp = 0;
+		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, m, 0, bits, s));
+		L.tmp.ensure(tmp);
+		HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, kin, kout, vin, vout, m, 0, bits, s));
+	};
 	for (int attempt = 0;; attempt++) {
 		SBL_CHECK(attempt < 8, SBL_ERR_INTERNAL, "k-mer bucket classification did not converge");
-		if (attempt == 0 || (cnt[2] & 1u)) {
-			if (attempt) { SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)"); bits = std::min(bits + 2, 28u); }
-			size_t tmp = 0;
-			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<u64>(), L.srec.as<u64>(), n, 0, bits, s));
-			L.tmp.ensure(tmp);
-			HIP_TRY(rocprim::radix_sort_pairs(L.tmp.p, tmp, L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<u64>(), L.srec.as<u64>(), n, 0, bits, s));
-			L.boff.ensure((((size_t)1 << bits) + 1) * 4 + 64);
-			k_fp_bucket_bounds<<<nblocks(((size_t)1 << bits) + 1, 256), 256, 0, s>>>(L.skey1.as<u64>(), n, bits, L.boff.as<unsigned>());
+		const size_t nb = (size_t)1 << bits;
+		L.boff.ensure((nb + 1) * 4 + 64);
+		partition(L.key1.as<u64>(), L.skey1.as<u64>(), L.rec.as<u64>(), L.srec.as<u64>(), nmine);
+		k_fp_bucket_bounds<<<nblocks(nb + 1, 256), 256, 0, s>>>(L.skey1.as<u64>(), nmine, bits, L.boff.as<unsigned>());
+		ckey = L.skey1.as<u64>(); cval = L.srec.as<u64>(); nown = nmine;
+		if (sh) {
+			// ---- the exchange: what goes to one owner is ONE contiguous range of the partitioned arrays
+			std::vector<unsigned> fb(R + 1), send_at(R + 1, 0);
+			uint64_t trange[2];
+			SBL_CHECK(sbl_shard_layout(R, r, bits, ntiles, fb.data(), trange) == SBL_OK, SBL_ERR_INTERNAL, "shard layout");
+			for (uint32_t p = 0; p <= R; p++) HIP_TRY(hipMemcpyAsync(&send_at[p], L.boff.as<unsigned>() + fb[p], 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			std::vector<unsigned long long> scount(R), allcount((size_t)R * R);
+			for (uint32_t p = 0; p < R; p++) scount[p] = send_at[p + 1] - send_at[p];
+			timed([&] { cm->allgather_host(c, scount.data(), R * 8, allcount.data()); });
+			std::vector<size_t> sb(R), so(R), rb(R), ro(R);
+			uint64_t got = 0;
+			static_assert(sizeof(size_t) == sizeof(uint64_t), "64-bit host");
+			SBL_CHECK(sbl_shard_exchange_plan(R, r, (const uint64_t *)allcount.data(), send_at.data(), 8, (uint64_t *)sb.data(), (uint64_t *)so.data(),
+			                                  (uint64_t *)rb.data(), (uint64_t *)ro.data(), &got) == SBL_OK, SBL_ERR_INTERNAL, "exchange plan: the gathered counts contradict my own");
+			nown = (size_t)got;
+			SBL_CHECK(nown < 0xFFFFFFF0ull, SBL_ERR_TOO_LARGE, "too many records for one owner");
+			for (uint32_t p = 0; p < R; p++) if (p != r) c->stats.exchange_bytes += 2 * sb[p];
+			L.rkey.ensure(2 * (nown * 8 + 16)); L.rval.ensure(2 * (nown * 8 + 16));      // received / partitioned again
+			u64 *rk = L.rkey.as<u64>(), *rv = L.rval.as<u64>(), *ok = rk + nown + 2, *ov = rv + nown + 2;
+			timed([&] { cm->alltoallv(c, (const char *)L.skey1.as<u64>(), sb.data(), so.data(), (char *)rk, rb.data(), ro.data()); });
+			timed([&] { cm->alltoallv(c, (const char *)L.srec.as<u64>(), sb.data(), so.data(), (char *)rv, rb.data(), ro.data()); });
+			partition(rk, ok, rv, ov, nown);                                      // R runs, each sorted by bucket
+			k_fp_bucket_bounds<<<nblocks(nb + 1, 256), 256, 0, s>>>(ok, nown, bits, L.boff.as<unsigned>());
+			ckey = ok; cval = ov;
 		}
-		L.pairs.ensure(maxpairs * 8 + 16); L.members.ensure(maxmembers * 8 + 16);
-		HIP_TRY(hipMemsetAsync(L.ctr.p, 0, 256 * 4, s));
-		k_fp_classify<<<nblocks((size_t)1 << bits, FPB_GROUP), FPB_THREADS, 0, s>>>(L.skey1.as<u64>(), L.srec.as<u64>(), L.boff.as<unsigned>(), (unsigned)((size_t)1 << bits), L.ctr.as<unsigned>(),
-		                                                                   L.pairs.as<u64>(), (unsigned)maxpairs, L.members.as<u64>(), (unsigned)maxmembers);
-		HIP_TRY(hipGetLastError());
-		unsigned all[FPB_CTR_WORDS];
-		HIP_TRY(hipMemcpyAsync(all, L.ctr.p, sizeof all, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
-		cnt[0] = all[FPB_CTR_PAIRS]; cnt[1] = all[FPB_CTR_MEM]; cnt[2] = all[FPB_CTR_FLAG];
-		if (cnt[2] & 1u) continue;
-		if (cnt[0] > maxpairs) { maxpairs = (size_t)cnt[0] + 1024; continue; }
-		break;
+		const size_t maxmembers = nown;
+		for (;;) {
+			L.pairs.ensure(maxpairs * 8 + 16); L.members.ensure(maxmembers * 8 + 16);
+			HIP_TRY(hipMemsetAsync(L.ctr.p, 0, 256 * 4, s));
+			k_fp_classify<<<nblocks(nb, FPB_GROUP), FPB_THREADS, 0, s>>>(ckey, cval, L.boff.as<unsigned>(), (unsigned)nb, L.ctr.as<unsigned>(),
+			                                                            L.pairs.as<u64>(), (unsigned)maxpairs, L.members.as<u64>(), (unsigned)maxmembers);
+			HIP_TRY(hipGetLastError());
+			unsigned all[FPB_CTR_WORDS];
+			HIP_TRY(hipMemcpyAsync(all, L.ctr.p, sizeof all, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			cnt[0] = all[FPB_CTR_PAIRS]; cnt[1] = all[FPB_CTR_MEM]; cnt[2] = all[FPB_CTR_FLAG];
+			if (!(cnt[2] & 1u) && cnt[0] > maxpairs) { maxpairs = (size_t)cnt[0] + 1024; continue; }
+			break;
+		}
+		bool rebucket = (cnt[2] & 1u) != 0;
+		if (sh) {                                                                // a bucket that overflowed anywhere makes everybody re-bucket with a longer prefix
+			std::vector<unsigned long long> flag(1, rebucket ? 1 : 0), flags(R);
+			timed([&] { cm->allgather_host(c, flag.data(), 8, flags.data()); });
+			rebucket = std::find(flags.begin(), flags.end(), 1ull) != flags.end();
+		}
+		if (!rebucket) break;
+		SBL_CHECK(bits < 28, SBL_ERR_TOO_LARGE, "k-mer buckets keep overflowing at 2^28 buckets (adversarial key distribution)");
+		bits = std::min(bits + 2, 28u);
 	}
 	HIP_TRY(hipEventRecord(c->ev[1], s));
-	const unsigned npairs = cnt[0], nmem = cnt[1];
-	SBL_CHECK(nmem <= maxmembers, SBL_ERR_INTERNAL, "more member positions than windows");
+	const unsigned mypairs = cnt[0], nmem = cnt[1];
+	SBL_CHECK(nmem <= nown, SBL_ERR_INTERNAL, "more member positions than windows");
 
-	// ---- F6: verification of every member of every bifurcation group
+	// ---- F6: verification of every member of every bifurcation group (owners verify their buckets: the packed sequence is everywhere)
 	const unsigned nchunks = (k + 31) / 32;
 	unsigned *d_bad = L.ctr.as<unsigned>() + 128, *d_nkeys = L.ctr.as<unsigned>() + 160, *d_nheads = L.ctr.as<unsigned>() + 192;
-	if (nmem) {
-		const size_t work = (size_t)nmem * nchunks;
-		SBL_CHECK(work / 256 < 0x7FFFFFFFull, SBL_ERR_TOO_LARGE, "verification grid too large");
-		k_fp_verify<<<nblocks(work, 256), 256, 0, s>>>(c->d_pk.as<u64>(), L.members.as<u64>(), nmem, L.pairs.as<u64>(), k, nchunks, d_bad);
+	{
 		unsigned bad = 0;
-		HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
-		if (bad) {
-			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] long k: %u of %zu chunk comparisons of the fingerprint groups failed -- falling back to exact rank doubling\n", bad, work);
+		const size_t work = (size_t)nmem * nchunks;
+		if (nmem) {
+			SBL_CHECK(work / 256 < 0x7FFFFFFFull, SBL_ERR_TOO_LARGE, "verification grid too large");
+			k_fp_verify<<<nblocks(work, 256), 256, 0, s>>>(c->d_pk.as<u64>(), L.members.as<u64>(), nmem, L.pairs.as<u64>(), k, nchunks, d_bad);
+			HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+		}
+		unsigned long long anybad = bad;
+		if (sh) {                                                                // one rank's failed comparison sends EVERY rank to the rank doubling
+			std::vector<unsigned long long> mine(1, bad), all(R);
+			timed([&] { cm->allgather_host(c, mine.data(), 8, all.data()); });
+			anybad = 0; for (auto v : all) anybad += v;
+		}
+		if (anybad) {
+			if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] long k: %llu of the chunk comparisons of the fingerprint groups failed -- falling back to exact rank doubling\n", anybad);
 			return false;
 		}
 	}
 	c->stats.fp_verified = (uint64_t)nmem;
 
-	// ---- F7: ids = lexicographic rank of the bifurcation k-mers
+	// ---- F7: ids = lexicographic rank of the bifurcation k-mers; with several GPUs the representatives of all owners, in rank order
+	const u64 *gp = L.pairs.as<u64>();
+	unsigned npairs = mypairs;
+	size_t pair0 = 0;                                                            // index of my first pair among everybody's
+	if (sh) {
+		size_t at = 0;
+		const size_t tot = allgatherv((const char *)L.pairs.as<u64>(), (size_t)mypairs * 8, L.gpairs, &at);
+		SBL_CHECK(tot / 8 < 0x7FFFFFF0ull, SBL_ERR_TOO_LARGE, "too many bifurcations");
+		gp = L.gpairs.as<u64>(); npairs = (unsigned)(tot / 8); pair0 = at / 8;
+	}
 	unsigned nkeys = 0;
 	L.pairids.ensure((size_t)npairs * 8 + 16);
 	if (npairs) {
 		const size_t cap = 2 * (size_t)npairs;
 		L.ref.ensure(cap * 8); L.payload.ensure(cap * 4); L.rank.ensure(cap * 4); L.keys.ensure(cap * 8); L.skeys.ensure(cap * 8); L.idx.ensure(cap * 4); L.sidx.ensure(cap * 4);
 		L.head.ensure(cap * 4); L.gstart.ensure(cap * 4);
-		k_fp_rank_init<<<nblocks(npairs, 256), 256, 0, s>>>(L.pairs.as<u64>(), npairs, L.ref.as<u64>(), L.payload.as<unsigned>(), d_nkeys);
+		HIP_TRY(hipMemsetAsync(d_nkeys, 0, 4, s));
+		k_fp_rank_init<<<nblocks(npairs, 256), 256, 0, s>>>(gp, npairs, L.ref.as<u64>(), L.payload.as<unsigned>(), d_nkeys);
 		HIP_TRY(hipMemcpyAsync(&nkeys, d_nkeys, 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipMemsetAsync(L.rank.p, 0, cap * 4, s));
 		HIP_TRY(hipStreamSynchronize(s));
@@ -811,14 +900,26 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			if (heads == nkeys) break;                                      // every string stands alone: ranks are final
 			SBL_CHECK(off + csym < k || heads == nkeys, SBL_ERR_INTERNAL, "two bifurcation k-mers compare equal over their whole length");
 		}
-		k_fp_rank_ids<<<nblocks(nkeys, 256), 256, 0, s>>>(L.rank.as<unsigned>(), L.payload.as<unsigned>(), L.pairs.as<u64>(), nkeys, L.pairids.as<unsigned>());
+		k_fp_rank_ids<<<nblocks(nkeys, 256), 256, 0, s>>>(L.rank.as<unsigned>(), L.payload.as<unsigned>(), gp, nkeys, L.pairids.as<unsigned>());
 	}
 	c->bif_count = nkeys;
+	const unsigned *myids = L.pairids.as<unsigned>() + 2 * pair0;                 // ids of MY pairs (the members carry my pair indices)
 	for (int st = 0; st < 2; st++) {
 		c->d_bif[st].ensure(elem_capacity * 4);
 		HIP_TRY(hipMemsetAsync(c->d_bif[st].p, 0xFF, elem_capacity * 4, s));
 	}
-	if (nmem) k_fp_marks<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, L.pairids.as<unsigned>(), c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
+	if (sh) {
+		// marks of my buckets' member positions, gathered and scattered into the dense arrays everywhere (16 B per member position)
+		for (int st = 0; st < 2; st++) {
+			L.keys.ensure((size_t)nmem * 4 + 16); L.skeys.ensure((size_t)nmem * 4 + 16);
+			if (nmem) k_fp_mark_pairs<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, myids, (unsigned)st, L.keys.as<unsigned>(), L.skeys.as<unsigned>());
+			HIP_TRY(hipGetLastError());
+			const size_t tot = allgatherv((const char *)L.keys.as<unsigned>(), (size_t)nmem * 4, L.gel, nullptr) / 4;
+			allgatherv((const char *)L.skeys.as<unsigned>(), (size_t)nmem * 4, L.gid, nullptr);
+			if (tot) k_scatter_marks<<<nblocks(tot, 256), 256, 0, s>>>(L.gel.as<unsigned>(), L.gid.as<unsigned>(), tot, c->d_bif[st].as<unsigned>());
+		}
+	} else {
+	if (nmem) k_fp_marks<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, myids, c->d_bif[0].as<unsigned>(), c->d_bif[1].as<unsigned>());
 	// The ordered (element, id) lists of the marks (what sbl_compact_marks makes by scanning every element of both mark arrays twice):
 	// with few members -- a cascade state has hundreds, 900 Mbp of random sequence 40 -- sorting them is next to nothing (6.5 ms of
 	// scans at 900 Mbp).  A window is a member once, so no element appears twice in a strand's list.  (SBL_FP_DENSE_MARKS=1: test switch.)
@@ -828,7 +929,7 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 			c->nmarks[st] = nmem;
 			if (!nmem) continue;
 			L.keys.ensure((size_t)nmem * 4 + 16); L.skeys.ensure((size_t)nmem * 4 + 16);
-			k_fp_mark_pairs<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, L.pairids.as<unsigned>(), (unsigned)st, L.keys.as<unsigned>(), L.skeys.as<unsigned>());
+			k_fp_mark_pairs<<<nblocks(nmem, 256), 256, 0, s>>>(L.members.as<u64>(), nmem, k, myids, (unsigned)st, L.keys.as<unsigned>(), L.skeys.as<unsigned>());
 			size_t tmp = 0;
 			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, L.keys.as<unsigned>(), c->d_melem[st].as<unsigned>(), L.skeys.as<unsigned>(), c->d_mid[st].as<unsigned>(), nmem, 0, 32, s));
 			L.tmp.ensure(tmp);
@@ -836,6 +937,8 @@ bool sbl_run_enumeration_longk_fp(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		}
 		c->marks_compact_ready = true;
 	}
+	}
+	c->stats.exchange_ms = xms;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	float ms = 0;

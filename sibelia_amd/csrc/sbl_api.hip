@@ -7,6 +7,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "sbl_ctx.h"
+#include "sbl_comm.h"
 #include "kmer_kernels.h"
 #include "kmer_bucket_kernels.h"
 
@@ -219,9 +220,20 @@ void sbl_run_enumeration(sbl_ctx *c, uint32_t k, size_t elem_capacity)
 		// attached GPUs -- for a job on several GPUs
 		const bool doubling = getenv("SBL_LONGK_DOUBLING") != nullptr && atoi(getenv("SBL_LONGK_DOUBLING")) != 0;
 		c->stats.longk_path = 0;
-		if (c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr) { sbl_run_enumeration_longk_sharded(c, k, elem_capacity); c->stats.longk_path = 2; }
-		else if (!doubling && sbl_run_enumeration_longk_fp(c, k, elem_capacity)) c->stats.longk_path = 1;
-		else { sbl_run_enumeration_longk(c, k, elem_capacity); c->stats.longk_path = doubling ? 2 : 3; }      // (3: fell back after a failed verification)
+		const bool sharded = c->comm && getenv("SBL_LONGK_REPLICATED") == nullptr;      // one job on several GPUs: the table (or the doubling) is split over them
+		bool done = false;
+		if (!doubling) {
+			// (with a communicator the fingerprint table is sharded by hash prefix, all-to-all like the k <= 32 table; its verdict "a
+			// verification failed" is agreed on by all ranks, so they all take the fall-back together.  A rank that leaves with an error
+			// releases its peers.)
+			if (sharded) { try { done = sbl_run_enumeration_longk_fp(c, k, elem_capacity); } catch (...) { c->comm->abort_peers(); throw; } }
+			else { struct SblComm *cm = c->comm; c->comm = nullptr; try { done = sbl_run_enumeration_longk_fp(c, k, elem_capacity); } catch (...) { c->comm = cm; throw; } c->comm = cm; }      // (SBL_LONGK_REPLICATED: every rank builds the whole table)
+		}
+		if (done) c->stats.longk_path = 1;
+		else {
+			if (sharded) sbl_run_enumeration_longk_sharded(c, k, elem_capacity); else sbl_run_enumeration_longk(c, k, elem_capacity);
+			c->stats.longk_path = doubling ? 2 : 3;                                      // (3: fell back after a failed verification)
+		}
 		return;
 	}
 	if (c->comm) { sbl_run_enumeration_sharded(c, k, elem_capacity); return; }    // k-mer table sharded by hash prefix over the attached GPUs

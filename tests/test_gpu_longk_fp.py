@@ -152,3 +152,46 @@ def test_random_long_k_cases(monkeypatch):
         got, path = _enumerate(seqs, k, monkeypatch)
         assert path == 1
         _same(got, want, "case %d n %d L0 %d k %d" % (case, n, L0, k))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_fingerprint_table_sharded_over_virtual_ranks(nranks, monkeypatch):
+    """One job on several GPUs: the fingerprint table is sharded by hash prefix like the k <= 32 table (one all-to-all of the 16-B
+    records, owners classify and verify their buckets, representatives all-gathered and ranked everywhere, member marks all-gathered).
+    Every rank returns the single-GPU result, says which path ran, and has sent something; colliding fingerprints send ALL ranks to the
+    sharded rank doubling together."""
+    from oracle.oracle import Oracle
+    from sibelia_amd.dist import LocalShardedFinder
+    seqs = _mixed(seed=5)
+    for k in (33, 100, 1024, 3000):
+        want = Oracle(seqs).enumerate(k)
+        f = LocalShardedFinder(seqs, [0] * nranks)
+        try:
+            _same(f.enumerate(k), want, "%d ranks, k = %d" % (nranks, k))
+            st = f.stats()
+            assert all(int(x["longk_path"]) == 1 for x in st), [int(x["longk_path"]) for x in st]
+            assert all(x["exchange_bytes"] > 0 for x in st)
+        finally:
+            f.close()
+    monkeypatch.setenv("SBL_TEST_WEAK_FP", "8")
+    f = LocalShardedFinder(seqs, [0] * nranks)
+    try:
+        _same(f.enumerate(100), Oracle(seqs).enumerate(100), "%d ranks, weak fingerprints" % nranks)
+        assert all(int(x["longk_path"]) == 3 for x in f.stats())
+    finally:
+        f.close()
+
+
+def test_sharded_long_k_cascade_matches_the_oracle(monkeypatch):
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    from sibelia_amd.dist import LocalShardedFinder
+    seqs = W.gen_strains(L0=50_000, n=4, seed=23, snp=0.02, inv_min=500, inv_max=3000) + [b"ACGT" * 9]
+    f, orc = LocalShardedFinder(seqs, [0, 0, 0]), Oracle(seqs)
+    try:
+        for k, D in ((30, 150), (100, 500), (500, 1500)):
+            assert f.simplify_stage(k, D, 4) == orc.simplify_stage(k, D, 4)
+            (sa, pa), (sb, pb) = f.state(), orc.state()
+            assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb)), (k, D)
+    finally:
+        f.close()

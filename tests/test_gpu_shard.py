@@ -63,10 +63,14 @@ LONGK_SMALL = [v for v in VECS if v["name"].startswith("small/") and _max_k(v) >
 
 @pytest.mark.parametrize("nranks", [2, 3, 5])
 @pytest.mark.parametrize("v", LONGK, ids=[v["name"] for v in LONGK])
-def test_sharded_long_k_matches_reference_genomes(v, nranks):
-    """k > 32 (exact rank doubling) split over the attached GPUs (csrc/longk.hip: sharded rank doubling): the -s loose / -s fine
-    cascades of the reference (k = 100 .. 5000) through 2, 3 and 5 virtual ranks, every output identical on every rank"""
+def test_sharded_long_k_matches_reference_genomes(v, nranks, monkeypatch):
+    """k > 32 split over the attached GPUs: the -s loose / -s fine cascades of the reference (k = 100 .. 5000) through 2, 3 and 5
+    virtual ranks, every output identical on every rank -- by the fingerprint table sharded by hash prefix (csrc/longk_fp.hip, the
+    default since round 6) and, with three ranks, also by the sharded rank doubling (csrc/longk.hip: SBL_LONGK_DOUBLING=1, the fall-back)"""
     V.replay(v, _sharded(nranks))
+    if nranks == 3:
+        monkeypatch.setenv("SBL_LONGK_DOUBLING", "1")
+        V.replay(v, _sharded(nranks))
 
 
 @pytest.mark.parametrize("v", LONGK_SMALL, ids=[v["name"] for v in LONGK_SMALL])
@@ -82,6 +86,7 @@ def test_long_k_is_sharded_not_replicated(monkeypatch):
     from sibelia_amd import BlockFinder, workloads as W
     seqs = W.gen_strains(L0=30_000, n=3, seed=4, inv_min=500, inv_max=2000)
     one, many = BlockFinder(seqs, device=0), _sharded(4)(seqs)
+    monkeypatch.setenv("SBL_LONGK_DOUBLING", "1")      # (the exchange bound below is the sharded rank doubling's; the fingerprint table's sharding: tests/test_gpu_longk_fp.py)
     for k in (33, 64, 100, 500):
         a, b = one.enumerate(k), many.enumerate(k)
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
@@ -90,6 +95,7 @@ def test_long_k_is_sharded_not_replicated(monkeypatch):
         nsuf = 2 * (sum(len(s) for s in seqs) + len(seqs) + 1) - 1 + k
         rounds = max(1, int(np.log2(k)) - 3)
         assert sum(s["exchange_bytes"] for s in st) < (20 * rounds + 12 + 8) * nsuf + (1 << 16)      # 20 B per suffix and round at most
+    monkeypatch.delenv("SBL_LONGK_DOUBLING")
     assert one.simplify_stage(100, 500, 4) == many.simplify_stage(100, 500, 4)
     (sa, pa), (sb, pb) = one.state(), many.state()
     assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb))
