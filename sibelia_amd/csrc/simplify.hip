@@ -293,7 +293,6 @@ struct DeviceBackend {
 	}
 	void snapshot_all(bool incremental)
 	{
-		st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
 		while (st->snap_ev.size() < 2 * (size_t)(snap_used + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); st->snap_ev.push_back(e); }
 		HIP_TRY(hipEventRecord(st->snap_ev[2 * snap_used], c->stream));
 		uint32_t plo = 0, phi = nid_;
@@ -315,8 +314,12 @@ struct DeviceBackend {
 			MarkStream ms;
 			linearise_marks(ms);
 			k_snapshot_stream<<<256 * 32, 64, 0, c->stream>>>(g, ms, st->nmark.as<unsigned>(), st->perm.as<unsigned>(), 1, plo, phi);
-		} else
-		k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>(), plo, phi);
+		} else {
+			// (the walking snapshot's scratch -- up to 16 GB where D is in the thousands -- is only allocated when that kernel runs: a fresh
+			// context that never needs it used to spend seconds mapping it, tools/stress.py LONGK=1)
+			st->snap_arena.ensure((size_t)snap_threads * snap_arena_bytes);
+			k_snapshot<<<snap_threads, 64, 0, c->stream>>>(g, st->snap_arena.as<uint8_t>(), snap_arena_bytes, incremental ? 1 : 0, st->perm.as<unsigned>(), plo, phi);
+		}
 		HIP_TRY(hipGetLastError());
 		if (split) {
 			// the verdict bytes of my share of the positional order to everybody; after a snapshot no id is "touched" any more, anywhere

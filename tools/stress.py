@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle stress: python tools/stress.py [seconds] [first_seed]
 Environment: SHARD=n (n virtual ranks), N2=1 (synteny blocks + GlueStripes + reports as well), STAGES=3 (three-stage cascades),
-MANY=1 (30 - 70 strains of a few kbp: ids with dozens of instances, mark lists and AnyBulges tables in the arena).
+MANY=1 (30 - 70 strains of a few kbp: ids with dozens of instances, mark lists and AnyBulges tables in the arena),
+LONGK=1 (vertex sizes 33 .. 1500: the fingerprint path of longk_fp.hip, cascades k -> 2k).
 A bounded run of the same loop is part of the GPU suite (tests/test_gpu_stress.py)."""
 import os
 import sys
@@ -27,6 +28,10 @@ def draw_case(seed, many=False, stages3=False):
     seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
                          inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
     stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
+    if os.environ.get("LONGK"):                                 # long vertex sizes: k > 32 in every stage
+        k = int(rng.choice([33, 40, 64, 100, 127, 128, 200, 333, 512, 700, 1024, 1500]))
+        D = int(rng.integers(k + 1, 4 * k + 50))
+        stages = [(k, D)] if rng.random() < 0.5 else [(k, D), (2 * k, 2 * D)]
     if stages3:                                                 # every case is a three-stage cascade (state carried across copy-backs)
         stages = [(k, D), (int(min(40, k + 5)), D + 50), (int(min(48, k + 10)), D + 100)]
     return seqs, stages, rng, n, L0, snp
