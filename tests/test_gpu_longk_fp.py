@@ -195,3 +195,39 @@ def test_sharded_long_k_cascade_matches_the_oracle(monkeypatch):
             assert sa == sb and all(np.array_equal(x, y) for x, y in zip(pa, pb)), (k, D)
     finally:
         f.close()
+
+
+def test_bucket_overflow_and_buffer_growth_paths_of_the_fingerprint_table(monkeypatch):
+    """the table re-buckets with a longer prefix when a bucket holds more distinct fingerprints than its LDS table, and grows its pair
+    buffer on demand: force both (2 bucket bits for 1.2 M windows, room for 16 pairs) -- one GPU and three virtual ranks (where the
+    decision to re-bucket is collective)"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    from sibelia_amd.dist import LocalShardedFinder
+    seqs = W.gen_strains(L0=300_000, n=4, seed=17, inv_min=3000, inv_max=12000)
+    want = Oracle(seqs).enumerate(48)
+    monkeypatch.setenv("SBL_TEST_BUCKET_BITS", "2")
+    monkeypatch.setenv("SBL_TEST_MAXPAIRS", "16")
+    for make in (_bf, lambda s: LocalShardedFinder(s, [0, 0, 0])):
+        bf = make(seqs)
+        try:
+            _same(bf.enumerate(48), want, "forced re-bucketing / buffer growth")
+            st = bf.stats()
+            assert all(int(x["longk_path"]) == 1 for x in (st if isinstance(st, list) else [st]))
+        finally:
+            bf.close()
+
+
+@pytest.mark.parametrize("k", [33, 64, 200])
+def test_low_complexity_sequence_at_long_k(k, monkeypatch):
+    """homopolymers and tandem repeats: ONE k-mer with thousands of occurrences (a bucket far larger than the member stage: the direct
+    path of k_fp_classify), k-mers that are their own reverse complement over long stretches ((AT)n at even k), every window a bifurcation"""
+    from oracle.oracle import Oracle
+    from sibelia_amd import workloads as W
+    rnd = W.random_dna(4000, 3, seed=41)
+    seqs = [b"A" * 6000 + rnd[0] + b"T" * 3000, b"AT" * 2500 + rnd[1] + b"ACG" * 1500, rnd[2][:1500] + b"A" * 2500 + rnd[2][1500:] + b"CCGG" * 700, b"AT" * 40, b"A" * (k + 1)]
+    want = Oracle(seqs).enumerate(k)
+    got, path = _enumerate(seqs, k, monkeypatch)
+    assert path == 1
+    _same(got, want, "low complexity, k = %d" % k)
+    assert want[0] > 0
