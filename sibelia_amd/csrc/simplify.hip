@@ -38,6 +38,13 @@ struct SimplifyState {
 };
 
 struct RestartStage {};      // thrown out of an optimistic attempt that would need a roll-back (DeviceBackend::restore)
+// thrown out of the ordered rounds when they have turned into a slow serial chain and the one-launch path is the better bet (round 6):
+// many strains x genomes of a few kbp x a minBranchSize of a tenth of a genome -- a transaction's neighbourhood IS the genome, the
+// rounds commit one or two transactions each, and a round costs 10 - 30 ms there (tools/stress.py MANY=1: seed 67000 121 s, 67008 17.8 s,
+// 67012 19.8 s against 32 / 6.2 / 5.7 s through k_dense_stage, exact either way; the same path is 10 - 100 x SLOWER on every input the
+// rounds parallelise -- measured case by case, gpurun_out/r6k -- so it is only taken after the rounds have shown what they are)
+struct TryDense {};
+#define DENSE_SWITCH_MAX_ELEMS (4u << 20)
 
 struct DeviceBackend {
 	sbl_ctx *c;
@@ -104,6 +111,10 @@ struct DeviceBackend {
 		g.idx_probe = g.bidx && getenv("SBL_NO_IDX_PROBE") == nullptr ? 1u : 0u;        // measurement switches: the walking probe / reservation for every entry
 		g.idx_reserve = g.bidx && getenv("SBL_NO_IDX_RESERVE") == nullptr ? 1u : 0u;
 	}
+	// ---- the switch to the one-launch path (TryDense): allowed for this attempt, chain-mode rounds so far, progress of the stage
+	bool may_try_dense = false;
+	uint32_t chain_rounds = 0, iter_count = 0, last_lo = 0, max_iter_ = 1;
+	std::chrono::steady_clock::time_point t_stage = std::chrono::steady_clock::now();
 	bool posted = false;                                              // the selection in flight posts the counters itself (k_select_write)
 	void read_ctr()
 	{
@@ -130,6 +141,7 @@ struct DeviceBackend {
 	}
 	void checkpoint()
 	{
+		iter_count++;                                               // (called once per iteration, before its first snapshot)
 		read_ctr();
 		ck_ne = st->h_ctr[CTR_NE]; ck_nn = st->h_ctr[CTR_NN];
 		if (optimistic) return;
@@ -390,6 +402,7 @@ struct DeviceBackend {
 		if (!sel_ready) read_ctr();                                 // (the first selection of an iteration, or one re-issued behind a fence)
 		sel_pending = sel_ready = false;
 		*nwin = st->h_ctr[CTR_NWIN]; *newlo = st->h_ctr[CTR_LO]; *solo = st->h_ctr[CTR_PUSHED];
+		last_lo = *newlo;
 	}
 	// Per-kernel times of the rounds: start stamps written by the kernels themselves (round_stamp) for probe and reservation, and a
 	// HIP event pair around the dominant kernel, k_commit (what bench.py's roofline is computed from).
@@ -506,6 +519,13 @@ struct DeviceBackend {
 	uint32_t parked_known = 0;                                        // ctr[CTR_PARKED] as of the last counters(): transactions parked when the next launches start
 	bool chain(uint32_t nwin, uint32_t round)
 	{
+		// the driver is in chain mode: the rounds have stopped being parallel.  After three seconds with less than 30 % of the stage behind it
+		// (iterations x ids: a lower bound -- later iterations are usually shorter) the attempt is given up for the one-launch path.
+		if (may_try_dense && ++chain_rounds >= 32u) {
+			const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
+			const double progress = ((double)(iter_count ? iter_count - 1u : 0u) + (double)last_lo / (double)(nid_ ? nid_ : 1u)) / (double)max_iter_;
+			if (el > 3.0 && progress < 0.3) throw TryDense{};
+		}
 		// parked transactions resume in an ordered round (the chain kernel has another LDS layout): the driver has asked for the chain, so
 		// nothing NEW parks from here on (GraphView::park_hold) -- what is parked runs to its end in the next rounds and the chain starts then
 		if (g.park_cap && parked_known) { g.park_hold = 1; return false; }
@@ -620,8 +640,9 @@ struct ProgressFilter {
 		else if (!f->ended) { f->ended = true; f->fn(p, state, f->user); }
 	}
 };
-enum { RUN_DONE = 0, RUN_DENSE_FAILED = 1, RUN_RESTART = 2 };
-static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic);
+enum { RUN_DONE = 0, RUN_DENSE_FAILED = 1, RUN_RESTART = 2, RUN_TRY_DENSE = 3 };
+static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic,
+                             bool force_dense = false /* the one-launch path for up to DENSE_SWITCH_MAX_ELEMS elements: the rounds gave up (TryDense) */, bool may_switch = false /* this attempt may give up for it */);
 static void simplify_run_guarded(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges);
 void sbl_simplify_run(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges)
 {
@@ -642,7 +663,12 @@ static void simplify_run_guarded(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t ma
 	// context had to be abandoned for an order violation -- inputs that do that once tend to do it again, and an abandoned attempt
 	// costs a whole stage, a checkpoint 2 - 4 %)
 	const bool optimistic = getenv("SBL_CHECKPOINTS") == nullptr && !c->hint_checkpoints;
-	int r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, true, optimistic);
+	int r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, true, optimistic, false, true);
+	if (r == RUN_TRY_DENSE) {
+		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] the ordered rounds have turned into a slow serial chain: the stage runs again through the one-launch path\n");
+		r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, true, optimistic, true, false);
+		c->stats.replays++;                                               // the abandoned attempt
+	}
 	if (r == RUN_DENSE_FAILED) r = simplify_run_impl(c, k, D, max_iter, pfn, &pf, bulges, false, optimistic);
 	if (r == RUN_RESTART) {
 		if (getenv("SBL_TRACE")) fprintf(stderr, "[sbl] optimistic attempt abandoned: the stage runs again with iteration checkpoints (element slack hint %zu, node capacity hint %zu)\n", c->hint_elem_slack, c->hint_cap_n);
@@ -651,7 +677,8 @@ static void simplify_run_guarded(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t ma
 		c->hint_checkpoints = c->stats.replays > c->stats.grow_replays + 1;      // order violations (not just a pool that was too small): the next stage starts with checkpoints
 	} else if (!optimistic && r == RUN_DONE && c->stats.replays == c->stats.grow_replays) c->hint_checkpoints = false;      // a checkpointed stage that never rolled back
 }
-static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic)
+static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_iter, sbl_progress_fn progress, void *user, uint64_t *bulges, bool allow_dense, bool optimistic,
+                             bool force_dense, bool may_switch)
 {
 	hipStream_t s = c->stream;
 	if (!c->simp) {
@@ -695,7 +722,11 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	c->stats.instances = ninst;
 	size_t dense_max = DENSE_MAX_ELEMS;
 	if (const char *e = getenv("SBL_DENSE_MAX_ELEMS")) dense_max = (size_t)atoll(e);
+	if (force_dense) dense_max = std::max<size_t>(dense_max, DENSE_SWITCH_MAX_ELEMS);
 	const bool dense = allow_dense && E <= dense_max && be.nid_ > 0 && getenv("SBL_NO_DENSE_PATH") == nullptr;
+	// (a job on several GPUs never switches: the decision is timed, and the ranks must stay in step)
+	be.may_try_dense = may_switch && !dense && !c->comm && E <= DENSE_SWITCH_MAX_ELEMS && getenv("SBL_NO_DENSE_PATH") == nullptr && getenv("SBL_NO_DENSE_SWITCH") == nullptr;
+	be.max_iter_ = max_iter ? max_iter : 1u;
 	// (the one-launch path cannot grow a pool and replay: low-complexity input makes hundreds of nodes per collapse, and 16 M nodes are 270 MB)
 	size_t cap_n = dense ? std::max<size_t>(4 * ninst + (1u << 20), 16u << 20) : 4 * ninst + (1u << 20);
 	if (dense) if (const char *e = getenv("SBL_TEST_DENSE_NODE_SLACK")) cap_n = ninst + (size_t)atoll(e);      // test hook: provoke the fall-back
@@ -904,6 +935,7 @@ static int simplify_run_impl(sbl_ctx *c, uint32_t k, uint32_t D, uint32_t max_it
 	} else {
 		try { rep = simplify_graph(be, max_iter, window, progress, user, window_max); }
 		catch (const RestartStage &) { HIP_TRY(hipStreamSynchronize(s)); return RUN_RESTART; }
+		catch (const TryDense &) { HIP_TRY(hipStreamSynchronize(s)); return RUN_TRY_DENSE; }
 	}
 	HIP_TRY(hipEventRecord(c->ev[4], s));
 	if (!dense && be.phase_events) be.stamps_collect();
