@@ -41,8 +41,8 @@ struct RestartStage {};      // thrown out of an optimistic attempt that would n
 // thrown out of the ordered rounds when they have turned into a slow serial chain and the one-launch path is the better bet (round 6):
 // many strains x genomes of a few kbp x a minBranchSize of a tenth of a genome -- a transaction's neighbourhood IS the genome, the
 // rounds commit one or two transactions each, and a round costs 10 - 30 ms there (tools/stress.py MANY=1: seed 67000 121 s, 67008 17.8 s,
-// 67012 19.8 s against 32 / 6.2 / 5.7 s through k_dense_stage, exact either way; the same path is 10 - 100 x SLOWER on every input the
-// rounds parallelise -- measured case by case, gpurun_out/r6k -- so it is only taken after the rounds have shown what they are)
+// 67012 19.8 s against 8.8 / 2.2 / 2.5 s through k_dense_stage, exact either way; the same path is 3 - 100 x SLOWER on every input the
+// rounds parallelise -- measured case by case, tools/gpu_r06_k.sh -- so it is only taken after the rounds have shown what they are)
 struct TryDense {};
 #define DENSE_SWITCH_MAX_ELEMS (4u << 20)
 
@@ -519,12 +519,15 @@ struct DeviceBackend {
 	uint32_t parked_known = 0;                                        // ctr[CTR_PARKED] as of the last counters(): transactions parked when the next launches start
 	bool chain(uint32_t nwin, uint32_t round)
 	{
-		// the driver is in chain mode: the rounds have stopped being parallel.  After three seconds with less than 30 % of the stage behind it
-		// (iterations x ids: a lower bound -- later iterations are usually shorter) the attempt is given up for the one-launch path.
+		// the driver is in chain mode: the rounds have stopped being parallel.  After a second, with less than 40 % of the stage behind it
+		// (the first iteration counted as 80 % of a stage: the later ones see what the few collapses of the one before left), the attempt
+		// is given up for the one-launch path -- which is within 2 x of the rounds on every many-strains case measured and up to 8 x
+		// faster on the slow ones (tools/gpu_r06_k.sh).
 		if (may_try_dense && ++chain_rounds >= 32u) {
 			const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
-			const double progress = ((double)(iter_count ? iter_count - 1u : 0u) + (double)last_lo / (double)(nid_ ? nid_ : 1u)) / (double)max_iter_;
-			if (el > 3.0 && progress < 0.3) throw TryDense{};
+			const double within = (double)last_lo / (double)(nid_ ? nid_ : 1u);
+			const double progress = iter_count <= 1u ? 0.8 * within : 0.8 + 0.2 * ((double)(iter_count - 2u) + within) / (double)(max_iter_ > 1u ? max_iter_ - 1u : 1u);
+			if (el > 1.0 && progress < 0.4) throw TryDense{};
 		}
 		// parked transactions resume in an ordered round (the chain kernel has another LDS layout): the driver has asked for the chain, so
 		// nothing NEW parks from here on (GraphView::park_hold) -- what is parked runs to its end in the next rounds and the chain starts then

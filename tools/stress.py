@@ -58,7 +58,10 @@ def run(budget=300.0, seed=1000, stages3=False, nshard=0, n2=False, log=print, c
         orc = Oracle(seqs)
         tg = tc = 0.0
         if rng.random() < 0.3 and not nshard:
-            bf.set_window(int(rng.choice([1, 3, 64, 1000])))
+            # a pinned commit window (results must not depend on it).  MANY=1: not the windows of 1 and 3 entries -- one or three ids per round on
+            # 15 000 ids x 4 iterations is 17 734 rounds of 13 ms: round 5's "livelock" of seed 67000 was this knob, not the product (r06.md 1b)
+            w = int(rng.choice([1, 3, 64, 1000]))
+            bf.set_window(w if not os.environ.get("MANY") else max(w, 64))
         ok = True
         for kk, dd in stages:
             t1 = time.time(); a = bf.simplify_stage(kk, dd, 4); t2 = time.time(); b = orc.simplify_stage(kk, dd, 4); t3 = time.time()
