@@ -56,7 +56,6 @@ __host__ __device__ __forceinline__ u64 sub61(u64 x, u64 y) { return x >= y ? x 
 __host__ __device__ __forceinline__ Fp fp_mul(Fp x, Fp y) { return Fp{mul61(x.a, y.a), x.b * y.b}; }
 __host__ __device__ __forceinline__ Fp fp_add(Fp x, Fp y) { return Fp{add61(x.a, y.a), x.b + y.b}; }
 __host__ __device__ __forceinline__ Fp fp_sub(Fp x, Fp y) { return Fp{sub61(x.a, y.a), x.b - y.b}; }
-__host__ __device__ __forceinline__ Fp fp_sym(unsigned s) { return Fp{(u64)s, (u64)s}; }
 __host__ __device__ __forceinline__ Fp fp_horner(Fp h, Fp base, unsigned s) { return Fp{add61(mul61(h.a, base.a), (u64)s), h.b * base.b + s}; }   // h B + s
 
 #define FP_TILE 512u                              // elements per tile = one wave x FP_RUN (the scans inside a tile are wave scans: no LDS, no barrier)
