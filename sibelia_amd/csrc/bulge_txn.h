@@ -120,6 +120,14 @@ struct GraphView {
 	// entries of this round (appended by k_reserve, ctr[CTR_PLIST] of them): k_resume's grid is the parked transactions, not the window.
 	uint32_t park_hold, any_parked; uint32_t *park_list;
 };
+// The LDS state of a parked transaction (Txn first) sits in the last PARK_IMG bytes of its arena slice (commit.hip: park_store / park_load).
+// Cleanup is part of a transaction's END (bifurcationstorage.cpp:33-41; CountBifurcations, :71-75, counts erased instances until then --
+// the transaction itself reads such sizes, bt_max_mult_pair), so while a transaction is parked the ids it has erased instances of carry
+// list sizes that are one transaction's private view.  The marks are gone from the graph, so no neighbourhood walk finds those ids any
+// more: the reservation of a parked entry claims them from the image's erase chain (Txn::tc_head through nclr, k_reserve) -- exclusively,
+// every round until the transaction is through -- and whoever would read such a size waits, exactly as for an id inside the core.
+// (Found by tools/stress.py seed 93194: a neighbour read a size one too high, collapsed in the other direction and counted one bulge less.)
+#define PARK_IMG 12288u
 #define CTR_PARKED (CTR_DETAIL + 8)      // parked transactions at the moment
 #define CTR_PLIST (CTR_DETAIL + 10)      // entries of GraphView::park_list in this round (reset behind every round by k_select_write)
 // (the tag is 11 bits of a 12-bit round: finished markers are swept every 1024 rounds, DeviceBackend::commit, so that none survives to the round with the same tag)

@@ -46,6 +46,26 @@ __device__ __forceinline__ void wave_erase(const GraphView &g, Txn &t, unsigned 
 }
 
 __device__ unsigned long long g_txn_hist[4][16];   // SBL_PHASES=1: transactions by number of collapses (0, 1, 2, 3+) x log2(duration / 8192 cycles)
+#ifdef SBL_DBG_IDRET
+// debug build only (tools/diag_case.py): collapses reported and parks per id, summed over the iterations of a stage
+__device__ unsigned g_dbg_ret[1u << 20], g_dbg_park[1u << 20], g_dbg_fin[1u << 20];
+__device__ unsigned g_dbg_log[8u << 20], g_dbg_nlog;      // every collapse: id, round, ret, source element, target element, dS, dT, resumed
+extern "C" unsigned sbl_dbg_log(unsigned *out, unsigned cap)
+{
+	unsigned n = 0;
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_dbg_nlog), 4);
+	if (n > cap) n = cap;
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_log), (size_t)n * 32u);
+	return n;
+}
+extern "C" void sbl_dbg_idret(unsigned *ret, unsigned *park, unsigned *fin, unsigned n, int reset)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(ret, HIP_SYMBOL(g_dbg_ret), n * 4u); (void)hipMemcpyFromSymbol(park, HIP_SYMBOL(g_dbg_park), n * 4u); (void)hipMemcpyFromSymbol(fin, HIP_SYMBOL(g_dbg_fin), n * 4u);
+	if (reset) { static unsigned z[1u << 20]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ret), z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_park), z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_fin), z, sizeof z); }
+}
+#endif
 __device__ unsigned long long g_txn_max[2];        // longest transaction: cycles, (instances << 32) | collapses
 __device__ unsigned long long g_round_max[4096];   // SBL_PHASES=1: per launch of k_commit (slot = round stamp slot / 4), the slowest transaction: (cycles << 24) | min(instances, 255) << 16 | old-form collapses << 8 | collapses
 __device__ unsigned g_old_collapses;
@@ -1174,8 +1194,7 @@ __device__ __forceinline__ int wave_any_bulges(const GraphView &g, Txn &t, Bulge
 #ifndef COMMIT_FAST_BYTES
 #define COMMIT_FAST_BYTES 8192               // LDS scratch of a transaction; with Txn / BulgeWork ~9 KB per workgroup = 17 workgroups per CU (12 KB: 12, and 4 % slower)
 #endif
-// ---- parked transactions (GraphView::park_of): the LDS state of a transaction at the end of its arena slice
-#define PARK_IMG 12288u
+// ---- parked transactions (GraphView::park_of): the LDS state of a transaction at the end of its arena slice (PARK_IMG bytes, bulge_txn.h)
 // The image holds raw LDS addresses (t.fscr, the w.* arrays laid out in `fast`, absh.skey / sval): it is only valid in a kernel that
 // places t, w, absh and fast where the parking kernel had them.  k_commit and k_resume instantiate the same declarations
 // (commit_kernel), so they do; the image records the four addresses and park_load refuses (BT_ERR_LAYOUT) an image from another layout.
@@ -1199,6 +1218,9 @@ __device__ __forceinline__ void park_store(const GraphView &g, Txn &t, BulgeWork
 		unsigned *lay = reinterpret_cast<unsigned *>(image + PARK_OFF_LAYOUT);
 		lay[0] = lds_addr(&t); lay[1] = lds_addr(&w); lay[2] = lds_addr(&absh); lay[3] = lds_addr(fast);
 		g.park_of[id] = (slice + 1u) | (bt_round_tag(g) << 20); g.slice_busy[slice] = 1; g.need[id] = 2; atomicAdd(&g.ctr[CTR_PARKED], 1u);
+#ifdef SBL_DBG_IDRET
+		if (id < (1u << 20)) atomicCAS(&g_dbg_park[id], 0u, ((SS_ROUND_MAX - (g.round_bits >> 20)) << 8) | (w.ret & 255u));      // first park: round, ret
+#endif
 	}
 }
 // ... and back; what belongs to the round (the graph view with its round stamp, the claim stamp) is renewed
@@ -1336,6 +1358,12 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 				park_store(g, t, w, absh, fast, fast_bytes, mine + arena_bytes, id, park_slice);      // (arena_bytes: already without the image)
 				return;                                                    // (no Cleanup, no counters: the transaction is not over)
 			}
+#ifdef SBL_DBG_IDRET
+			if (lane == 0) {
+				const unsigned o = atomicAdd(&g_dbg_nlog, 1u);
+				if (o < (1u << 20)) { unsigned *r = g_dbg_log + (size_t)o * 8u; r[0] = id; r[1] = SS_ROUND_MAX - (g.round_bits >> 20); r[2] = w.ret; r[3] = (g.nslot[w.start[w.c_src] >> 1] << 1) | (w.start[w.c_src] & 1u); r[4] = (g.nslot[w.start[w.c_tgt] >> 1] << 1) | (w.start[w.c_tgt] & 1u); r[5] = w.c_dS; r[6] = w.c_dT; r[7] = RESUME ? 1u : 0u; }
+			}
+#endif
 			if (w.lazy) {
 				wave_collapse_any(g, t, w, lane, stampv, prof);
 				PH_ADD(5);
@@ -1461,6 +1489,9 @@ __device__ __forceinline__ void commit_body(const GraphView &g, Txn &t, BulgeWor
 			atomicOr(&g.ctr[CTR_ERR], t.err);
 		}
 		atomicAdd(&g.ctr[CTR_BULGES], w.ret);
+#ifdef SBL_DBG_IDRET
+		if (id < (1u << 20)) { atomicAdd(&g_dbg_ret[id], w.ret); atomicCAS(&g_dbg_fin[id], 0u, ((SS_ROUND_MAX - (g.round_bits >> 20)) << 8) | (RESUME ? 128u : 0u) | (w.ret & 127u)); }      // first finish: round, resumed, collapses
+#endif
 	}
 }
 

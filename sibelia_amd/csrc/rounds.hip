@@ -307,6 +307,10 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, const VtRef &vt, co
                                          unsigned n, unsigned lane, unsigned id, unsigned tid)
 {
 	const unsigned VT_FILL = 3u << (vt.bits - 2u);                       // three quarters of the slots
+	// A chunk whose marks COULD pass VT_FILL (dozens of instances x dozens of marks: 16 windows of a 62-strain input carry > 384 marks between
+	// them, nearly all of them the same few ids) is inserted under the exact bound instead: the distinct ids so far + the marks of the next
+	// batch of inserts may not pass VT_HARD, 7/8 of the slots (a full table would never end vt_insert's probing).
+	const unsigned VT_HARD = 7u << (vt.bits - 3u);
 	const unsigned k = g.k, D = g.D, ws = D + k + 2u, norig = g.norig;
 	const unsigned nbw = (ws + 126u) >> 6;                                 // blocks a window can touch
 	const unsigned lsh = nbw <= 4u ? 2u : nbw <= 8u ? 3u : nbw <= 16u ? 4u : 99u;
@@ -387,9 +391,15 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, const VtRef &vt, co
 			unsigned long long cm = act && !slow && bit ? mk & vm & idx_bits(1 - t0, (int)upper - t0) : 0ull;
 			unsigned total = (unsigned)__popcll(cm);
 			for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d);
-			if (distinct + total > VT_FILL) return -1;                       // the table could fill up
+			const bool tight = distinct + total > VT_FILL;                   // the table could fill up: count batch by batch
 			const unsigned *__restrict__ marks = g.bif[dir];
 			while (__any(cm != 0ull)) {
+				if (tight) {
+					unsigned nins = (unsigned)__popcll(cm);
+					nins = nins < 4u ? nins : 4u;
+					for (int d = 32; d > 0; d >>= 1) nins += __shfl_xor(nins, d);
+					if (distinct + nins > VT_HARD) return -1;
+				}
 				unsigned sl[4]; bool has[4]; unsigned bb[4];
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
@@ -419,9 +429,9 @@ __device__ __forceinline__ int probe_idx(const GraphView &g, const VtRef &vt, co
 				const char e2 = wd ? bt_comp((char)ww.craw) : (char)ww.craw;
 				const unsigned b2 = e2 == 'A' ? 1u : e2 == 'C' ? 2u : e2 == 'G' ? 4u : 8u;
 				const unsigned lim2 = ww.len < D ? ww.len : D;
-				if (distinct + ww.nm > VT_FILL) return -1;
 				bool found = false;
 				for (unsigned m0 = 0; m0 < ww.nm; m0 += 64) {
+					if (distinct + (ww.nm - m0 < 64u ? ww.nm - m0 : 64u) > VT_HARD) return -1;
 					const unsigned m = m0 + lane;
 					const bool ok = m < ww.nm && mk_step[m] < lim2;
 					found |= vt_insert(vt, ok ? mk_id[m] : BT_NONE, b2, distinct);
@@ -814,7 +824,7 @@ __device__ __forceinline__ void reserve_idx_gather(const GraphView &g, const Rsv
 // The instances of the id are dealt out to the waves of the workgroup (blockDim.x / 64 of them: two where ids have a handful of
 // instances -- 8 strains: 85.0 ms per stage against 86.1 with four and 88.8 with eight -- four where they have dozens, DeviceBackend::rsv_waves).
 __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap,
-                                                                 const unsigned *__restrict__ instbuf, unsigned istride)
+                                                                 const unsigned *__restrict__ instbuf, unsigned istride, const uint8_t *arena, unsigned arena_bytes)
 {
 	const unsigned RSV_WAVES = blockDim.x >> 6;
 	const unsigned w = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -858,6 +868,18 @@ __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, uns
 	RSV_T(0);
 	ClaimList cl; cl.buf = claims + (size_t)w * (CLAIM_CAP + 1); cl.n = &nclaims; cl.seen = seen; cl.sbits = seen_bits;
 	if (wv == 0) wave_claim(g, cl, st, lane == 0 ? id : BT_NONE, lane);
+	// a parked transaction: the ids it has erased instances of keep their list sizes until its Cleanup -- nobody else may read them
+	// meanwhile, and no walk finds them (the marks are gone): claimed from the erase chain of the parked image (bulge_txn.h: PARK_IMG)
+	if (wv == RSV_WAVES - 1u && arena && bt_parked(g, id)) {
+		const unsigned slice = (g.park_of[id] & 0xFFFFFu) - 1u;
+		const Txn *pt = reinterpret_cast<const Txn *>(arena + (size_t)slice * arena_bytes + (arena_bytes - PARK_IMG));
+		unsigned nd = pt->tc_head;                                   // (uniform: every lane follows the chain, lane x keeps the x-th id)
+		while (nd != BT_NONE) {
+			unsigned mine = BT_NONE;
+			for (unsigned x = 0; x < 64u && nd != BT_NONE; x++) { const unsigned v = g.nidst[nd] >> 1; if (lane == x) mine = v; nd = g.nclr[nd]; }
+			wave_claim(g, cl, st, mine, lane);
+		}
+	}
 	unsigned back = g.D + g.k + 2, fwd = 2 * (g.D + g.k + 2) + g.k, core = g.D + 2 * g.k + 3;
 	// Who can interact with an instance: anything marked where the transaction itself reads or writes (core, both
 	// strands) -- claimed exclusively, the instance lists of those ids may be rewritten; instances upstream on the same

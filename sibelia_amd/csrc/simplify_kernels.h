@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_select_write(GraphView g, unsig
                                                               unsigned chunk0, unsigned chunk, unsigned nchunks, volatile unsigned *post, unsigned post_seq);
 __global__ void __launch_bounds__(256) k_pack_probe(const unsigned *__restrict__ ctr, const uint8_t *__restrict__ live, unsigned w0, unsigned w1, unsigned rank, unsigned stride, uint8_t *__restrict__ robuf);
 __global__ void __launch_bounds__(64 * RSV_WAVES_MAX) k_reserve(GraphView g, unsigned nwin, unsigned *claims, const uint8_t *live, unsigned seen_bits, unsigned list_cap,
-                                                                 const unsigned *__restrict__ instbuf, unsigned istride);
+                                                                 const unsigned *__restrict__ instbuf, unsigned istride, const uint8_t *arena, unsigned arena_bytes);
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_commit(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, int solo, const unsigned *claims, const uint8_t *live, int prof);
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_resume(GraphView g, unsigned nwin, uint8_t *arena, unsigned arena_bytes, const unsigned *claims, const uint8_t *live, int prof);
 __global__ void __launch_bounds__(256) k_park_sweep(unsigned *__restrict__ park_of, unsigned n);
