@@ -2,7 +2,8 @@
 """Randomised GPU-vs-oracle stress: python tools/stress.py [seconds] [first_seed]
 Environment: SHARD=n (n virtual ranks), N2=1 (synteny blocks + GlueStripes + reports as well), STAGES=3 (three-stage cascades),
 MANY=1 (30 - 70 strains of a few kbp: ids with dozens of instances, mark lists and AnyBulges tables in the arena),
-LONGK=1 (vertex sizes 33 .. 1500: the fingerprint path of longk_fp.hip, cascades k -> 2k).
+LONGK=1 (vertex sizes 33 .. 1500: the fingerprint path of longk_fp.hip, cascades k -> 2k),
+PARKY=1 (a dozen strains, k 15 - 20, 3 - 8 % SNPs: transactions of several collapses side by side -- where parked transactions meet neighbours).
 A bounded run of the same loop is part of the GPU suite (tests/test_gpu_stress.py)."""
 import os
 import sys
@@ -28,6 +29,11 @@ def draw_case(seed, many=False, stages3=False):
     seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000, 2000])),
                          inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
     stages = [(k, D)] if rng.random() < 0.6 else [(k, D), (int(min(40, k + 5)), D + 50)]
+    if os.environ.get("PARKY"):                                 # multi-collapse transactions side by side: small k, many SNPs, a dozen strains (seed 93194's kind)
+        n, L0 = int(rng.integers(8, 14)), int(rng.integers(15_000, 60_000))
+        k = int(rng.choice([15, 16, 20])); D = int(rng.integers(3 * k, 8 * k)); snp = float(rng.choice([0.03, 0.08]))
+        seqs = W.gen_strains(L0=L0, n=n, seed=seed, snp=snp, indel_every=int(rng.choice([200, 1000])), inv_min=max(50, L0 // 100), inv_max=max(200, L0 // 20))
+        stages = [(k, D)]
     if os.environ.get("LONGK"):                                 # long vertex sizes: k > 32 in every stage
         k = int(rng.choice([33, 40, 64, 100, 127, 128, 200, 333, 512, 700, 1024, 1500]))
         D = int(rng.integers(k + 1, 4 * k + 50))
