@@ -53,3 +53,11 @@ def test_sharded_enumeration_with_three_virtual_ranks_matches_the_oracle():
 
 def test_blocks_and_reports_after_random_stages_match_the_oracle():
     _run("blocks_reports", seed=_first_seed(4_000_000), count=_cases(8), n2=True)
+
+
+def test_transactions_of_several_collapses_side_by_side_match_the_oracle(monkeypatch):
+    """tools/stress.py PARKY=1: a dozen strains, k 15 - 20, 3 - 8 % SNPs -- the regime of seed 93194, where a parked transaction's private
+    list sizes were read by a neighbour (round 6); bulge COUNTS are compared as well as states.  Parked after every collapse."""
+    monkeypatch.setenv("PARKY", "1")
+    monkeypatch.setenv("SBL_PARK", "1")
+    _run("parky", seed=_first_seed(5_000_000), count=_cases(10))
