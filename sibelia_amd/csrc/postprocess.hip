@@ -9,8 +9,9 @@
 #include <climits>
 #include <cstring>
 #include <algorithm>
-#include <sstream>
-#include <iterator>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
 #include <set>
 
 #include "sbl_ctx.h"
@@ -107,86 +108,121 @@ void glue_stripes(std::vector<sbl_block> &block, uint32_t nchr)
 }
 
 struct Records { std::vector<std::string> name; std::vector<uint64_t> size; };
-const std::string kDelimiter(80, '-');                              // DELIMITER, src/util.cpp:9
 
-void list_chrs(const Records &r, std::ostream &out)
-{
-	out << "Seq_id\tSize\tDescription" << std::endl;
-	for (size_t i = 0; i < r.size.size(); i++) out << i + 1 << '\t' << r.size[i] << '\t' << r.name[i] << std::endl;
-	out << kDelimiter << std::endl;
-}
+// ---- the three reports.  The texts are fixed by the files the reference's users parse (blocks_coords.txt, genomes_permutations.txt,
+// coverage_report.txt); they are assembled here as rows of a string with printf conversions -- "%+d" is what the reference's showpos
+// stream prints for a signed block id, "%.2f%%" its fixed two-digit percentage (libstdc++ formats doubles through the same C
+// conversion, NaN included) -- and the coverage of a group of blocks is the length of a union of intervals, not a byte mask per
+// chromosome and row.  Row ORDER is the one part that cannot be chosen: ties of the reference's unstable sorts show in the output, so
+// the same std::sort calls run on the same element order (group_by, then the sort inside each group).
+struct Text {
+	std::string s;
+	void row(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+	{
+		char buf[256];
+		va_list ap;
+		va_start(ap, fmt);
+		const int n = vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		if (n < (int)sizeof buf) { s.append(buf, (size_t)(n > 0 ? n : 0)); return; }
+		std::string big((size_t)n + 1, '\0');
+		va_start(ap, fmt);
+		vsnprintf(&big[0], big.size(), fmt, ap);
+		va_end(ap);
+		s.append(big.data(), (size_t)n);
+	}
+	void rule() { s.append(80, '-'); s += '\n'; }                       // DELIMITER, src/util.cpp:9
+	// the table of records every report but the permutations starts with
+	void records(const Records &r)
+	{
+		s += "Seq_id\tSize\tDescription\n";
+		for (size_t i = 0; i < r.size.size(); i++) { row("%zu\t%llu\t", i + 1, (unsigned long long)r.size[i]); s += r.name[i]; s += '\n'; }
+		rule();
+	}
+};
 
 std::string blocks_coords(const std::vector<sbl_block> &block, const Records &r)
 {
-	std::ostringstream out;
-	list_chrs(r, out);
+	Text t;
+	t.records(r);
 	std::vector<sbl_block> v = block;
 	for (const auto &g : group_by(v, ById())) {
 		std::sort(v.begin() + g.first, v.begin() + g.second, ByChr());
-		out << "Block #" << iabs(v[g.first].id) << std::endl << "Seq_id\tStrand\tStart\tEnd\tLength" << std::endl;
+		t.row("Block #%d\nSeq_id\tStrand\tStart\tEnd\tLength\n", iabs(v[g.first].id));
 		for (size_t i = g.first; i < g.second; i++) {
+			// 1-based, and a reverse-strand instance is reported from its far end (src/blockinstance.cpp:57-75)
 			const sbl_block &b = v[i];
-			// conventional (1-based, strand-aware) coordinates: src/blockinstance.cpp:57-75
-			out << b.chr + 1 << '\t' << (b.id < 0 ? '-' : '+') << '\t' << (b.id > 0 ? b.start + 1 : b.end) << '\t' << (b.id > 0 ? b.end : b.start + 1)
-			    << '\t' << b.end - b.start << "\n";
+			const bool fwd = b.id > 0;
+			const unsigned long long from = fwd ? b.start + 1 : b.end, to = fwd ? b.end : b.start + 1;
+			t.row("%u\t%c\t%llu\t%llu\t%llu\n", b.chr + 1, fwd ? '+' : '-', from, to, (unsigned long long)(b.end - b.start));
 		}
-		out << kDelimiter << std::endl;
+		t.rule();
 	}
-	return out.str();
+	return t.s;
 }
 
 std::string permutations(const std::vector<sbl_block> &block, const Records &r)
 {
-	std::ostringstream out;
+	Text t;
 	std::vector<sbl_block> v = block;
 	for (const auto &g : group_by(v, ByChr())) {
-		out.setf(std::ios_base::showpos);
-		out << '>' << r.name[v[g.first].chr] << std::endl;
+		t.s += '>'; t.s += r.name[v[g.first].chr]; t.s += '\n';
 		std::sort(v.begin() + g.first, v.begin() + g.second, ByChrStart());
-		for (size_t i = g.first; i < g.second; i++) out << v[i].id << " ";
-		out << "$" << std::endl;
+		for (size_t i = g.first; i < g.second; i++) t.row("%+d ", v[i].id);
+		t.s += "$\n";
 	}
-	return out.str();
+	return t.s;
+}
+
+// bases covered by a set of half-open intervals (sorted here)
+uint64_t union_length(std::vector<std::pair<uint64_t, uint64_t>> &iv)
+{
+	std::sort(iv.begin(), iv.end());
+	uint64_t total = 0, reach = 0;
+	for (const auto &x : iv) {
+		const uint64_t lo = x.first > reach ? x.first : reach;
+		if (x.second > lo) { total += x.second - lo; reach = x.second; }
+	}
+	return total;
 }
 
 std::string coverage_report(const std::vector<sbl_block> &block, const Records &r)
 {
-	std::ostringstream out;
+	Text t;
+	const size_t nrec = r.size.size();
 	std::vector<sbl_block> v = block;
-	typedef std::pair<size_t, std::pair<size_t, size_t>> Deg;          // (degree, range of the block's instances in v)
-	std::vector<Deg> byBlock;
-	for (const auto &g : group_by(v, ById())) byBlock.push_back({g.second - g.first, g});
-	list_chrs(r, out);
-	out << "Degree\tCount\tTotal";
-	for (size_t i = 0; i < r.size.size(); i++) out << "\tSeq " << i + 1;
-	out << std::endl;
-	auto groups = group_by(byBlock, [](const Deg &a, const Deg &b) { return a.first < b.first; });
-	groups.push_back({0, byBlock.size()});
-	std::vector<uint8_t> cover;
-	for (size_t gi = 0; gi < groups.size(); gi++) {
-		const auto &g = groups[gi];
-		if (gi + 1 != groups.size()) out << byBlock[g.first].first << '\t' << g.second - g.first << '\t';
-		else out << "All\t" << g.second - g.first << "\t";
-		out.precision(2);
-		out.setf(std::ostream::fixed);
-		std::vector<double> pct;
-		double totalBp = 0, totalCovered = 0;
-		for (size_t c = 0; c < r.size.size(); c++) {
-			totalBp += r.size[c];
-			cover.assign(r.size[c], 0);
-			for (size_t x = g.first; x < g.second; x++)
-				for (size_t i = byBlock[x].second.first; i < byBlock[x].second.second; i++)
-					if (v[i].chr == c) memset(cover.data() + v[i].start, 1, v[i].end - v[i].start);
-			const double covered = (double)std::count(cover.begin(), cover.end(), 1);
-			pct.push_back(covered / cover.size() * 100);
-			totalCovered += covered;
+	// the blocks by degree (number of instances): (degree, first instance in v, one past the last)
+	struct Deg { size_t degree, lo, hi; };
+	std::vector<Deg> blocks;
+	for (const auto &g : group_by(v, ById())) blocks.push_back({g.second - g.first, g.first, g.second});
+	auto rows = group_by(blocks, [](const Deg &a, const Deg &b) { return a.degree < b.degree; });
+	rows.push_back({0, blocks.size()});                                 // the last row: every block
+	t.records(r);
+	t.s += "Degree\tCount\tTotal";
+	for (size_t c = 0; c < nrec; c++) t.row("\tSeq %zu", c + 1);
+	t.s += '\n';
+	std::vector<std::vector<std::pair<uint64_t, uint64_t>>> iv(nrec);
+	for (size_t ri = 0; ri < rows.size(); ri++) {
+		const size_t lo = rows[ri].first, hi = rows[ri].second;
+		if (ri + 1 < rows.size()) t.row("%zu\t%zu\t", blocks[lo].degree, hi - lo);
+		else t.row("All\t%zu\t", hi - lo);
+		for (auto &x : iv) x.clear();
+		for (size_t x = lo; x < hi; x++)
+			for (size_t i = blocks[x].lo; i < blocks[x].hi; i++) iv[v[i].chr].push_back({v[i].start, v[i].end});
+		double all_bases = 0, all_covered = 0;
+		std::vector<double> share(nrec);
+		for (size_t c = 0; c < nrec; c++) {
+			const double covered = (double)union_length(iv[c]);
+			all_bases += (double)r.size[c];
+			all_covered += covered;
+			share[c] = covered / (double)r.size[c] * 100;
 		}
-		pct.insert(pct.begin(), totalCovered / totalBp * 100);
-		std::copy(pct.begin(), pct.end(), std::ostream_iterator<double>(out, "%\t"));
-		out << std::endl;
+		t.row("%.2f%%\t", all_covered / all_bases * 100);
+		for (size_t c = 0; c < nrec; c++) t.row("%.2f%%\t", share[c]);
+		t.s += '\n';
 	}
-	out << kDelimiter << std::endl;
-	return out.str();
+	t.rule();
+	return t.s;
 }
 
 }  // namespace
